@@ -1,0 +1,65 @@
+"""Golden-case definitions shared by make_golden.py and the tests.
+
+A case = recipe for the synthetic inputs + ``Config`` keyword arguments (in the
+reference's constructor units: seconds for ``max_piece_size``; a nested
+``limiter`` dict holds ``LimiterConfig`` keyword arguments)."""
+
+import numpy as np
+
+from matchering_amd.synth import make_pair
+
+CASES = {
+    # CD-rate defaults (F = 4096), several analysis pieces, limiter engaged on ~0.7 % of frames
+    "cd_default": dict(
+        seconds=2.0, reference_seconds=1.7, sample_rate=44100, pair=0,
+        config=dict(max_piece_size=0.45)),
+    # low rate, short FIR, "hot" reference: ~25 % of the frames are limited, odd length
+    "hot_lowrate": dict(
+        seconds=6.0125, reference_seconds=4.9, sample_rate=8000, pair=1, reference_gain=6.0,
+        config=dict(internal_sample_rate=8000, fft_size=512, max_piece_size=1.3)),
+    # reference below the threshold: final amplitude coefficient != 1 (match_levels.py:29-44)
+    "quiet_reference": dict(
+        seconds=3.0, reference_seconds=4.1, sample_rate=22050, pair=2, reference_gain=0.6,
+        config=dict(internal_sample_rate=22050, fft_size=1024, max_piece_size=0.8)),
+    # non-default limiter timing and pipeline knobs
+    "custom_limiter": dict(
+        seconds=1.5, reference_seconds=1.5, sample_rate=48000, pair=3, reference_gain=4.0,
+        config=dict(internal_sample_rate=48000, fft_size=2048, max_piece_size=0.4,
+                    rms_correction_steps=2, lin_log_oversampling=2,
+                    limiter=dict(attack=2.5, hold=3.0, release=1000.0,
+                                 hold_filter_coefficient=11.0, release_filter_coefficient=600.0))),
+    # reference whose peak is one short burst: after peak normalisation its RMS is low, the
+    # result never reaches the threshold and the limiter early-outs (hyrax.py:83-85)
+    "limiter_bypassed": dict(
+        kind="burst_reference", seconds=2.5, reference_seconds=2.0, sample_rate=16000, pair=4,
+        reference_gain=0.5,
+        config=dict(internal_sample_rate=16000, fft_size=1024, max_piece_size=0.7)),
+}
+
+
+def build_inputs(case):
+    sr = case["sample_rate"]
+    target, reference = make_pair(
+        case["seconds"], sr, case["pair"], reference_seconds=case.get("reference_seconds"),
+        reference_gain=case.get("reference_gain", 2.5))
+    if case.get("kind") == "burst_reference":
+        n = reference.shape[0]
+        reference = reference.copy()
+        reference[n // 2 : n // 2 + int(0.02 * sr)] *= 4.0
+    return target, reference
+
+
+def oracle_params(cfg_kwargs):
+    import mastering_oracle as mo
+
+    kw = dict(cfg_kwargs)
+    kw.update(kw.pop("limiter", {}))
+    return mo.params(**kw)
+
+
+def sparse_index(n):
+    """Frames kept in float64: both edges (filter edge effects live there) and
+    every 13th frame in between."""
+    edge = min(3000, n // 3)
+    return np.unique(np.concatenate((np.arange(edge), np.arange(edge, n - edge, 13),
+                                     np.arange(n - edge, n))))
