@@ -1,0 +1,166 @@
+/* mgx -- C ABI of the MI355X-native mastering core.
+ *
+ * sergree/matchering is pure Python: it has no FFI of its own.  The functions
+ * below are the boundary a maintainer would bind (ctypes stub in INTEGRATION.md)
+ * to replace the body of matchering/stages.py:210-272 (`main`) and, one level
+ * down, the stage helpers it calls.  Each entry point cites the reference
+ * interface it replaces.  Plain pointers and sizes only; no framework types.
+ *
+ * Conventions
+ *  - audio is float32, interleaved stereo frames (n,2) -- numpy C order, the
+ *    layout soundfile hands to matchering/loader.py:35.
+ *  - "dev" pointers are device (HBM) addresses obtained from mgx_malloc; "host"
+ *    pointers are ordinary memory.  Nothing is freed or retained across calls
+ *    except through the handle.
+ *  - every function returns 0 on success, a negative mgx_status otherwise;
+ *    mgx_last_error() gives the message (thread-local).
+ *  - a handle is bound to one GPU and one HIP stream; calls on one handle are
+ *    serialised by the caller, different handles are independent.
+ */
+#ifndef MGX_H
+#define MGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgx_handle mgx_handle;
+
+enum mgx_status {
+    MGX_OK = 0,
+    MGX_ERR_ARGUMENT = -1,     /* bad size / null pointer / unsupported parameter */
+    MGX_ERR_HIP = -2,          /* HIP runtime error (message has the hipError name) */
+    MGX_ERR_NO_DEVICE = -3,    /* no usable GPU: there is NO CPU fallback */
+    MGX_ERR_UNSUPPORTED = -4,  /* valid for the reference but not implemented here */
+    MGX_ERR_RCCL = -5
+};
+
+/* matchering/defaults.py:25-58 LimiterConfig + :61-155 Config, the fields the
+ * hot path consumes.  max_piece_size is in SAMPLES (defaults.py:109 already
+ * multiplied it by the sample rate). */
+typedef struct mgx_config {
+    int32_t internal_sample_rate;
+    int32_t fft_size;
+    int32_t lin_log_oversampling;
+    int32_t rms_correction_steps;
+    double max_piece_size;
+    double threshold;
+    double min_value;
+    double lowess_frac;
+    int32_t lowess_it;
+    int32_t reserved0;
+    double lowess_delta;
+    /* limiter */
+    double attack_ms, hold_ms, release_ms;
+    double attack_filter_coefficient;
+    int32_t hold_filter_order;
+    int32_t release_filter_order;
+    double hold_filter_coefficient;
+    double release_filter_coefficient;
+} mgx_config;
+
+/* Scalars that flow between the stages of stages.py:210-272 (what the reference
+ * logs through debug()).  Filled by mgx_master / the stage calls. */
+typedef struct mgx_report {
+    double final_amplitude_coefficient;  /* match_levels.py:29-44 */
+    double target_match_rms, reference_match_rms;
+    double rms_coefficient;              /* stages.py:80-88 */
+    double correction_coefficients[16];  /* stages.py:149-168, first rms_correction_steps entries */
+    double normalize_coefficient;        /* stages.py:186-191 (0 when not requested) */
+    double result_peak;                  /* max |result_no_limiter| */
+    int32_t target_divisions, reference_divisions;
+    int64_t target_piece, reference_piece;
+    int32_t target_loud_count, reference_loud_count;
+    int32_t limiter_active;              /* 0 = hyrax.py:83-85 early-out */
+    int32_t reserved;
+} mgx_report;
+
+/* ---- library / device ---------------------------------------------------- */
+int mgx_version(void);
+const char* mgx_last_error(void);
+int mgx_device_count(int* count);
+int mgx_create(int device, mgx_handle** out);
+int mgx_destroy(mgx_handle* h);
+int mgx_config_default(mgx_config* cfg);         /* Config() defaults, defaults.py:61-84 */
+
+/* device memory + transfers (the Python host has no other way to hold HBM) */
+int mgx_malloc(mgx_handle* h, size_t bytes, void** dev);
+int mgx_free(mgx_handle* h, void* dev);
+int mgx_memcpy_h2d(mgx_handle* h, void* dev, const void* host, size_t bytes);
+int mgx_memcpy_d2h(mgx_handle* h, void* host, const void* dev, size_t bytes);
+int mgx_synchronize(mgx_handle* h);
+/* HIP-event timing on the handle's stream: bracket any sequence of calls */
+int mgx_timer_start(mgx_handle* h);
+int mgx_timer_stop(mgx_handle* h, float* milliseconds);
+
+/* ---- the drop-in boundary: stages.main ------------------------------------ */
+/* Replaces matchering/stages.py:210-272 `main(target, reference, config,
+ * need_default, need_no_limiter, need_no_limiter_normalized)`.  target_dev /
+ * reference_dev: (n,2) float32 in HBM.  Each non-null output receives (n_target,2)
+ * float32 in HBM; a null output = the corresponding need_* flag False.  Inputs
+ * are not modified.  Asynchronous on the handle's stream except for one host
+ * round trip for the FIR design; report (host, may be null) is valid after
+ * mgx_synchronize. */
+int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target,
+               const float* reference_dev, int64_t n_reference, const mgx_config* cfg,
+               float* result_dev, float* result_no_limiter_dev,
+               float* result_no_limiter_normalized_dev, mgx_report* report);
+
+/* ---- stage-level entry points (parity tests, custom pipelines) ------------- */
+/* match_levels.py:134-161 analyze_levels (+ dsp.py:93-100 peak for the reference,
+ * match_levels.py:29-44) and match_frequencies.py:30-42 __average_fft of the loud
+ * pieces, in one pass.  Host outputs (any may be null): piece_rms[divisions],
+ * loud[divisions] (0/1), avg_mid/avg_side[fft_size/2+1] = mean |rfft|/F over the
+ * loud pieces of the (peak-normalised, if is_reference) track. */
+int mgx_analyze(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cfg,
+                int is_reference, double* peak, double* amplitude_coefficient,
+                double* match_rms, int32_t* divisions, int64_t* piece_size,
+                double* piece_rms, int32_t* loud, double* avg_mid, double* avg_side);
+
+/* match_frequencies.py:78-101 get_fir from averaged spectra (host, float64).
+ * avg_target must already include the level gain of stages.py:90-91.  Pure host
+ * code: works without a GPU. */
+int mgx_design_fir(const mgx_config* cfg, const double* avg_target, const double* avg_reference,
+                   double* taps, double* curve_raw, double* curve_smooth);
+
+/* match_frequencies.py:104-119 convolve (fftconvolve "same" on mid and side,
+ * then ms_to_lr): y = L/R result (n,2), y_mid (n) optional.  taps are host
+ * float64 arrays of fft_size entries; `gain` scales both (stages.py:80-88 folded in). */
+int mgx_convolve(mgx_handle* h, const float* x_dev, int64_t n, const double* fir_mid,
+                 const double* fir_side, int32_t taps, double gain, float* y_dev, float* y_mid_dev,
+                 double* peak);
+
+/* Measurement aid for bench.py: the same convolution launched `iters` times back to
+ * back with HIP events around the k_conv launches only (filter preparation excluded);
+ * *ms_per_launch = average duration of one launch. */
+int mgx_convolve_timed(mgx_handle* h, const float* x_dev, int64_t n, const double* fir_mid,
+                       const double* fir_side, int32_t taps, double gain, float* y_dev,
+                       float* y_mid_dev, int32_t iters, float* ms_per_launch);
+
+/* One round of stages.py:149-160: piece RMS of clip(gain*mid, -1, 1) over the
+ * target's piece grid.  Host output sumsq[divisions] = sum of squares per piece. */
+int mgx_clipped_piece_sumsq(mgx_handle* h, const float* mid_dev, int64_t n, int64_t piece_size,
+                            int32_t divisions, double gain, double* sumsq);
+
+/* limiter/hyrax.py:78-99 limit(array*gain) * post_gain, float32 in/out in HBM.
+ * active (host, may be null) receives 0 when the limiter early-outs. */
+int mgx_limit(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cfg, double gain,
+              double post_gain, float* out_dev, int32_t* active);
+
+/* dsp.py:89-90 amplify on interleaved frames: out = x * gain */
+int mgx_scale(mgx_handle* h, const float* x_dev, int64_t n, double gain, float* out_dev);
+
+/* ---- multi-GPU: one process per GPU, FIR taps over RCCL/xGMI ---------------- */
+int mgx_comm_unique_id(void* id128);                                  /* ncclGetUniqueId, 128 bytes */
+int mgx_comm_init(mgx_handle* h, const void* id128, int rank, int world);
+int mgx_comm_broadcast_f32(mgx_handle* h, float* dev, int64_t count, int root);
+int mgx_comm_allgather_f32(mgx_handle* h, const float* send_dev, float* recv_dev, int64_t count);
+int mgx_comm_destroy(mgx_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H */

@@ -1,0 +1,32 @@
+"""Build matchering_amd/libmgx.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libmgx.so")
+SOURCES = [os.path.join(CSRC, "mgx.hip"), os.path.join(CSRC, "fir_design.cpp")]
+
+
+def _deps():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(os.path.dirname(HERE), "include", "mgx.h"))
+    return deps
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP library in-tree.  Returns the path of the shared object."""
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in _deps()):
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+           "-Wno-unused-result", "-Wno-unused-value", "-o", OUT] + SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose="-v" in sys.argv))

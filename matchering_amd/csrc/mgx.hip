@@ -1,0 +1,721 @@
+// libmgx.so -- C ABI (include/mgx.h) over the gfx950 kernels.  No CPU fallback:
+// every entry point that needs a GPU fails with MGX_ERR_NO_DEVICE / MGX_ERR_HIP.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mgx.h"
+#include "fir_design.h"
+#include "host_params.h"
+#include "mgx_kernels.h"
+
+using namespace mgx;
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_error;
+static int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(MGX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorName(e_) + " (" + \
+                                         hipGetErrorString(e_) + ")");                        \
+    } while (0)
+#define MGX_TRY(expr)          \
+    do {                       \
+        int rc_ = (expr);      \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+#define NCCL_TRY(expr)                                                                       \
+    do {                                                                                     \
+        ncclResult_t r_ = (expr);                                                            \
+        if (r_ != ncclSuccess)                                                               \
+            return fail(MGX_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));   \
+    } while (0)
+
+// ---------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct TrackWork {              // per-track analysis workspace + results (device)
+    DevBuf wg_sumsq, wg_peak, wg_spec, stats, rms, loud, avg;   // avg: [2][F/2+1] double
+    int divisions = 0, segs_per_piece = 0, segs_per_wg = 0, chunks = 0;
+    long long piece = 0;
+};
+
+struct mgx_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<int, float2*> twiddles;
+    TrackWork track[2];
+    DevBuf y, mid, block_peak, fa, fc, taps, partial, cstate, scalars;
+    DevBuf lim_agg, lim_carry, lim_edge;
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+};
+
+static int ensure(mgx_handle* h, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return 0;
+    if (b.p) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    const size_t want = std::max(bytes, (size_t)256);
+    HIP_TRY(hipMalloc(&b.p, want));
+    b.bytes = want;
+    return 0;
+}
+static int ensure_pinned(mgx_handle* h, size_t bytes) {
+    if (h->pinned_bytes >= bytes) return 0;
+    if (h->pinned) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipHostFree(h->pinned));
+        h->pinned = nullptr;
+        h->pinned_bytes = 0;
+    }
+    HIP_TRY(hipHostMalloc(&h->pinned, bytes, hipHostMallocDefault));
+    h->pinned_bytes = bytes;
+    return 0;
+}
+
+static int get_twiddles(mgx_handle* h, int log2n, const float2** out) {
+    auto it = h->twiddles.find(log2n);
+    if (it != h->twiddles.end()) {
+        *out = it->second;
+        return 0;
+    }
+    const int n = 1 << log2n;
+    std::vector<float2> tw(n);
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k < n; ++k)
+        tw[k] = make_float2((float)std::cos(2.0 * pi * k / n), (float)-std::sin(2.0 * pi * k / n));
+    float2* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, n * sizeof(float2)));
+    HIP_TRY(hipMemcpy(d, tw.data(), n * sizeof(float2), hipMemcpyHostToDevice));
+    h->twiddles[log2n] = d;
+    *out = d;
+    return 0;
+}
+
+template <typename K>
+static int allow_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+static int check_config(const mgx_config* c) {
+    if (!c) return fail(MGX_ERR_ARGUMENT, "config is null");
+    if (c->internal_sample_rate <= 0) return fail(MGX_ERR_ARGUMENT, "internal_sample_rate must be positive");
+    if (ilog2_exact(c->fft_size) < 0) return fail(MGX_ERR_ARGUMENT, "fft_size must be a power of two");
+    if (c->fft_size < 64 || c->fft_size > 8192)
+        return fail(MGX_ERR_UNSUPPORTED, "fft_size outside [64, 8192] is not implemented "
+                                         "(the overlap-save block 2*fft_size must fit one CU's LDS)");
+    if (c->rms_correction_steps < 0 || c->rms_correction_steps > 16)
+        return fail(MGX_ERR_UNSUPPORTED, "rms_correction_steps outside [0, 16]");
+    if (c->lowess_it != 0) return fail(MGX_ERR_UNSUPPORTED, "lowess_it != 0 is not implemented");
+    if (!(c->threshold > c->min_value && c->threshold < 1.0 && c->min_value > 0.0))
+        return fail(MGX_ERR_ARGUMENT, "threshold/min_value out of range (defaults.py:93-99)");
+    if (!(c->max_piece_size > c->fft_size)) return fail(MGX_ERR_ARGUMENT, "max_piece_size must exceed fft_size samples");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// stage runners (asynchronous on h->stream)
+// ---------------------------------------------------------------------------
+template <int LOG2N>
+static int launch_analysis(mgx_handle* h, const AnalysisArgs& a, int nwg) {
+    const size_t lds = analysis_lds_bytes<LOG2N>();
+    MGX_TRY(allow_lds(k_analyze<LOG2N>, lds));
+    hipLaunchKernelGGL(k_analyze<LOG2N>, dim3(nwg), dim3(Fft<LOG2N>::T), lds, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int run_analysis(mgx_handle* h, const float* x, long long n, const mgx_config* cfg, int is_reference,
+                        TrackWork& w) {
+    const int f = cfg->fft_size, half = f / 2;
+    if (n <= f) return fail(MGX_ERR_ARGUMENT, "track must be longer than fft_size frames (core.py:69-74)");
+    piece_geometry(n, cfg->max_piece_size, w.divisions, w.piece);
+    w.segs_per_piece = (int)(w.piece / f);
+    if (w.segs_per_piece < 1)
+        return fail(MGX_ERR_UNSUPPORTED, "analysis pieces shorter than fft_size are not implemented");
+    const int want_chunks = std::min(w.segs_per_piece, std::max(1, (1536 + w.divisions - 1) / w.divisions));
+    w.segs_per_wg = (w.segs_per_piece + want_chunks - 1) / want_chunks;
+    w.chunks = (w.segs_per_piece + w.segs_per_wg - 1) / w.segs_per_wg;
+    const int nwg = w.divisions * w.chunks;
+    MGX_TRY(ensure(h, w.wg_sumsq, (size_t)nwg * sizeof(double)));
+    MGX_TRY(ensure(h, w.wg_peak, (size_t)nwg * sizeof(float)));
+    MGX_TRY(ensure(h, w.wg_spec, (size_t)nwg * 2 * (half + 1) * sizeof(float)));
+    MGX_TRY(ensure(h, w.stats, sizeof(TrackStats)));
+    MGX_TRY(ensure(h, w.rms, (size_t)w.divisions * sizeof(double)));
+    MGX_TRY(ensure(h, w.loud, (size_t)w.divisions * sizeof(int)));
+    MGX_TRY(ensure(h, w.avg, (size_t)2 * (half + 1) * sizeof(double)));
+    AnalysisArgs a;
+    a.x = reinterpret_cast<const float2*>(x);
+    a.n = n;
+    a.fft = f;
+    a.piece = w.piece;
+    a.divisions = w.divisions;
+    a.segs_per_piece = w.segs_per_piece;
+    a.segs_per_wg = w.segs_per_wg;
+    a.chunks_per_piece = w.chunks;
+    a.wg_sumsq = (double*)w.wg_sumsq.p;
+    a.wg_peak = (float*)w.wg_peak.p;
+    a.wg_spec = (float*)w.wg_spec.p;
+    const int l = ilog2_exact(f);
+    MGX_TRY(get_twiddles(h, l, &a.tw));
+    switch (l) {
+#define CASE(L) case L: MGX_TRY(launch_analysis<L>(h, a, nwg)); break;
+        CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
+#undef CASE
+        default: return fail(MGX_ERR_UNSUPPORTED, "fft_size not supported by the analysis kernel");
+    }
+    const size_t lds = (size_t)(64 + w.divisions) * sizeof(double);
+    if (lds > 150 * 1024) return fail(MGX_ERR_UNSUPPORTED, "too many analysis pieces");
+    MGX_TRY(allow_lds(k_levels, lds));
+    hipLaunchKernelGGL(k_levels, dim3(1), dim3(1024), lds, h->stream, (const double*)w.wg_sumsq.p,
+                       (const float*)w.wg_peak.p, w.chunks, w.divisions, w.piece, is_reference, cfg->threshold,
+                       cfg->min_value, (TrackStats*)w.stats.p, (double*)w.rms.p, (int*)w.loud.p);
+    HIP_TRY(hipGetLastError());
+    const int total = 2 * (half + 1);
+    hipLaunchKernelGGL(k_average_spectra, dim3((total + 255) / 256), dim3(256), 0, h->stream,
+                       (const float*)w.wg_spec.p, (const int*)w.loud.p, (const TrackStats*)w.stats.p, w.chunks,
+                       w.divisions, w.segs_per_piece, f, (double*)w.avg.p, (double*)w.avg.p + (half + 1));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int LOG2N>
+static int launch_conv(mgx_handle* h, ConvArgs a, const float* taps_mid, const float* taps_side, double gain,
+                       int repeat) {
+    const size_t lds = conv_lds_bytes<LOG2N>();
+    MGX_TRY(allow_lds(k_conv_prep<LOG2N>, lds));
+    MGX_TRY(allow_lds(k_conv<LOG2N>, lds));
+    hipLaunchKernelGGL(k_conv_prep<LOG2N>, dim3(1), dim3(Fft<LOG2N>::T), lds, h->stream, taps_mid, taps_side,
+                       a.taps, a.tw, (float2*)h->fa.p, (float2*)h->fc.p, (const double*)nullptr, gain);
+    HIP_TRY(hipGetLastError());
+    const long long lout = ConvBlock<LOG2N>::lout(a.taps);
+    a.nblocks = (a.n + lout - 1) / lout;
+    MGX_TRY(ensure(h, h->block_peak, (size_t)a.nblocks * sizeof(float)));
+    a.block_peak = (float*)h->block_peak.p;
+    const unsigned grid = (unsigned)std::min<long long>(a.nblocks, 1 << 20);
+    if (repeat > 1) HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    for (int r = 0; r < repeat; ++r)
+        hipLaunchKernelGGL(k_conv<LOG2N>, dim3(grid), dim3(Fft<LOG2N>::T), lds, h->stream, a);
+    if (repeat > 1) HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// taps_dev: [2][F] float (mid then side) already on the device
+static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const float* taps_dev, double gain,
+                    float* y, float* ymid, long long* nblocks_out, int repeat = 1) {
+    const int l = ilog2_exact(taps);
+    if (l < 0) return fail(MGX_ERR_ARGUMENT, "FIR length must be a power of two");
+    const int log2b = l + 1;
+    const size_t nb = (size_t)1 << log2b;
+    MGX_TRY(ensure(h, h->fa, nb * sizeof(float2)));
+    MGX_TRY(ensure(h, h->fc, nb * sizeof(float2)));
+    ConvArgs a;
+    a.x = reinterpret_cast<const float2*>(x);
+    a.n = n;
+    a.y = reinterpret_cast<float2*>(y);
+    a.ymid = ymid;
+    a.fa = (const float2*)h->fa.p;
+    a.fc = (const float2*)h->fc.p;
+    a.taps = taps;
+    a.nblocks = 0;
+    a.block_peak = nullptr;
+    MGX_TRY(get_twiddles(h, log2b, &a.tw));
+    const long long lout = ((long long)1 << log2b) - taps + 1;
+    if (nblocks_out) *nblocks_out = (n + lout - 1) / lout;
+    switch (log2b) {
+#define CASE(L) case L: return launch_conv<L>(h, a, taps_dev, taps_dev + taps, gain, repeat);
+        CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+#undef CASE
+        default: return fail(MGX_ERR_UNSUPPORTED, "FIR length not supported by the convolution kernel");
+    }
+}
+
+static int clipped_chunks(int divisions) { return std::max(1, std::min(1024, (2048 + divisions - 1) / divisions)); }
+
+static int run_clipped_sumsq(mgx_handle* h, const float* mid, long long piece, int divisions,
+                             const double* gain_ptr, double gain_mul, int* chunks_out) {
+    const int chunks = clipped_chunks(divisions);
+    MGX_TRY(ensure(h, h->partial, (size_t)divisions * chunks * sizeof(double)));
+    hipLaunchKernelGGL(k_clipped_sumsq, dim3(divisions * chunks), dim3(256), 0, h->stream, mid, piece, chunks,
+                       gain_ptr, gain_mul, (double*)h->partial.p);
+    HIP_TRY(hipGetLastError());
+    if (chunks_out) *chunks_out = chunks;
+    return 0;
+}
+
+static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_config* cfg, const double* gain_dev,
+                       const double* post_dev, const int* active_dev, float* out) {
+    LimiterParams lp;
+    const std::string err = limiter_params(*cfg, lp);
+    if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
+    if (n < 8) return fail(MGX_ERR_ARGUMENT, "limiter input too short");
+    const LimiterBlock::Geometry geo = LimiterBlock::geometry(lp.hw, lp.hb);
+    LimiterArgs a;
+    a.y = reinterpret_cast<const float2*>(y);
+    a.n = n;
+    a.out = reinterpret_cast<float2*>(out);
+    a.gain = gain_dev;
+    a.post_gain = post_dev;
+    a.active = active_dev;
+    a.threshold = (float)cfg->threshold;
+    a.hw = lp.hw;
+    a.hb = lp.hb;
+    a.att = lp.att;
+    a.hold = lp.hold_f;
+    a.rel = lp.rel_f;
+    a.nchunks = (n + geo.chunk - 1) / geo.chunk;
+    MGX_TRY(ensure(h, h->lim_agg, (size_t)4 * a.nchunks * sizeof(Affine)));
+    MGX_TRY(ensure(h, h->lim_carry, (size_t)4 * a.nchunks * sizeof(double)));
+    MGX_TRY(ensure(h, h->lim_edge, 128));
+    a.agg = (Affine*)h->lim_agg.p;
+    a.carry = (double*)h->lim_carry.p;
+    a.edge_sl = (float*)h->lim_edge.p;
+    a.edge_state = (double*)((char*)h->lim_edge.p + 64);
+    const size_t lds = LimiterBlock::LDS_BYTES, lds_scan = ChunkScan::LDS_BYTES;
+    const dim3 grid((unsigned)a.nchunks), block(LimiterBlock::T);
+    hipLaunchKernelGGL(k_limit<1>, grid, block, lds, h->stream, a);
+    hipLaunchKernelGGL(k_limit_scan<1>, dim3(1), dim3(ChunkScan::T), lds_scan, h->stream, a);
+    hipLaunchKernelGGL(k_limit<2>, grid, block, lds, h->stream, a);
+    hipLaunchKernelGGL(k_limit_scan<2>, dim3(1), dim3(ChunkScan::T), lds_scan, h->stream, a);
+    hipLaunchKernelGGL(k_limit<3>, grid, block, lds, h->stream, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int mgx_version(void) { return 100; }
+const char* mgx_last_error(void) { return g_error.c_str(); }
+
+int mgx_device_count(int* count) {
+    if (!count) return fail(MGX_ERR_ARGUMENT, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(MGX_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorName(e));
+    }
+    *count = n;
+    return 0;
+}
+
+int mgx_config_default(mgx_config* c) {
+    if (!c) return fail(MGX_ERR_ARGUMENT, "config is null");
+    std::memset(c, 0, sizeof(*c));
+    c->internal_sample_rate = 44100;
+    c->fft_size = 4096;
+    c->lin_log_oversampling = 4;
+    c->rms_correction_steps = 4;
+    c->max_piece_size = 15.0 * 44100;
+    c->threshold = (32768.0 - 61.0) / 32768.0;
+    c->min_value = 1e-6;
+    c->lowess_frac = 0.0375;
+    c->lowess_it = 0;
+    c->lowess_delta = 0.001;
+    c->attack_ms = 1.0;
+    c->hold_ms = 1.0;
+    c->release_ms = 3000.0;
+    c->attack_filter_coefficient = -2.0;
+    c->hold_filter_order = 1;
+    c->release_filter_order = 1;
+    c->hold_filter_coefficient = 7.0;
+    c->release_filter_coefficient = 800.0;
+    return 0;
+}
+
+int mgx_create(int device, mgx_handle** out) {
+    if (!out) return fail(MGX_ERR_ARGUMENT, "out is null");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MGX_ERR_NO_DEVICE, "no HIP device visible: matchering_amd has no CPU fallback");
+    if (device < 0 || device >= n) return fail(MGX_ERR_ARGUMENT, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    mgx_handle* h = new mgx_handle();
+    h->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+    *out = h;
+    return 0;
+}
+
+int mgx_destroy(mgx_handle* h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    if (h->comm) ncclCommDestroy(h->comm);
+    DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->fa, &h->fc, &h->taps, &h->partial, &h->cstate,
+                      &h->scalars, &h->lim_agg, &h->lim_carry, &h->lim_edge};
+    for (DevBuf* b : bufs)
+        if (b->p) hipFree(b->p);
+    for (TrackWork& w : h->track) {
+        DevBuf* tb[] = {&w.wg_sumsq, &w.wg_peak, &w.wg_spec, &w.stats, &w.rms, &w.loud, &w.avg};
+        for (DevBuf* b : tb)
+            if (b->p) hipFree(b->p);
+    }
+    for (auto& kv : h->twiddles) hipFree(kv.second);
+    if (h->pinned) hipHostFree(h->pinned);
+    hipEventDestroy(h->ev0);
+    hipEventDestroy(h->ev1);
+    hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int mgx_malloc(mgx_handle* h, size_t bytes, void** dev) {
+    if (!h || !dev) return fail(MGX_ERR_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipMalloc(dev, bytes ? bytes : 256));
+    return 0;
+}
+int mgx_free(mgx_handle* h, void* dev) {
+    if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
+    if (!dev) return 0;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(dev));
+    return 0;
+}
+int mgx_memcpy_h2d(mgx_handle* h, void* dev, const void* host, size_t bytes) {
+    if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
+    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int mgx_memcpy_d2h(mgx_handle* h, void* host, const void* dev, size_t bytes) {
+    if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int mgx_synchronize(mgx_handle* h) {
+    if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return 0;
+}
+int mgx_timer_start(mgx_handle* h) {
+    if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    return 0;
+}
+int mgx_timer_stop(mgx_handle* h, float* ms) {
+    if (!h || !ms) return fail(MGX_ERR_ARGUMENT, "null argument");
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return 0;
+}
+
+// ---- stage level -----------------------------------------------------------
+int mgx_analyze(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cfg, int is_reference,
+                double* peak, double* amplitude_coefficient, double* match_rms, int32_t* divisions,
+                int64_t* piece_size, double* piece_rms, int32_t* loud, double* avg_mid, double* avg_side) {
+    if (!h || !x_dev) return fail(MGX_ERR_ARGUMENT, "null argument");
+    MGX_TRY(check_config(cfg));
+    HIP_TRY(hipSetDevice(h->device));
+    TrackWork& w = h->track[is_reference ? 1 : 0];
+    MGX_TRY(run_analysis(h, x_dev, n, cfg, is_reference, w));
+    TrackStats st;
+    HIP_TRY(hipMemcpyAsync(&st, w.stats.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int half = cfg->fft_size / 2;
+    if (peak) *peak = st.peak;
+    if (amplitude_coefficient) *amplitude_coefficient = st.amplitude_c;
+    if (match_rms) *match_rms = st.match_rms;
+    if (divisions) *divisions = w.divisions;
+    if (piece_size) *piece_size = w.piece;
+    if (piece_rms) HIP_TRY(hipMemcpy(piece_rms, w.rms.p, w.divisions * sizeof(double), hipMemcpyDeviceToHost));
+    if (loud) HIP_TRY(hipMemcpy(loud, w.loud.p, w.divisions * sizeof(int), hipMemcpyDeviceToHost));
+    if (avg_mid) HIP_TRY(hipMemcpy(avg_mid, w.avg.p, (half + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    if (avg_side)
+        HIP_TRY(hipMemcpy(avg_side, (double*)w.avg.p + (half + 1), (half + 1) * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int mgx_design_fir(const mgx_config* cfg, const double* avg_target, const double* avg_reference, double* taps,
+                   double* curve_raw, double* curve_smooth) {
+    if (!cfg || !avg_target || !avg_reference || !taps) return fail(MGX_ERR_ARGUMENT, "null argument");
+    if (ilog2_exact(cfg->fft_size) < 0 || cfg->fft_size < 8) return fail(MGX_ERR_ARGUMENT, "bad fft_size");
+    if (cfg->lowess_it != 0) return fail(MGX_ERR_UNSUPPORTED, "lowess_it != 0 is not implemented");
+    FirDesignParams p{cfg->fft_size, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac,
+                      cfg->lowess_it, cfg->lowess_delta, cfg->min_value};
+    design_fir(avg_target, avg_reference, p, taps, curve_raw, curve_smooth);
+    return 0;
+}
+
+static int upload_taps(mgx_handle* h, const double* fir_mid, const double* fir_side, int taps) {
+    MGX_TRY(ensure(h, h->taps, (size_t)2 * taps * sizeof(float)));
+    MGX_TRY(ensure_pinned(h, std::max((size_t)2 * taps * sizeof(float), (size_t)1 << 16)));
+    float* st = (float*)h->pinned;
+    for (int i = 0; i < taps; ++i) {
+        st[i] = (float)fir_mid[i];
+        st[taps + i] = (float)fir_side[i];
+    }
+    HIP_TRY(hipMemcpyAsync(h->taps.p, st, (size_t)2 * taps * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+
+int mgx_convolve(mgx_handle* h, const float* x_dev, int64_t n, const double* fir_mid, const double* fir_side,
+                 int32_t taps, double gain, float* y_dev, float* y_mid_dev, double* peak) {
+    if (!h || !x_dev || !fir_mid || !fir_side || !y_dev) return fail(MGX_ERR_ARGUMENT, "null argument");
+    if (n <= 0) return fail(MGX_ERR_ARGUMENT, "empty input");
+    HIP_TRY(hipSetDevice(h->device));
+    MGX_TRY(upload_taps(h, fir_mid, fir_side, taps));
+    long long nblocks = 0;
+    MGX_TRY(run_conv(h, x_dev, n, taps, (const float*)h->taps.p, gain, y_dev, y_mid_dev, &nblocks));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (peak) {
+        std::vector<float> bp(nblocks);
+        HIP_TRY(hipMemcpy(bp.data(), h->block_peak.p, nblocks * sizeof(float), hipMemcpyDeviceToHost));
+        float m = 0.f;
+        for (float v : bp) m = std::max(m, v);
+        *peak = m;
+    }
+    return 0;
+}
+
+int mgx_convolve_timed(mgx_handle* h, const float* x_dev, int64_t n, const double* fir_mid, const double* fir_side,
+                       int32_t taps, double gain, float* y_dev, float* y_mid_dev, int32_t iters,
+                       float* ms_per_launch) {
+    if (!h || !x_dev || !fir_mid || !fir_side || !y_dev || !ms_per_launch || iters < 2)
+        return fail(MGX_ERR_ARGUMENT, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    MGX_TRY(upload_taps(h, fir_mid, fir_side, taps));
+    MGX_TRY(run_conv(h, x_dev, n, taps, (const float*)h->taps.p, gain, y_dev, y_mid_dev, nullptr, iters));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *ms_per_launch = ms / iters;
+    return 0;
+}
+
+int mgx_clipped_piece_sumsq(mgx_handle* h, const float* mid_dev, int64_t n, int64_t piece_size, int32_t divisions,
+                            double gain, double* sumsq) {
+    if (!h || !mid_dev || !sumsq) return fail(MGX_ERR_ARGUMENT, "null argument");
+    if (piece_size <= 0 || divisions <= 0 || piece_size * divisions > n)
+        return fail(MGX_ERR_ARGUMENT, "piece grid does not fit the array");
+    HIP_TRY(hipSetDevice(h->device));
+    int chunks = 0;
+    MGX_TRY(run_clipped_sumsq(h, mid_dev, piece_size, divisions, nullptr, gain, &chunks));
+    std::vector<double> part((size_t)divisions * chunks);
+    HIP_TRY(hipMemcpyAsync(part.data(), h->partial.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int d = 0; d < divisions; ++d) {
+        double s = 0.0;
+        for (int c = 0; c < chunks; ++c) s += part[(size_t)d * chunks + c];
+        sumsq[d] = s;
+    }
+    return 0;
+}
+
+int mgx_limit(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cfg, double gain, double post_gain,
+              float* out_dev, int32_t* active) {
+    if (!h || !x_dev || !out_dev) return fail(MGX_ERR_ARGUMENT, "null argument");
+    MGX_TRY(check_config(cfg));
+    HIP_TRY(hipSetDevice(h->device));
+    // peak -> early-out decision, through the same kernels the pipeline uses
+    MGX_TRY(ensure(h, h->cstate, sizeof(CorrectionState)));
+    MGX_TRY(ensure(h, h->scalars, 64));
+    MGX_TRY(ensure_pinned(h, 1 << 16));
+    CorrectionState* cs = (CorrectionState*)h->cstate.p;
+    hipLaunchKernelGGL(k_correction_init, dim3(1), dim3(1), 0, h->stream, cs, gain);
+    // per-block peaks of x via the scale kernel's sibling: reuse k_finalize on a peak pass
+    const long long nb = (n + 4095) / 4096;
+    MGX_TRY(ensure(h, h->block_peak, (size_t)nb * sizeof(float)));
+    hipLaunchKernelGGL(k_frame_peaks, dim3((unsigned)nb), dim3(256), 0, h->stream, (const float2*)x_dev, (long long)n,
+                       (float*)h->block_peak.p);
+    hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, h->stream, (const float*)h->block_peak.p, nb,
+                       cfg->threshold, cfg->min_value, cs);
+    double* post = (double*)h->pinned;
+    *post = post_gain;
+    HIP_TRY(hipMemcpyAsync(h->scalars.p, post, sizeof(double), hipMemcpyHostToDevice, h->stream));
+    MGX_TRY(run_limiter(h, x_dev, n, cfg, &cs->gain, (const double*)h->scalars.p, &cs->limiter_active, out_dev));
+    CorrectionState host_cs;
+    HIP_TRY(hipMemcpyAsync(&host_cs, cs, sizeof(host_cs), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (active) *active = host_cs.limiter_active;
+    return 0;
+}
+
+int mgx_scale(mgx_handle* h, const float* x_dev, int64_t n, double gain, float* out_dev) {
+    if (!h || !x_dev || !out_dev) return fail(MGX_ERR_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(k_scale_outputs, dim3(grid), dim3(256), 0, h->stream, (const float2*)x_dev, (long long)n,
+                       (const double*)nullptr, gain, (const double*)nullptr, (float2*)out_dev, (float2*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- the boundary: stages.main ----------------------------------------------
+int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const float* reference_dev,
+               int64_t n_reference, const mgx_config* cfg, float* result_dev, float* result_no_limiter_dev,
+               float* result_no_limiter_normalized_dev, mgx_report* report) {
+    if (!h || !target_dev || !reference_dev) return fail(MGX_ERR_ARGUMENT, "null argument");
+    MGX_TRY(check_config(cfg));
+    HIP_TRY(hipSetDevice(h->device));
+    const int f = cfg->fft_size, half = f / 2, bins = half + 1;
+    if (result_dev) {               // validate limiter parameters before any work is queued
+        LimiterParams lp;
+        const std::string err = limiter_params(*cfg, lp);
+        if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
+    }
+    // stage 1 (stages.py:38-104): both tracks analysed in one pass each
+    TrackWork& tw = h->track[0];
+    TrackWork& rw = h->track[1];
+    MGX_TRY(run_analysis(h, target_dev, n_target, cfg, 0, tw));
+    MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
+    // host round trip: 2 x TrackStats + 4 spectra
+    const size_t spec_bytes = (size_t)2 * bins * sizeof(double);
+    MGX_TRY(ensure_pinned(h, std::max((size_t)1 << 16, 2 * spec_bytes + 4096 + (size_t)2 * f * sizeof(float))));
+    char* pin = (char*)h->pinned;
+    TrackStats* st_t = (TrackStats*)pin;
+    TrackStats* st_r = (TrackStats*)(pin + 256);
+    double* avg_t = (double*)(pin + 1024);
+    double* avg_r = avg_t + 2 * bins;
+    HIP_TRY(hipMemcpyAsync(st_t, tw.stats.p, sizeof(TrackStats), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(st_r, rw.stats.p, sizeof(TrackStats), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(avg_t, tw.avg.p, spec_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(avg_r, rw.avg.p, spec_bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const TrackStats stt = *st_t, str = *st_r;
+    const double c0 = str.match_rms / std::max(cfg->min_value, stt.match_rms);        // match_levels.py:106-111
+    // stage 2 (stages.py:107-135): FIR design on the host, float64
+    std::vector<double> fir_mid(f), fir_side(f), scaled(bins);
+    FirDesignParams p{f, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac, cfg->lowess_it,
+                      cfg->lowess_delta, cfg->min_value};
+    for (int k = 0; k < bins; ++k) scaled[k] = avg_t[k] * c0;                          // stages.py:90
+    design_fir(scaled.data(), avg_r, p, fir_mid.data(), nullptr, nullptr);
+    for (int k = 0; k < bins; ++k) scaled[k] = avg_t[bins + k] * c0;                   // stages.py:91
+    design_fir(scaled.data(), avg_r + bins, p, fir_side.data(), nullptr, nullptr);
+    MGX_TRY(ensure(h, h->taps, (size_t)2 * f * sizeof(float)));
+    float* tap_stage = (float*)(pin + 1024 + 2 * spec_bytes + 1024);
+    for (int i = 0; i < f; ++i) {
+        tap_stage[i] = (float)fir_mid[i];
+        tap_stage[f + i] = (float)fir_side[i];
+    }
+    HIP_TRY(hipMemcpyAsync(h->taps.p, tap_stage, (size_t)2 * f * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    MGX_TRY(ensure(h, h->y, (size_t)n_target * sizeof(float2)));
+    MGX_TRY(ensure(h, h->mid, (size_t)n_target * sizeof(float)));
+    long long nblocks = 0;
+    MGX_TRY(run_conv(h, target_dev, n_target, f, (const float*)h->taps.p, c0, (float*)h->y.p, (float*)h->mid.p,
+                     &nblocks));
+    // stage 3 (stages.py:138-170): scalar feedback stays on the device
+    MGX_TRY(ensure(h, h->cstate, sizeof(CorrectionState)));
+    CorrectionState* cs = (CorrectionState*)h->cstate.p;
+    hipLaunchKernelGGL(k_correction_init, dim3(1), dim3(1), 0, h->stream, cs, 1.0);
+    const double* ref_match = &((const TrackStats*)rw.stats.p)->match_rms;
+    const size_t lds_step = (size_t)(64 + tw.divisions) * sizeof(double);
+    for (int step = 0; step < cfg->rms_correction_steps; ++step) {
+        int chunks = 0;
+        MGX_TRY(run_clipped_sumsq(h, (const float*)h->mid.p, tw.piece, tw.divisions, &cs->gain, 1.0, &chunks));
+        hipLaunchKernelGGL(k_correction_step, dim3(1), dim3(1024), lds_step, h->stream, (const double*)h->partial.p,
+                           chunks, tw.divisions, tw.piece, ref_match, cfg->min_value, cs);
+    }
+    hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, h->stream, (const float*)h->block_peak.p, nblocks,
+                       cfg->threshold, cfg->min_value, cs);
+    HIP_TRY(hipGetLastError());
+    // stage 4 (stages.py:173-207)
+    if (result_no_limiter_dev || result_no_limiter_normalized_dev) {
+        const unsigned grid = (unsigned)std::min<long long>((n_target + 255) / 256, 8192);
+        hipLaunchKernelGGL(k_scale_outputs, dim3(grid), dim3(256), 0, h->stream, (const float2*)h->y.p,
+                           (long long)n_target, (const double*)&cs->gain, 1.0, (const double*)&cs->normalize_c,
+                           (float2*)result_no_limiter_dev, (float2*)result_no_limiter_normalized_dev);
+        HIP_TRY(hipGetLastError());
+    }
+    if (result_dev) {
+        const double* post = &((const TrackStats*)rw.stats.p)->amplitude_c;
+        MGX_TRY(run_limiter(h, (const float*)h->y.p, n_target, cfg, &cs->gain, post, &cs->limiter_active, result_dev));
+    }
+    if (report) {
+        CorrectionState* hc = (CorrectionState*)(pin + 512);
+        HIP_TRY(hipMemcpyAsync(hc, cs, sizeof(CorrectionState), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        std::memset(report, 0, sizeof(*report));
+        report->final_amplitude_coefficient = str.amplitude_c;
+        report->target_match_rms = stt.match_rms;
+        report->reference_match_rms = str.match_rms;
+        report->rms_coefficient = c0;
+        for (int i = 0; i < 16; ++i) report->correction_coefficients[i] = hc->coeffs[i];
+        report->normalize_coefficient = result_no_limiter_normalized_dev ? hc->normalize_c : 0.0;
+        report->result_peak = hc->result_peak;
+        report->target_divisions = stt.divisions;
+        report->reference_divisions = str.divisions;
+        report->target_piece = stt.piece;
+        report->reference_piece = str.piece;
+        report->target_loud_count = stt.loud_count;
+        report->reference_loud_count = str.loud_count;
+        report->limiter_active = hc->limiter_active;
+    }
+    return 0;
+}
+
+// ---- RCCL ----------------------------------------------------------------------
+int mgx_comm_unique_id(void* id128) {
+    if (!id128) return fail(MGX_ERR_ARGUMENT, "null argument");
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    std::memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+int mgx_comm_init(mgx_handle* h, const void* id128, int rank, int world) {
+    if (!h || !id128) return fail(MGX_ERR_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    NCCL_TRY(ncclCommInitRank(&h->comm, world, id, rank));
+    h->comm_rank = rank;
+    h->comm_world = world;
+    return 0;
+}
+int mgx_comm_broadcast_f32(mgx_handle* h, float* dev, int64_t count, int root) {
+    if (!h || !h->comm) return fail(MGX_ERR_ARGUMENT, "communicator not initialised");
+    NCCL_TRY(ncclBroadcast(dev, dev, (size_t)count, ncclFloat, root, h->comm, h->stream));
+    return 0;
+}
+int mgx_comm_allgather_f32(mgx_handle* h, const float* send_dev, float* recv_dev, int64_t count) {
+    if (!h || !h->comm) return fail(MGX_ERR_ARGUMENT, "communicator not initialised");
+    NCCL_TRY(ncclAllGather(send_dev, recv_dev, (size_t)count, ncclFloat, h->comm, h->stream));
+    return 0;
+}
+int mgx_comm_destroy(mgx_handle* h) {
+    if (!h || !h->comm) return 0;
+    NCCL_TRY(ncclCommDestroy(h->comm));
+    h->comm = nullptr;
+    return 0;
+}
+
+}  // extern "C"
+

@@ -1,0 +1,446 @@
+// __global__ wrappers around the phase functions (device only; included by mgx.hip).
+//
+// Wave-level reductions here are gfx950 wave64 shuffles; nothing in this file is
+// exercised by the CPU emulation (which drives the phase functions directly).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "analysis_kernel.h"
+#include "conv_kernel.h"
+#include "limiter_kernel.h"
+
+namespace mgx {
+
+#define MGX_LDS extern __shared__ __attribute__((aligned(16))) char mgx_smem[]
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// scratch: at least (threads/64) floats / doubles of LDS; result valid on thread 0
+template <int THREADS>
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) r = fmaxf(r, scratch[w]);
+    }
+    return r;
+}
+template <int THREADS>
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) r += scratch[w];
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// convolution
+// ---------------------------------------------------------------------------
+template <int LOG2N>
+constexpr size_t conv_lds_bytes() { return (size_t)Fft<LOG2N>::LDS_ELEMS * sizeof(float2) + 64; }
+
+template <int LOG2N>
+__global__ __launch_bounds__(Fft<LOG2N>::T) void k_conv(ConvArgs a) {
+    using CB = ConvBlock<LOG2N>;
+    using F = Fft<LOG2N>;
+    MGX_LDS;
+    float2* lds = reinterpret_cast<float2*>(mgx_smem);
+    float* scratch = reinterpret_cast<float*>(mgx_smem + (size_t)F::LDS_ELEMS * sizeof(float2));
+    const int tid = threadIdx.x;
+    for (long long blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
+        CB::phase_load(tid, blk, a, lds);
+        __syncthreads();
+        if (F::P == 3) {
+            CB::phase_fwd_mid(tid, lds, a.tw);
+            __syncthreads();
+        }
+        CB::phase_pointwise(tid, a, lds);
+        __syncthreads();
+        if (F::P == 3) {
+            CB::phase_inv_mid(tid, lds, a.tw);
+            __syncthreads();
+        }
+        const float pk = CB::phase_store(tid, blk, a, lds);
+        const float bp = block_max<F::T>(pk, scratch);
+        if (tid == 0 && a.block_peak) a.block_peak[blk] = bp;
+        __syncthreads();
+    }
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(Fft<LOG2N>::T) void k_conv_prep(const float* h_mid, const float* h_side, int taps,
+                                                             const float2* tw, float2* fa, float2* fc,
+                                                             const double* gain_ptr, double gain) {
+    using CB = ConvBlock<LOG2N>;
+    using F = Fft<LOG2N>;
+    MGX_LDS;
+    float2* lds = reinterpret_cast<float2*>(mgx_smem);
+    const int tid = threadIdx.x;
+    CB::phase_load_taps(tid, h_mid, h_side, taps, lds, tw);
+    __syncthreads();
+    if (F::P == 3) {
+        CB::phase_fwd_mid(tid, lds, tw);
+        __syncthreads();
+    }
+    F::template fwd_pass_lds<F::LAST>(tid, lds, tw);
+    __syncthreads();
+    const double g = gain_ptr ? *gain_ptr * gain : gain;
+    CB::phase_split_filters(tid, lds, fa, fc, (float)(g / (double)F::N));
+}
+
+// ---------------------------------------------------------------------------
+// analysis
+// ---------------------------------------------------------------------------
+template <int LOG2N>
+constexpr size_t analysis_lds_bytes() { return (size_t)Fft<LOG2N>::LDS_ELEMS * sizeof(float2) + 128; }
+
+template <int LOG2N>
+__global__ __launch_bounds__(Fft<LOG2N>::T) void k_analyze(AnalysisArgs a) {
+    using AB = AnalysisBlock<LOG2N>;
+    using F = Fft<LOG2N>;
+    MGX_LDS;
+    float2* lds = reinterpret_cast<float2*>(mgx_smem);
+    double* dscratch = reinterpret_cast<double*>(mgx_smem + (size_t)F::LDS_ELEMS * sizeof(float2));
+    float* fscratch = reinterpret_cast<float*>(dscratch + 8);
+    const int tid = threadIdx.x, wg = blockIdx.x;
+    const int d = wg / a.chunks_per_piece, ch = wg % a.chunks_per_piece;
+    typename AB::Thread th;
+    AB::init(th);
+    const int s0 = ch * a.segs_per_wg;
+    const int s1 = min(a.segs_per_piece, s0 + a.segs_per_wg);
+    for (int s = s0; s < s1; ++s) {
+        const long long start = (long long)d * a.piece + (long long)s * F::N;
+        AB::phase_load(tid, start, a, th, lds);
+        __syncthreads();
+        if (F::P == 3) {
+            AB::phase_fwd_mid(tid, lds, a.tw);
+            __syncthreads();
+        }
+        AB::phase_magnitudes(tid, th, lds);
+        __syncthreads();
+    }
+    if (ch == a.chunks_per_piece - 1) {
+        AB::phase_loose_frames(tid, (long long)d * a.piece + (long long)a.segs_per_piece * F::N,
+                               (long long)(d + 1) * a.piece, true, a, th);
+        if (d == a.divisions - 1)
+            AB::phase_loose_frames(tid, (long long)a.divisions * a.piece, a.n, false, a, th);
+    }
+    AB::phase_write_spectrum(tid, wg, a, th);
+    const double ss = block_sum<F::T>(th.sumsq, dscratch);
+    const float pk = block_max<F::T>(th.peak, fscratch);
+    if (tid == 0) {
+        a.wg_sumsq[wg] = ss;
+        a.wg_peak[wg] = pk;
+    }
+}
+
+// ---- piece statistics -> decisions (match_levels.py:62-71,93-103), one 1024-thread workgroup ----
+// Step 1: wave w sums the chunk partials of pieces w, w+16, ... (lanes = chunks) into LDS.
+// Step 2: thread d owns piece d: rms, mean of squares, rms >= average, RMS of the loud ones.
+// All reductions are fixed trees, so results are run-to-run identical.
+__device__ __forceinline__ void piece_sums_to_lds(const double* partial, int chunks, int divisions, double* sums) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+    for (int d = wave; d < divisions; d += nwaves) {
+        double s = 0.0;
+        for (int ch = lane; ch < chunks; ch += 64) s += partial[(size_t)d * chunks + ch];
+        s = wave_sum(s);
+        if (lane == 0) sums[d] = s;
+    }
+    __syncthreads();
+}
+// returns (on every thread) average rms, match rms and the loud count; optionally stores rms/loud
+__device__ __forceinline__ void decide_loud(const double* sums, int divisions, long long piece, double inv_c,
+                                            double* red, double* rms_out, int* loud_out, double& avg,
+                                            double& match, int& count) {
+    double acc = 0.0;
+    for (int d = threadIdx.x; d < divisions; d += blockDim.x) {
+        const double r = sqrt(sums[d] / (double)piece) * inv_c;
+        acc += r * r;
+    }
+    double tot = block_sum<1024>(acc, red);
+    if (threadIdx.x == 0) red[16] = sqrt(tot / divisions);
+    __syncthreads();
+    avg = red[16];
+    double lacc = 0.0, lcnt = 0.0;
+    for (int d = threadIdx.x; d < divisions; d += blockDim.x) {
+        const double r = sqrt(sums[d] / (double)piece) * inv_c;
+        const bool l = r >= avg;
+        if (l) { lacc += r * r; lcnt += 1.0; }
+        if (rms_out) rms_out[d] = r;
+        if (loud_out) loud_out[d] = l ? 1 : 0;
+    }
+    __syncthreads();
+    tot = block_sum<1024>(lacc, red);
+    if (threadIdx.x == 0) red[17] = tot;
+    __syncthreads();
+    const double cnt = block_sum<1024>(lcnt, red + 18);
+    if (threadIdx.x == 0) red[40] = cnt;
+    __syncthreads();
+    count = (int)red[40];
+    match = sqrt(red[17] / red[40]);
+}
+
+__global__ __launch_bounds__(1024) void k_levels(const double* wg_sumsq, const float* wg_peak,
+                                                 int chunks_per_piece, int divisions, long long piece,
+                                                 int is_reference, double threshold, double eps,
+                                                 TrackStats* st, double* rms, int* loud) {
+    MGX_LDS;
+    double* red = reinterpret_cast<double*>(mgx_smem);          // 64 doubles of reduction scratch
+    double* sums = red + 64;                                     // [divisions]
+    float* fred = reinterpret_cast<float*>(red + 52);
+    float m = 0.f;
+    for (int w = threadIdx.x; w < divisions * chunks_per_piece; w += blockDim.x) m = fmaxf(m, wg_peak[w]);
+    const float pk = block_max<1024>(m, fred);
+    if (threadIdx.x == 0) red[41] = (double)pk;
+    __syncthreads();
+    const double peak = red[41];
+    double c = 1.0;
+    if (is_reference && peak < threshold) c = fmax(eps, peak / threshold);     // dsp.py:98-99
+    piece_sums_to_lds(wg_sumsq, chunks_per_piece, divisions, sums);
+    double avg, match;
+    int count;
+    decide_loud(sums, divisions, piece, 1.0 / c, red, rms, loud, avg, match, count);
+    if (threadIdx.x == 0) {
+        TrackStats s;
+        s.peak = peak;
+        s.amplitude_c = c;
+        s.average_rms = avg;
+        s.match_rms = match;
+        s.divisions = divisions;
+        s.loud_count = count;
+        s.piece = piece;
+        *st = s;
+    }
+}
+
+// mean over loud pieces and segments of |rfft|/F (match_frequencies.py:42), float64
+__global__ void k_average_spectra(const float* wg_spec, const int* loud, const TrackStats* st,
+                                  int chunks_per_piece, int divisions, int segs_per_piece, int fft,
+                                  double* avg_mid, double* avg_side) {
+    const int half = fft / 2, bins = half + 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * bins) return;
+    const int plane = i / bins, k = i % bins;
+    double s = 0.0;
+    for (int d = 0; d < divisions; ++d) {
+        if (!loud[d]) continue;
+        for (int ch = 0; ch < chunks_per_piece; ++ch)
+            s += (double)wg_spec[((size_t)(d * chunks_per_piece + ch) * 2 + plane) * bins + k];
+    }
+    const double scale = 1.0 / ((double)st->loud_count * (double)segs_per_piece * (double)fft * st->amplitude_c);
+    (plane == 0 ? avg_mid : avg_side)[k] = s * scale;
+}
+
+// ---------------------------------------------------------------------------
+// level correction (stages.py:138-170)
+// ---------------------------------------------------------------------------
+struct CorrectionState {
+    double gain;              // product of the coefficients so far
+    double coeffs[16];
+    double result_peak;       // max |gain * y|
+    double normalize_c;       // stages.py:186-191
+    int limiter_active;
+    int steps_done;
+};
+
+// partial[d*chunks + ch] = sum over the chunk of clip(gain*mid, -1, 1)^2
+__global__ __launch_bounds__(256) void k_clipped_sumsq(const float* mid, long long piece, int chunks,
+                                                       const double* gain_ptr, double gain_mul,
+                                                       double* partial) {
+    __shared__ double scratch[4];
+    const int d = blockIdx.x / chunks, ch = blockIdx.x % chunks;
+    const long long len = (piece + chunks - 1) / chunks;
+    const long long b = (long long)d * piece + ch * len;
+    const long long e = min((long long)(d + 1) * piece, b + len);
+    const double g = (gain_ptr ? *gain_ptr : 1.0) * gain_mul;
+    double acc = 0.0;
+    // float64 product then clip: the reference clips the float64 mid (dsp.py:109-110)
+    long long i = b + threadIdx.x;
+    for (; i + 3 * 256 < e; i += 4 * 256) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = mid[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const double c = fmin(fmax((double)v[u] * g, -1.0), 1.0);
+            acc = fma(c, c, acc);
+        }
+    }
+    for (; i < e; i += 256) {
+        const double c = fmin(fmax((double)mid[i] * g, -1.0), 1.0);
+        acc = fma(c, c, acc);
+    }
+    const double s = block_sum<256>(acc, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// one round of stages.py:149-168 on the partial sums
+__global__ __launch_bounds__(1024) void k_correction_step(const double* partial, int chunks, int divisions,
+                                                          long long piece, const double* reference_match_rms,
+                                                          double eps, CorrectionState* cs) {
+    MGX_LDS;
+    double* red = reinterpret_cast<double*>(mgx_smem);
+    double* sums = red + 64;
+    piece_sums_to_lds(partial, chunks, divisions, sums);
+    double avg, match;
+    int count;
+    decide_loud(sums, divisions, piece, 1.0, red, nullptr, nullptr, avg, match, count);
+    if (threadIdx.x == 0) {
+        const double c = *reference_match_rms / fmax(eps, match);      // match_levels.py:106-111
+        cs->coeffs[cs->steps_done] = c;
+        cs->steps_done += 1;
+        cs->gain *= c;
+    }
+}
+
+__global__ void k_correction_init(CorrectionState* cs, double gain) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        cs->gain = gain;
+        cs->steps_done = 0;
+        cs->result_peak = 0.0;
+        cs->normalize_c = 1.0;
+        cs->limiter_active = 1;
+        for (int i = 0; i < 16; ++i) cs->coeffs[i] = 0.0;
+    }
+}
+
+// peak of the corrected result, limiter early-out decision (hyrax.py:83-85 with numpy.isclose
+// defaults) and the normalisation coefficient of stages.py:186-191 / dsp.py:93-100
+__global__ __launch_bounds__(256) void k_finalize_scalars(const float* block_peak, long long nblocks,
+                                                          double threshold, double eps, CorrectionState* cs) {
+    __shared__ float scratch[4];
+    float m = 0.f;
+    for (long long i = threadIdx.x; i < nblocks; i += 256) m = fmaxf(m, block_peak[i]);
+    const float pk = block_max<256>(m, scratch);
+    if (threadIdx.x == 0) {
+        const double peak = (double)(float)((double)pk * cs->gain);      // max |float32(y*gain)|
+        cs->result_peak = peak;
+        const double rect = fmax(peak, threshold) / threshold;
+        cs->limiter_active = fabs(rect - 1.0) > (1e-8 + 1e-5) ? 1 : 0;
+        cs->normalize_c = fmax(eps, peak / threshold);
+    }
+}
+
+// result_no_limiter = y*gain (dsp.py:89-90) and/or the normalised variant
+__global__ __launch_bounds__(256) void k_scale_outputs(const float2* y, long long n, const double* gain_ptr,
+                                                       double gain_mul, const double* normalize_ptr,
+                                                       float2* out_plain, float2* out_normalized) {
+    const double g = (gain_ptr ? *gain_ptr : 1.0) * gain_mul;
+    const double inv = normalize_ptr ? *normalize_ptr : 1.0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float2 v = y[i];
+        const double l = (double)v.x * g, r = (double)v.y * g;
+        if (out_plain) out_plain[i] = make_float2((float)l, (float)r);
+        if (out_normalized) out_normalized[i] = make_float2((float)(l / inv), (float)(r / inv));
+    }
+}
+
+// per-block max(|L|,|R|) of interleaved frames (4096 frames per block)
+__global__ __launch_bounds__(256) void k_frame_peaks(const float2* x, long long n, float* block_peak) {
+    __shared__ float scratch[4];
+    const long long b = (long long)blockIdx.x * 4096;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < 4096; i += 256) {
+        const long long f = b + i;
+        if (f < n) {
+            const float2 v = x[f];
+            m = fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y)));
+        }
+    }
+    const float r = block_max<256>(m, scratch);
+    if (threadIdx.x == 0) block_peak[blockIdx.x] = r;
+}
+
+// ---------------------------------------------------------------------------
+// limiter
+// ---------------------------------------------------------------------------
+template <int PASS>
+__global__ __launch_bounds__(LimiterBlock::T) void k_limit(LimiterArgs a) {
+    using LB = LimiterBlock;
+    MGX_LDS;
+    float* lds = reinterpret_cast<float*>(mgx_smem);
+    const int tid = threadIdx.x;
+    const long long chunk = blockIdx.x;
+    const bool active = a.active ? (*a.active != 0) : true;
+    LB::Thread th;
+    if (!active) {
+        if (PASS == 3) {                 // hyrax.py:83-85: the array passes through, then stages.py:203
+            LB::phase_g0(tid, chunk, a, th, lds);
+            if (th.core) {
+                const double post = *a.post_gain;
+#pragma unroll
+                for (int j = 0; j < LB::E; ++j)
+                    if (j < th.valid)
+                        a.out[th.base + j] = make_float2((float)((double)th.v[j].x * post),
+                                                         (float)((double)th.v[j].y * post));
+            }
+        }
+        return;
+    }
+    LB::phase_g0(tid, chunk, a, th, lds);
+    __syncthreads();
+    LB::phase_sl(tid, a, th, lds);
+    __syncthreads();
+    LB::phase_sh_runs(tid, a, th, lds);
+    __syncthreads();
+    LB::Scan::scan_groups(LB::scan_area(lds), tid);
+    __syncthreads();
+    LB::Scan::scan_top(LB::scan_area(lds), tid);
+    __syncthreads();
+    if (PASS == 1) {
+        LB::phase_publish(tid, chunk, a, lds, 0, 1);
+        return;
+    }
+    Affine m_ro, m_yb;
+    LB::phase_exact_first(tid, chunk, a, th, lds, m_ro, m_yb);
+    __syncthreads();
+    LB::phase_put_second(tid, lds, m_ro, m_yb);
+    __syncthreads();
+    LB::Scan::scan_groups(LB::scan_area(lds), tid);
+    __syncthreads();
+    LB::Scan::scan_top(LB::scan_area(lds), tid);
+    __syncthreads();
+    if (PASS == 2) {
+        LB::phase_publish(tid, chunk, a, lds, 2, 3);
+        return;
+    }
+    LB::phase_output(tid, chunk, a, th, lds);
+}
+
+template <int STEP>
+__global__ __launch_bounds__(ChunkScan::T) void k_limit_scan(LimiterArgs a) {
+    MGX_LDS;
+    Affine* sc = reinterpret_cast<Affine*>(mgx_smem);
+    const int tid = threadIdx.x;
+    if (a.active && *a.active == 0) return;
+    const int sa = STEP == 1 ? 0 : 2, sb = STEP == 1 ? 1 : 3;
+    const bool fwd_b = STEP == 1;
+    ChunkScan::phase_put(tid, a, sa, sb, fwd_b, sc);
+    __syncthreads();
+    ChunkScan::Scan::scan_groups(sc, tid);
+    __syncthreads();
+    ChunkScan::Scan::scan_top(sc, tid);
+    __syncthreads();
+    const double init_b = STEP == 1 ? ChunkScan::filtfilt_left_state(a)
+                                    : ChunkScan::filtfilt_right_state(a, a.edge_state[0]);
+    ChunkScan::phase_write(tid, a, sa, sb, fwd_b, 0.0, init_b, sc);
+}
+
+}  // namespace mgx

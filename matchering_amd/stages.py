@@ -1,0 +1,72 @@
+"""``main``: the drop-in for matchering/stages.py:210-272.
+
+Same call signature and return convention as the reference -- two (n, 2) arrays
+in, a triple ``(result, result_no_limiter, result_no_limiter_normalized)`` out
+with ``None`` for outputs that were not requested -- but the four stages run as
+HIP kernels on an MI355X through ``mgx_master`` (include/mgx.h).  Arrays come
+back as float32 (n, 2) C-ordered; the reference returns float64.  The progress
+codes 2004-2007 are emitted in the reference's order (stages.py:52,117,147,182)
+and the per-stage scalars it prints through ``debug`` are reported from the
+device-side values.
+"""
+
+import numpy as np
+
+from .config import Config
+from .device import default_device
+from .log import Code, debug, debug_line, info
+from .utils import to_db
+
+
+def _as_frames(array, name):
+    array = np.asarray(array)
+    if array.ndim != 2 or array.shape[1] != 2:
+        raise ValueError(f"{name} must have shape (n, 2), got {array.shape}")
+    return np.ascontiguousarray(array, dtype=np.float32)
+
+
+def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default: bool = True,
+         need_no_limiter: bool = False, need_no_limiter_normalized: bool = False, device=None):
+    dev = device if device is not None else default_device()
+    target = _as_frames(target, "target")
+    reference = _as_frames(reference, "reference")
+    n, nr = target.shape[0], reference.shape[0]
+    native = config.to_native()
+
+    debug_line()
+    info(Code.INFO_MATCHING_LEVELS)
+    debug(f"The maximum size of the analyzed piece: {config.max_piece_size} samples "
+          f"or {config.max_piece_size / config.internal_sample_rate:.2f} seconds")
+    t_dev = dev.upload(target)
+    r_dev = dev.upload(reference)
+    outs = [dev.alloc(n * 8) if need else None
+            for need in (need_default, need_no_limiter, need_no_limiter_normalized)]
+    try:
+        report = dev.master(t_dev, n, r_dev, nr, native, *outs)
+        debug(f"The TARGET will be didived into {report.target_divisions} pieces of "
+              f"{report.target_piece} samples; the REFERENCE into {report.reference_divisions} of "
+              f"{report.reference_piece}")
+        if not np.isclose(report.final_amplitude_coefficient, 1.0):
+            debug("The REFERENCE was normalized. Final amplitude coefficient for the TARGET audio is: "
+                  f"{to_db(report.final_amplitude_coefficient)}")
+        debug(f"The RMS coefficient is: {to_db(report.rms_coefficient)}")
+        debug_line()
+        info(Code.INFO_MATCHING_FREQS)
+        debug_line()
+        info(Code.INFO_CORRECTING_LEVELS)
+        for step in range(config.rms_correction_steps):
+            debug(f"Applying RMS correction #{step + 1}... "
+                  f"The RMS coefficient is: {to_db(report.correction_coefficients[step])}")
+        debug_line()
+        info(Code.INFO_FINALIZING)
+        if need_no_limiter_normalized:
+            debug("The amplitude of the normalized RESULT should be adjusted by "
+                  f"{to_db(report.normalize_coefficient)}")
+        if need_default and not report.limiter_active:
+            debug("The limiter is not needed!")
+        results = tuple(dev.download(b, (n, 2)) if b is not None else None for b in outs)
+    finally:
+        for b in (t_dev, r_dev, *outs):
+            if b is not None:
+                b.release()
+    return results

@@ -1,0 +1,283 @@
+// CPU emulation harness for the kernel phase functions -- TEST INFRASTRUCTURE.
+//
+// Compiled by tests/emu/build.py with a plain host compiler and -DMGX_HOST_EMU.
+// It drives the SAME per-thread phase functions the HIP kernels inline
+// (matchering_amd/csrc/*_kernel.h) with a loop over thread ids where the GPU has
+// a workgroup and a plain sequence point where the GPU has a barrier.  The CPU
+// test-suite uses it to check the index arithmetic of the kernels against the
+// oracle without a GPU.  It is not part of the product and is never loaded by
+// matchering_amd.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../matchering_amd/csrc/analysis_kernel.h"
+#include "../../matchering_amd/csrc/conv_kernel.h"
+#include "../../matchering_amd/csrc/fir_design.h"
+#include "../../matchering_amd/csrc/host_params.h"
+#include "../../matchering_amd/csrc/limiter_kernel.h"
+
+using namespace mgx;
+
+static std::vector<float2> twiddles(int n) {
+    std::vector<float2> tw(n);
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k < n; ++k)
+        tw[k] = make_float2((float)std::cos(2.0 * pi * k / n), (float)-std::sin(2.0 * pi * k / n));
+    return tw;
+}
+
+#define FOR_THREADS(T_) for (int tid = 0; tid < (T_); ++tid)
+
+// ---------------------------------------------------------------------------
+template <int LOG2N>
+static int conv_impl(const float* x, long long n, const double* fir_mid, const double* fir_side, int taps,
+                     double gain, float* y, float* ymid, double* peak) {
+    using CB = ConvBlock<LOG2N>;
+    using F = typename CB::F;
+    const std::vector<float2> tw = twiddles(F::N);
+    std::vector<float2> lds(F::LDS_ELEMS), fa(F::N), fc(F::N);
+    std::vector<float> hm(taps), hs(taps);
+    for (int i = 0; i < taps; ++i) { hm[i] = (float)fir_mid[i]; hs[i] = (float)fir_side[i]; }
+    FOR_THREADS(F::T) CB::phase_load_taps(tid, hm.data(), hs.data(), taps, lds.data(), tw.data());
+    FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), tw.data());
+    FOR_THREADS(F::T) F::template fwd_pass_lds<F::LAST>(tid, lds.data(), tw.data());
+    FOR_THREADS(F::T) CB::phase_split_filters(tid, lds.data(), fa.data(), fc.data(), (float)(gain / F::N));
+
+    ConvArgs a;
+    a.x = reinterpret_cast<const float2*>(x);
+    a.n = n;
+    a.y = reinterpret_cast<float2*>(y);
+    a.ymid = ymid;
+    a.fa = fa.data();
+    a.fc = fc.data();
+    a.tw = tw.data();
+    a.taps = taps;
+    const long long lout = CB::lout(taps);
+    a.nblocks = (n + lout - 1) / lout;
+    a.block_peak = nullptr;
+    float pk = 0.f;
+    for (long long blk = 0; blk < a.nblocks; ++blk) {
+        FOR_THREADS(F::T) CB::phase_load(tid, blk, a, lds.data());
+        FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), a.tw);
+        FOR_THREADS(F::T) CB::phase_pointwise(tid, a, lds.data());
+        FOR_THREADS(F::T) CB::phase_inv_mid(tid, lds.data(), a.tw);
+        FOR_THREADS(F::T) pk = std::fmax(pk, CB::phase_store(tid, blk, a, lds.data()));
+    }
+    if (peak) *peak = pk;
+    return 0;
+}
+
+extern "C" int emu_convolve(const float* x, long long n, const double* fir_mid, const double* fir_side,
+                            int taps, double gain, float* y, float* ymid, double* peak) {
+    const int l = ilog2_exact(taps);
+    if (l < 0) return -1;
+    switch (l + 1) {
+#define CASE(L) case L: return conv_impl<L>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
+        CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+#undef CASE
+        default: return -4;
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <int LOG2N>
+static int analyze_impl(const float* x, long long n, const mgx_config* cfg, int is_reference, double* peak,
+                        double* amplitude_c, double* match_rms, int* divisions_out, long long* piece_out,
+                        double* piece_rms, int* loud, double* avg_mid, double* avg_side) {
+    using AB = AnalysisBlock<LOG2N>;
+    using F = typename AB::F;
+    const std::vector<float2> tw = twiddles(F::N);
+    int divisions;
+    long long piece;
+    piece_geometry(n, cfg->max_piece_size, divisions, piece);
+    AnalysisArgs a;
+    a.x = reinterpret_cast<const float2*>(x);
+    a.n = n;
+    a.fft = F::N;
+    a.piece = piece;
+    a.divisions = divisions;
+    a.segs_per_piece = (int)(piece / F::N);
+    a.segs_per_wg = 5;
+    a.chunks_per_piece = std::max(1, (a.segs_per_piece + a.segs_per_wg - 1) / a.segs_per_wg);
+    const int nwg = divisions * a.chunks_per_piece, half = F::N / 2;
+    std::vector<double> wg_sumsq(nwg);
+    std::vector<float> wg_peak(nwg), wg_spec((size_t)nwg * 2 * (half + 1), 0.f);
+    a.wg_sumsq = wg_sumsq.data();
+    a.wg_peak = wg_peak.data();
+    a.wg_spec = wg_spec.data();
+    a.tw = tw.data();
+    std::vector<float2> lds(F::LDS_ELEMS);
+    std::vector<typename AB::Thread> th(F::T);
+    for (int wg = 0; wg < nwg; ++wg) {
+        const int d = wg / a.chunks_per_piece, ch = wg % a.chunks_per_piece;
+        FOR_THREADS(F::T) AB::init(th[tid]);
+        const int s0 = ch * a.segs_per_wg, s1 = std::min(a.segs_per_piece, s0 + a.segs_per_wg);
+        for (int s = s0; s < s1; ++s) {
+            const long long start = d * piece + (long long)s * F::N;
+            FOR_THREADS(F::T) AB::phase_load(tid, start, a, th[tid], lds.data());
+            FOR_THREADS(F::T) AB::phase_fwd_mid(tid, lds.data(), a.tw);
+            FOR_THREADS(F::T) AB::phase_magnitudes(tid, th[tid], lds.data());
+        }
+        if (ch == a.chunks_per_piece - 1) {
+            FOR_THREADS(F::T)
+            AB::phase_loose_frames(tid, d * piece + (long long)a.segs_per_piece * F::N, (d + 1) * piece, true, a, th[tid]);
+            if (d == divisions - 1) {
+                FOR_THREADS(F::T) AB::phase_loose_frames(tid, (long long)divisions * piece, n, false, a, th[tid]);
+            }
+        }
+        FOR_THREADS(F::T) AB::phase_write_spectrum(tid, wg, a, th[tid]);
+        double ss = 0.0;
+        float pk = 0.f;
+        FOR_THREADS(F::T) { ss += th[tid].sumsq; pk = std::fmax(pk, th[tid].peak); }
+        wg_sumsq[wg] = ss;
+        wg_peak[wg] = pk;
+    }
+    std::vector<double> rms(divisions);
+    std::vector<int> ld(divisions);
+    TrackStats st;
+    finish_levels(wg_sumsq.data(), wg_peak.data(), a.chunks_per_piece, divisions, piece, is_reference != 0,
+                  cfg->threshold, cfg->min_value, rms.data(), ld.data(), st);
+    if (peak) *peak = st.peak;
+    if (amplitude_c) *amplitude_c = st.amplitude_c;
+    if (match_rms) *match_rms = st.match_rms;
+    if (divisions_out) *divisions_out = divisions;
+    if (piece_out) *piece_out = piece;
+    for (int d = 0; d < divisions; ++d) {
+        if (piece_rms) piece_rms[d] = rms[d];
+        if (loud) loud[d] = ld[d];
+    }
+    const double scale = 1.0 / ((double)st.loud_count * a.segs_per_piece * (double)F::N * st.amplitude_c);
+    for (int k = 0; k <= half; ++k) {
+        double sm = 0.0, ssd = 0.0;
+        for (int wg = 0; wg < nwg; ++wg) {
+            if (!ld[wg / a.chunks_per_piece]) continue;
+            sm += wg_spec[(size_t)wg * 2 * (half + 1) + k];
+            ssd += wg_spec[(size_t)wg * 2 * (half + 1) + (half + 1) + k];
+        }
+        if (avg_mid) avg_mid[k] = sm * scale;
+        if (avg_side) avg_side[k] = ssd * scale;
+    }
+    return 0;
+}
+
+extern "C" int emu_analyze(const float* x, long long n, const mgx_config* cfg, int is_reference, double* peak,
+                           double* amplitude_c, double* match_rms, int* divisions, long long* piece,
+                           double* piece_rms, int* loud, double* avg_mid, double* avg_side) {
+    const int l = ilog2_exact(cfg->fft_size);
+    switch (l) {
+#define CASE(L) case L: return analyze_impl<L>(x, n, cfg, is_reference, peak, amplitude_c, match_rms, divisions, piece, piece_rms, loud, avg_mid, avg_side);
+        CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+#undef CASE
+        default: return -4;
+    }
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, double gain, double post_gain,
+                         float* out, float* dbg_sl, float* dbg_sh) {
+    LimiterParams lp;
+    if (!limiter_params(*cfg, lp).empty()) return -1;
+    using LB = LimiterBlock;
+    const LB::Geometry geo = LB::geometry(lp.hw, lp.hb);
+    LimiterArgs a;
+    a.y = reinterpret_cast<const float2*>(x);
+    a.n = n;
+    a.out = reinterpret_cast<float2*>(out);
+    a.gain = &gain;
+    a.post_gain = &post_gain;
+    a.active = nullptr;
+    a.threshold = (float)cfg->threshold;
+    a.hw = lp.hw;
+    a.hb = lp.hb;
+    a.att = lp.att;
+    a.hold = lp.hold_f;
+    a.rel = lp.rel_f;
+    a.nchunks = (n + geo.chunk - 1) / geo.chunk;
+    std::vector<Affine> agg(4 * a.nchunks);
+    std::vector<double> carry(4 * a.nchunks, 0.0);
+    float edge_sl[14] = {0};
+    double edge_state[2] = {0, 0};
+    a.agg = agg.data();
+    a.carry = carry.data();
+    a.edge_sl = edge_sl;
+    a.edge_state = edge_state;
+    std::vector<float> lds(LB::LDS_BYTES / 4 + 8);
+    std::vector<LB::Thread> th(LB::T);
+    std::vector<Affine> m0(LB::T), m1(LB::T);
+    std::vector<Affine> sc(ChunkScan::Scan::SCRATCH);
+
+    auto first_phases = [&](long long chunk) {
+        FOR_THREADS(LB::T) LB::phase_g0(tid, chunk, a, th[tid], lds.data());
+        FOR_THREADS(LB::T) LB::phase_sl(tid, a, th[tid], lds.data());
+        FOR_THREADS(LB::T) LB::phase_sh_runs(tid, a, th[tid], lds.data());
+        FOR_THREADS(LB::T) LB::Scan::scan_groups(LB::scan_area(lds.data()), tid);
+        FOR_THREADS(LB::T) LB::Scan::scan_top(LB::scan_area(lds.data()), tid);
+    };
+    auto second_phases = [&](long long chunk) {
+        FOR_THREADS(LB::T) LB::phase_exact_first(tid, chunk, a, th[tid], lds.data(), m0[tid], m1[tid]);
+        FOR_THREADS(LB::T) LB::phase_put_second(tid, lds.data(), m0[tid], m1[tid]);
+        FOR_THREADS(LB::T) LB::Scan::scan_groups(LB::scan_area(lds.data()), tid);
+        FOR_THREADS(LB::T) LB::Scan::scan_top(LB::scan_area(lds.data()), tid);
+    };
+    // pass 1
+    for (long long c = 0; c < a.nchunks; ++c) {
+        first_phases(c);
+        FOR_THREADS(LB::T) LB::phase_publish(tid, c, a, lds.data(), 0, 1);
+        if (dbg_sl || dbg_sh) {
+            FOR_THREADS(LB::T) {
+                if (!th[tid].core) continue;
+                for (int j = 0; j < th[tid].valid; ++j) {
+                    if (dbg_sl) dbg_sl[th[tid].base + j] = th[tid].sl[j];
+                    if (dbg_sh) dbg_sh[th[tid].base + j] = th[tid].sh[j];
+                }
+            }
+        }
+    }
+    // scan 1
+    FOR_THREADS(ChunkScan::T) ChunkScan::phase_put(tid, a, 0, 1, true, sc.data());
+    FOR_THREADS(ChunkScan::T) ChunkScan::Scan::scan_groups(sc.data(), tid);
+    FOR_THREADS(ChunkScan::T) ChunkScan::Scan::scan_top(sc.data(), tid);
+    {
+        const double yf0 = ChunkScan::filtfilt_left_state(a);
+        FOR_THREADS(ChunkScan::T) ChunkScan::phase_write(tid, a, 0, 1, true, 0.0, yf0, sc.data());
+    }
+    // pass 2
+    for (long long c = 0; c < a.nchunks; ++c) {
+        first_phases(c);
+        second_phases(c);
+        FOR_THREADS(LB::T) LB::phase_publish(tid, c, a, lds.data(), 2, 3);
+    }
+    // scan 2
+    FOR_THREADS(ChunkScan::T) ChunkScan::phase_put(tid, a, 2, 3, false, sc.data());
+    FOR_THREADS(ChunkScan::T) ChunkScan::Scan::scan_groups(sc.data(), tid);
+    FOR_THREADS(ChunkScan::T) ChunkScan::Scan::scan_top(sc.data(), tid);
+    {
+        const double yb0 = ChunkScan::filtfilt_right_state(a, a.edge_state[0]);
+        FOR_THREADS(ChunkScan::T) ChunkScan::phase_write(tid, a, 2, 3, false, 0.0, yb0, sc.data());
+    }
+    // pass 3
+    for (long long c = 0; c < a.nchunks; ++c) {
+        first_phases(c);
+        second_phases(c);
+        FOR_THREADS(LB::T) LB::phase_output(tid, c, a, th[tid], lds.data());
+    }
+    return 0;
+}
+
+// host FIR design (product code, re-exported here so the CPU tests need no HIP runtime)
+extern "C" int emu_design_fir(const mgx_config* cfg, const double* avg_target, const double* avg_reference,
+                              double* taps, double* curve_raw, double* curve_smooth) {
+    FirDesignParams p{cfg->fft_size, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac,
+                      cfg->lowess_it, cfg->lowess_delta, cfg->min_value};
+    design_fir(avg_target, avg_reference, p, taps, curve_raw, curve_smooth);
+    return 0;
+}
+extern "C" int emu_lowess(const double* y, int n, double frac, double delta, double* fit) {
+    lowess_it0(y, n, frac, delta, fit);
+    return 0;
+}
+extern "C" int emu_spline(const double* x, const double* y, int n, const double* xq, int nq, double* out) {
+    cubic_spline_nak(x, y, n, xq, nq, out);
+    return 0;
+}
