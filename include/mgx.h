@@ -153,6 +153,11 @@ int mgx_limit(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cf
 /* dsp.py:89-90 amplify on interleaved frames: out = x * gain */
 int mgx_scale(mgx_handle* h, const float* x_dev, int64_t n, double gain, float* out_dev);
 
+/* Device address of the FIR pair ([2][fft_size] float32: mid taps then side taps, level gain
+ * not included) designed by the last mgx_master / uploaded by the last mgx_convolve on this
+ * handle -- the payload of the RCCL exchange below. */
+int mgx_last_fir(mgx_handle* h, void** taps_dev, int32_t* taps);
+
 /* ---- multi-GPU: one process per GPU, FIR taps over RCCL/xGMI ---------------- */
 int mgx_comm_unique_id(void* id128);                                  /* ncclGetUniqueId, 128 bytes */
 int mgx_comm_init(mgx_handle* h, const void* id128, int rank, int world);

@@ -68,6 +68,7 @@ struct mgx_handle {
     DevBuf lim_agg, lim_carry, lim_edge;
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    int last_taps = 0;
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
 };
@@ -483,6 +484,7 @@ static int upload_taps(mgx_handle* h, const double* fir_mid, const double* fir_s
         st[taps + i] = (float)fir_side[i];
     }
     HIP_TRY(hipMemcpyAsync(h->taps.p, st, (size_t)2 * taps * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    h->last_taps = taps;
     return 0;
 }
 
@@ -626,6 +628,7 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         tap_stage[f + i] = (float)fir_side[i];
     }
     HIP_TRY(hipMemcpyAsync(h->taps.p, tap_stage, (size_t)2 * f * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    h->last_taps = f;
     MGX_TRY(ensure(h, h->y, (size_t)n_target * sizeof(float2)));
     MGX_TRY(ensure(h, h->mid, (size_t)n_target * sizeof(float)));
     long long nblocks = 0;
@@ -678,6 +681,14 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         report->reference_loud_count = str.loud_count;
         report->limiter_active = hc->limiter_active;
     }
+    return 0;
+}
+
+int mgx_last_fir(mgx_handle* h, void** taps_dev, int32_t* taps) {
+    if (!h || !taps_dev || !taps) return fail(MGX_ERR_ARGUMENT, "null argument");
+    if (!h->taps.p || h->last_taps <= 0) return fail(MGX_ERR_ARGUMENT, "no FIR has been designed on this handle yet");
+    *taps_dev = h->taps.p;
+    *taps = h->last_taps;
     return 0;
 }
 

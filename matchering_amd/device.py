@@ -67,9 +67,11 @@ class Device:
         return buf
 
     def download(self, buf, shape, dtype=np.float32):
+        """Copy HBM -> numpy.  ``buf`` is a DeviceBuffer or a raw device address."""
         out = np.empty(shape, dtype=dtype)
+        ptr = buf if isinstance(buf, int) else buf.ptr
         check(library().mgx_memcpy_d2h(self.handle, out.ctypes.data_as(ctypes.c_void_p),
-                                       ctypes.c_void_p(buf.ptr), out.nbytes))
+                                       ctypes.c_void_p(ptr), out.nbytes))
         return out
 
     def synchronize(self):
