@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmgx.so")
-SOURCES = [os.path.join(CSRC, "mgx.hip"), os.path.join(CSRC, "fir_design.cpp")]
+SOURCES = [os.path.join(CSRC, "mgx.hip"), os.path.join(CSRC, "fir_design.cpp"), os.path.join(CSRC, "fir_plan.cpp")]
 
 
 def _deps():

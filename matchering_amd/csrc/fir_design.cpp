@@ -1,4 +1,5 @@
 #include "fir_design.h"
+#include "fir_plan.h"
 
 #include <algorithm>
 #include <cmath>
@@ -149,6 +150,11 @@ static void fft_pow2(std::vector<std::complex<double>>& a, int sign) {
 
 void design_fir(const double* avg_target, const double* avg_reference, const FirDesignParams& p,
                 double* taps, double* curve_raw, double* curve_smooth) {
+    FirPlanHost::get(p)->design(avg_target, avg_reference, 1.0, taps, curve_raw, curve_smooth);
+}
+
+void design_fir_direct(const double* avg_target, const double* avg_reference, const FirDesignParams& p,
+                       double* taps, double* curve_raw, double* curve_smooth) {
     const int f = p.fft_size, half = f / 2;
     std::vector<double> raw(half + 1), smooth(half + 1);
     for (int k = 0; k <= half; ++k)

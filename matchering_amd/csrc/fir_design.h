@@ -36,8 +36,14 @@ void smooth_matching_curve(const double* curve, const FirDesignParams& p, double
 
 // match_frequencies.py:93-99.  avg_* have F/2+1 entries and are already expressed for
 // the level-matched target / normalised reference.  taps gets F entries.  curve_raw /
-// curve_smooth (F/2+1 each) may be null.
+// curve_smooth (F/2+1 each) may be null.  Runs the precomputed-operator plan (fir_plan.h),
+// i.e. the same phases the GPU kernel runs.
 void design_fir(const double* avg_target, const double* avg_reference, const FirDesignParams& p,
                 double* taps, double* curve_raw, double* curve_smooth);
+
+// The same design written out step by step with the restated third-party routines above
+// (no precomputation); kept as an independent cross-check of the plan.
+void design_fir_direct(const double* avg_target, const double* avg_reference, const FirDesignParams& p,
+                       double* taps, double* curve_raw, double* curve_smooth);
 
 }  // namespace mgx

@@ -12,6 +12,7 @@
 
 #include "../../include/mgx.h"
 #include "fir_design.h"
+#include "fir_plan.h"
 #include "host_params.h"
 #include "mgx_kernels.h"
 
@@ -54,6 +55,7 @@ struct DevBuf {
 
 struct TrackWork {              // per-track analysis workspace + results (device)
     DevBuf wg_sumsq, wg_peak, wg_spec, stats, rms, loud, avg;   // avg: [2][F/2+1] double
+    DevBuf part;                                                 // [SPEC_SLICES][2][F/2+1] partial spectrum sums
     int divisions = 0, segs_per_piece = 0, segs_per_wg = 0, chunks = 0;
     long long piece = 0;
 };
@@ -66,6 +68,9 @@ struct mgx_handle {
     TrackWork track[2];
     DevBuf y, mid, block_peak, fa, fc, taps, partial, cstate, scalars;
     DevBuf lim_agg, lim_carry, lim_edge;
+    DevBuf fir_scratch;
+    std::map<const FirPlanHost*, void*> plan_dev;                 // uploaded plan blobs
+    std::vector<std::shared_ptr<FirPlanHost>> plans;              // keeps the host plans alive
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
     int last_taps = 0;
@@ -200,22 +205,64 @@ static int run_analysis(mgx_handle* h, const float* x, long long n, const mgx_co
                        (const float*)w.wg_peak.p, w.chunks, w.divisions, w.piece, is_reference, cfg->threshold,
                        cfg->min_value, (TrackStats*)w.stats.p, (double*)w.rms.p, (int*)w.loud.p);
     HIP_TRY(hipGetLastError());
-    const int total = 2 * (half + 1);
-    hipLaunchKernelGGL(k_average_spectra, dim3((total + 255) / 256), dim3(256), 0, h->stream,
-                       (const float*)w.wg_spec.p, (const int*)w.loud.p, (const TrackStats*)w.stats.p, w.chunks,
-                       w.divisions, w.segs_per_piece, f, (double*)w.avg.p, (double*)w.avg.p + (half + 1));
+    MGX_TRY(ensure(h, w.part, (size_t)SPEC_SLICES * 2 * (half + 1) * sizeof(double)));
+    hipLaunchKernelGGL(k_average_spectra, dim3((half + 1 + 63) / 64, 2, SPEC_SLICES), dim3(1024), 0, h->stream,
+                       (const float*)w.wg_spec.p, (const int*)w.loud.p, w.chunks, nwg, half + 1, (double*)w.part.p);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// device-side FIR design (fir_plan.h): spectra partial sums of both tracks -> h->taps ([2][F] float),
+// level gain c0 -> h->scalars[0].  No host synchronisation.
+static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork& tw, const TrackWork& rw) {
+    FirDesignParams p{cfg->fft_size, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac,
+                      cfg->lowess_it, cfg->lowess_delta, cfg->min_value};
+    std::shared_ptr<FirPlanHost> plan = FirPlanHost::get(p);
+    void* dev_blob = nullptr;
+    auto it = h->plan_dev.find(plan.get());
+    if (it == h->plan_dev.end()) {
+        HIP_TRY(hipMalloc(&dev_blob, plan->blob_bytes()));
+        HIP_TRY(hipMemcpy(dev_blob, plan->blob(), plan->blob_bytes(), hipMemcpyHostToDevice));
+        h->plan_dev[plan.get()] = dev_blob;
+        h->plans.push_back(plan);
+    } else {
+        dev_blob = it->second;
+    }
+    const FirPlanView pl = plan->view(dev_blob);
+    const size_t per = (size_t)3 * pl.bins + (size_t)3 * pl.nlog + pl.lw.anchors;
+    MGX_TRY(ensure(h, h->fir_scratch, 2 * per * sizeof(double)));
+    MGX_TRY(ensure(h, h->scalars, 64));
+    MGX_TRY(ensure(h, h->taps, (size_t)2 * cfg->fft_size * sizeof(float)));
+    FirInputs in;
+    in.part_t = (const double*)tw.part.p;
+    in.part_r = (const double*)rw.part.p;
+    in.st_t = (const TrackStats*)tw.stats.p;
+    in.st_r = (const TrackStats*)rw.stats.p;
+    in.segs_t = tw.segs_per_piece;
+    in.segs_r = rw.segs_per_piece;
+    in.eps = cfg->min_value;
+    double* scratch = (double*)h->fir_scratch.p;
+    const size_t lds_scan = (size_t)FirDesign::Scan::SCRATCH * sizeof(Affine);
+    hipLaunchKernelGGL(k_fir_a, dim3(2), dim3(1024), lds_scan, h->stream, pl, in, scratch, (double*)h->scalars.p);
+    hipLaunchKernelGGL(k_fir_lowess, dim3((pl.lw.anchors + 15) / 16, 2), dim3(1024), 0, h->stream, pl, scratch);
+    hipLaunchKernelGGL(k_fir_b, dim3(2), dim3(1024), lds_scan, h->stream, pl, scratch);
+    const size_t lds_taps = ((size_t)pl.fft + pl.bins + 1024) * sizeof(double);
+    MGX_TRY(allow_lds(k_fir_taps, lds_taps));
+    hipLaunchKernelGGL(k_fir_taps, dim3(pl.fft / 64, 2), dim3(1024), lds_taps, h->stream, pl, (const double*)scratch,
+                       (float*)h->taps.p);
+    HIP_TRY(hipGetLastError());
+    h->last_taps = cfg->fft_size;
     return 0;
 }
 
 template <int LOG2N>
 static int launch_conv(mgx_handle* h, ConvArgs a, const float* taps_mid, const float* taps_side, double gain,
-                       int repeat) {
+                       const double* gain_ptr, int repeat) {
     const size_t lds = conv_lds_bytes<LOG2N>();
     MGX_TRY(allow_lds(k_conv_prep<LOG2N>, lds));
     MGX_TRY(allow_lds(k_conv<LOG2N>, lds));
     hipLaunchKernelGGL(k_conv_prep<LOG2N>, dim3(1), dim3(Fft<LOG2N>::T), lds, h->stream, taps_mid, taps_side,
-                       a.taps, a.tw, (float2*)h->fa.p, (float2*)h->fc.p, (const double*)nullptr, gain);
+                       a.taps, a.tw, (float2*)h->fa.p, (float2*)h->fc.p, gain_ptr, gain);
     HIP_TRY(hipGetLastError());
     const long long lout = ConvBlock<LOG2N>::lout(a.taps);
     a.nblocks = (a.n + lout - 1) / lout;
@@ -232,7 +279,8 @@ static int launch_conv(mgx_handle* h, ConvArgs a, const float* taps_mid, const f
 
 // taps_dev: [2][F] float (mid then side) already on the device
 static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const float* taps_dev, double gain,
-                    float* y, float* ymid, long long* nblocks_out, int repeat = 1) {
+                    float* y, float* ymid, long long* nblocks_out, int repeat = 1,
+                    const double* gain_ptr = nullptr) {
     const int l = ilog2_exact(taps);
     if (l < 0) return fail(MGX_ERR_ARGUMENT, "FIR length must be a power of two");
     const int log2b = l + 1;
@@ -253,7 +301,7 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     const long long lout = ((long long)1 << log2b) - taps + 1;
     if (nblocks_out) *nblocks_out = (n + lout - 1) / lout;
     switch (log2b) {
-#define CASE(L) case L: return launch_conv<L>(h, a, taps_dev, taps_dev + taps, gain, repeat);
+#define CASE(L) case L: return launch_conv<L>(h, a, taps_dev, taps_dev + taps, gain, gain_ptr, repeat);
         CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return fail(MGX_ERR_UNSUPPORTED, "FIR length not supported by the convolution kernel");
@@ -447,6 +495,13 @@ int mgx_analyze(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* 
     HIP_TRY(hipSetDevice(h->device));
     TrackWork& w = h->track[is_reference ? 1 : 0];
     MGX_TRY(run_analysis(h, x_dev, n, cfg, is_reference, w));
+    {
+        const int total = 2 * (cfg->fft_size / 2 + 1);
+        hipLaunchKernelGGL(k_finish_spectra, dim3((total + 255) / 256), dim3(256), 0, h->stream,
+                           (const double*)w.part.p, (const TrackStats*)w.stats.p, w.segs_per_piece, cfg->fft_size,
+                           (double*)w.avg.p);
+        HIP_TRY(hipGetLastError());
+    }
     TrackStats st;
     HIP_TRY(hipMemcpyAsync(&st, w.stats.p, sizeof(st), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -587,7 +642,7 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     if (!h || !target_dev || !reference_dev) return fail(MGX_ERR_ARGUMENT, "null argument");
     MGX_TRY(check_config(cfg));
     HIP_TRY(hipSetDevice(h->device));
-    const int f = cfg->fft_size, half = f / 2, bins = half + 1;
+    const int f = cfg->fft_size;
     if (result_dev) {               // validate limiter parameters before any work is queued
         LimiterParams lp;
         const std::string err = limiter_params(*cfg, lp);
@@ -598,42 +653,14 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     TrackWork& rw = h->track[1];
     MGX_TRY(run_analysis(h, target_dev, n_target, cfg, 0, tw));
     MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
-    // host round trip: 2 x TrackStats + 4 spectra
-    const size_t spec_bytes = (size_t)2 * bins * sizeof(double);
-    MGX_TRY(ensure_pinned(h, std::max((size_t)1 << 16, 2 * spec_bytes + 4096 + (size_t)2 * f * sizeof(float))));
-    char* pin = (char*)h->pinned;
-    TrackStats* st_t = (TrackStats*)pin;
-    TrackStats* st_r = (TrackStats*)(pin + 256);
-    double* avg_t = (double*)(pin + 1024);
-    double* avg_r = avg_t + 2 * bins;
-    HIP_TRY(hipMemcpyAsync(st_t, tw.stats.p, sizeof(TrackStats), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(st_r, rw.stats.p, sizeof(TrackStats), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(avg_t, tw.avg.p, spec_bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(avg_r, rw.avg.p, spec_bytes, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    const TrackStats stt = *st_t, str = *st_r;
-    const double c0 = str.match_rms / std::max(cfg->min_value, stt.match_rms);        // match_levels.py:106-111
-    // stage 2 (stages.py:107-135): FIR design on the host, float64
-    std::vector<double> fir_mid(f), fir_side(f), scaled(bins);
-    FirDesignParams p{f, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac, cfg->lowess_it,
-                      cfg->lowess_delta, cfg->min_value};
-    for (int k = 0; k < bins; ++k) scaled[k] = avg_t[k] * c0;                          // stages.py:90
-    design_fir(scaled.data(), avg_r, p, fir_mid.data(), nullptr, nullptr);
-    for (int k = 0; k < bins; ++k) scaled[k] = avg_t[bins + k] * c0;                   // stages.py:91
-    design_fir(scaled.data(), avg_r + bins, p, fir_side.data(), nullptr, nullptr);
-    MGX_TRY(ensure(h, h->taps, (size_t)2 * f * sizeof(float)));
-    float* tap_stage = (float*)(pin + 1024 + 2 * spec_bytes + 1024);
-    for (int i = 0; i < f; ++i) {
-        tap_stage[i] = (float)fir_mid[i];
-        tap_stage[f + i] = (float)fir_side[i];
-    }
-    HIP_TRY(hipMemcpyAsync(h->taps.p, tap_stage, (size_t)2 * f * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    h->last_taps = f;
+    // stage 2 (stages.py:107-135): FIR design on the device, then the overlap-save convolution with
+    // the level gain of stages.py:80-88 (a device scalar) folded into the filter spectra
+    MGX_TRY(run_fir_design(h, cfg, tw, rw));
     MGX_TRY(ensure(h, h->y, (size_t)n_target * sizeof(float2)));
     MGX_TRY(ensure(h, h->mid, (size_t)n_target * sizeof(float)));
     long long nblocks = 0;
-    MGX_TRY(run_conv(h, target_dev, n_target, f, (const float*)h->taps.p, c0, (float*)h->y.p, (float*)h->mid.p,
-                     &nblocks));
+    MGX_TRY(run_conv(h, target_dev, n_target, f, (const float*)h->taps.p, 1.0, (float*)h->y.p, (float*)h->mid.p,
+                     &nblocks, 1, (const double*)h->scalars.p));
     // stage 3 (stages.py:138-170): scalar feedback stays on the device
     MGX_TRY(ensure(h, h->cstate, sizeof(CorrectionState)));
     CorrectionState* cs = (CorrectionState*)h->cstate.p;
@@ -662,23 +689,31 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         MGX_TRY(run_limiter(h, (const float*)h->y.p, n_target, cfg, &cs->gain, post, &cs->limiter_active, result_dev));
     }
     if (report) {
+        MGX_TRY(ensure_pinned(h, 1 << 16));
+        char* pin = (char*)h->pinned;
+        TrackStats* st_t = (TrackStats*)pin;
+        TrackStats* st_r = (TrackStats*)(pin + 256);
         CorrectionState* hc = (CorrectionState*)(pin + 512);
+        double* c0 = (double*)(pin + 1024);
+        HIP_TRY(hipMemcpyAsync(st_t, tw.stats.p, sizeof(TrackStats), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(st_r, rw.stats.p, sizeof(TrackStats), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(hc, cs, sizeof(CorrectionState), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(c0, h->scalars.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
         std::memset(report, 0, sizeof(*report));
-        report->final_amplitude_coefficient = str.amplitude_c;
-        report->target_match_rms = stt.match_rms;
-        report->reference_match_rms = str.match_rms;
-        report->rms_coefficient = c0;
+        report->final_amplitude_coefficient = st_r->amplitude_c;
+        report->target_match_rms = st_t->match_rms;
+        report->reference_match_rms = st_r->match_rms;
+        report->rms_coefficient = *c0;
         for (int i = 0; i < 16; ++i) report->correction_coefficients[i] = hc->coeffs[i];
         report->normalize_coefficient = result_no_limiter_normalized_dev ? hc->normalize_c : 0.0;
         report->result_peak = hc->result_peak;
-        report->target_divisions = stt.divisions;
-        report->reference_divisions = str.divisions;
-        report->target_piece = stt.piece;
-        report->reference_piece = str.piece;
-        report->target_loud_count = stt.loud_count;
-        report->reference_loud_count = str.loud_count;
+        report->target_divisions = st_t->divisions;
+        report->reference_divisions = st_r->divisions;
+        report->target_piece = st_t->piece;
+        report->reference_piece = st_r->piece;
+        report->target_loud_count = st_t->loud_count;
+        report->reference_loud_count = st_r->loud_count;
         report->limiter_active = hc->limiter_active;
     }
     return 0;

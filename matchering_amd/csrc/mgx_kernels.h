@@ -8,6 +8,7 @@
 
 #include "analysis_kernel.h"
 #include "conv_kernel.h"
+#include "fir_plan.h"
 #include "limiter_kernel.h"
 
 namespace mgx {
@@ -231,21 +232,172 @@ __global__ __launch_bounds__(1024) void k_levels(const double* wg_sumsq, const f
 }
 
 // mean over loud pieces and segments of |rfft|/F (match_frequencies.py:42), float64
-__global__ void k_average_spectra(const float* wg_spec, const int* loud, const TrackStats* st,
-                                  int chunks_per_piece, int divisions, int segs_per_piece, int fft,
-                                  double* avg_mid, double* avg_side) {
-    const int half = fft / 2, bins = half + 1;
+// Stage 1 of a fixed-order two-stage sum: grid (bin tiles of 64, 2 planes, SPEC_SLICES); a
+// workgroup = 64 bins x 16 lanes over its slice of the analysis workgroups.  Output
+// part[z][plane][bins] (unscaled sums over the LOUD pieces' workgroups); the consumer adds
+// the SPEC_SLICES slices and applies spectrum_scale().
+constexpr int SPEC_SLICES = 8;
+__global__ __launch_bounds__(1024) void k_average_spectra(const float* wg_spec, const int* loud,
+                                                          int chunks_per_piece, int nwg, int bins, double* part) {
+    __shared__ double red[1024];
+    const int bin = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    const int plane = blockIdx.y, z = blockIdx.z;
+    const int per = (nwg + SPEC_SLICES - 1) / SPEC_SLICES;
+    const int w0 = z * per, w1 = min(nwg, w0 + per);
+    double s = 0.0;
+    if (bin < bins) {
+        for (int w = w0 + lane; w < w1; w += 16)
+            if (loud[w / chunks_per_piece]) s += (double)wg_spec[((size_t)w * 2 + plane) * bins + bin];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0 && bin < bins) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[l * 64 + (threadIdx.x & 63)];
+        part[((size_t)z * 2 + plane) * bins + bin] = t;
+    }
+}
+__device__ __forceinline__ double spectrum_scale(const TrackStats* st, int segs_per_piece, int fft) {
+    return 1.0 / ((double)st->loud_count * (double)segs_per_piece * (double)fft * st->amplitude_c);
+}
+__device__ __forceinline__ double spectrum_at(const double* part, int plane, int bins, int k) {
+    double t = 0.0;
+#pragma unroll
+    for (int z = 0; z < SPEC_SLICES; ++z) t += part[((size_t)z * 2 + plane) * bins + k];
+    return t;
+}
+// mean |rfft|/F over the loud pieces (match_frequencies.py:42) for the stage-level API
+__global__ void k_finish_spectra(const double* part, const TrackStats* st, int segs_per_piece, int fft,
+                                 double* avg /* [2][bins] */) {
+    const int bins = fft / 2 + 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * bins) return;
-    const int plane = i / bins, k = i % bins;
-    double s = 0.0;
-    for (int d = 0; d < divisions; ++d) {
-        if (!loud[d]) continue;
-        for (int ch = 0; ch < chunks_per_piece; ++ch)
-            s += (double)wg_spec[((size_t)(d * chunks_per_piece + ch) * 2 + plane) * bins + k];
+    avg[i] = spectrum_at(part, i / bins, bins, i % bins) * spectrum_scale(st, segs_per_piece, fft);
+}
+
+// ---------------------------------------------------------------------------
+// FIR design on the device (fir_plan.h): four small kernels, no host round trip
+// ---------------------------------------------------------------------------
+struct FirInputs {
+    const double* part_t;        // target spectra partial sums   [SPEC_SLICES][2][bins]
+    const double* part_r;        // reference
+    const TrackStats* st_t;
+    const TrackStats* st_r;
+    int segs_t, segs_r;
+    double eps;
+};
+__device__ __forceinline__ FirScratch fir_scratch(double* base, const FirPlanView& pl, int plane) {
+    const size_t per = (size_t)3 * pl.bins + (size_t)3 * pl.nlog + pl.lw.anchors;
+    double* p = base + (size_t)plane * per;
+    FirScratch s;
+    s.raw = p;
+    s.m1 = s.raw + pl.bins;
+    s.smooth = s.m1 + pl.bins;
+    s.on_log = s.smooth + pl.bins;
+    s.log_s = s.on_log + pl.nlog;
+    s.m2 = s.log_s + pl.nlog;
+    s.fit = s.m2 + pl.nlog;
+    return s;
+}
+__device__ __forceinline__ void fir_solve(const SplineTables& sp, const double* y, double* m, Affine* sc) {
+    using FD = FirDesign;
+    const int tid = threadIdx.x;
+    FD::phase_fwd_local(tid, sp, y, sc);
+    __syncthreads();
+    FD::Scan::scan_groups(sc, tid);
+    __syncthreads();
+    FD::Scan::scan_top(sc, tid);
+    __syncthreads();
+    FD::phase_fwd_apply(tid, sp, y, sc, m);
+    __syncthreads();
+    FD::phase_bwd_local(tid, sp, m, sc);
+    __syncthreads();
+    FD::Scan::scan_groups(sc, tid);
+    __syncthreads();
+    FD::Scan::scan_top(sc, tid);
+    __syncthreads();
+    FD::phase_bwd_apply(tid, sp, sc, m);
+    __syncthreads();
+    FD::phase_closure(tid, sp, m);
+    __syncthreads();
+}
+// raw curve -> spline onto the log grid.  grid = 2 (mid, side)
+__global__ __launch_bounds__(1024) void k_fir_a(FirPlanView pl, FirInputs in, double* scratch, double* c0_out) {
+    MGX_LDS;
+    Affine* sc = reinterpret_cast<Affine*>(mgx_smem);
+    const int tid = threadIdx.x, plane = blockIdx.x;
+    FirScratch s = fir_scratch(scratch, pl, plane);
+    const double c0 = in.st_r->match_rms / fmax(in.eps, in.st_t->match_rms);      // match_levels.py:106-111
+    if (plane == 0 && tid == 0) *c0_out = c0;
+    const double sc_t = spectrum_scale(in.st_t, in.segs_t, pl.fft) * c0;          // stages.py:90-91
+    const double sc_r = spectrum_scale(in.st_r, in.segs_r, pl.fft);
+    for (int k = tid; k < pl.bins; k += 1024) {
+        const double at = spectrum_at(in.part_t, plane, pl.bins, k) * sc_t;
+        const double ar = spectrum_at(in.part_r, plane, pl.bins, k) * sc_r;
+        s.raw[k] = ar / fmax(pl.min_value, at);                                   // match_frequencies.py:93-94
     }
-    const double scale = 1.0 / ((double)st->loud_count * (double)segs_per_piece * (double)fft * st->amplitude_c);
-    (plane == 0 ? avg_mid : avg_side)[k] = s * scale;
+    __syncthreads();
+    fir_solve(pl.s1, s.raw, s.m1, sc);
+    FirDesign::phase_eval(tid, pl.s1, s.raw, s.m1, s.on_log);
+}
+// LOWESS regressions: one wave per anchor.  grid = (ceil(anchors/16), 2)
+__global__ __launch_bounds__(1024) void k_fir_lowess(FirPlanView pl, double* scratch) {
+    const int plane = blockIdx.y;
+    const FirScratch s = fir_scratch(scratch, pl, plane);
+    const int a = blockIdx.x * 16 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (a >= pl.lw.anchors) return;
+    const double* p = pl.lw.p + (size_t)a * pl.lw.k;
+    const double* y = s.on_log + pl.lw.lo[a];
+    double acc = 0.0;
+    for (int j = lane; j < pl.lw.k; j += 64) acc = fma(p[j], y[j], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) s.fit[a] = acc;
+}
+// skipped points -> spline back onto the linear grid -> pinned bins.  grid = 2
+__global__ __launch_bounds__(1024) void k_fir_b(FirPlanView pl, double* scratch) {
+    MGX_LDS;
+    Affine* sc = reinterpret_cast<Affine*>(mgx_smem);
+    const int tid = threadIdx.x, plane = blockIdx.x;
+    FirScratch s = fir_scratch(scratch, pl, plane);
+    FirDesign::phase_lowess_fill(tid, pl.lw, s.fit, s.log_s);
+    __syncthreads();
+    fir_solve(pl.s2, s.log_s, s.m2, sc);
+    FirDesign::phase_eval(tid, pl.s2, s.log_s, s.m2, s.smooth);
+    __syncthreads();
+    FirDesign::phase_pin(tid, s);
+}
+// irfft + ifftshift + Hann (match_frequencies.py:98-99).  grid = (F/64, 2); a workgroup
+// computes 64 taps, 16 lanes each summing a slice of the bins.
+__global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double* scratch, float* taps /* [2][F] */) {
+    MGX_LDS;
+    double* cosv = reinterpret_cast<double*>(mgx_smem);     // [F]
+    double* sm = cosv + pl.fft;                             // [bins]
+    double* red = sm + pl.bins;                             // [1024]
+    const int plane = blockIdx.y, f = pl.fft, half = f / 2;
+    const FirScratch s = fir_scratch(const_cast<double*>(scratch), pl, plane);
+    for (int i = threadIdx.x; i < f; i += 1024) cosv[i] = pl.cos_table[i];
+    for (int i = threadIdx.x; i < pl.bins; i += 1024) sm[i] = s.smooth[i];
+    __syncthreads();
+    const int i = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    const int mm = (i + half) & (f - 1);
+    const int per = (half - 1 + 15) / 16;                   // bins 1 .. half-1 split over 16 lanes
+    const int k0 = 1 + lane * per, k1 = min(half, k0 + per);
+    double acc = 0.0;
+    int idx = (int)(((long long)k0 * mm) & (f - 1));
+    for (int k = k0; k < k1; ++k) {
+        acc = fma(sm[k], cosv[idx], acc);
+        idx = (idx + mm) & (f - 1);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (lane == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[l * 64 + (threadIdx.x & 63)];
+        const double v = (sm[0] + ((mm & 1) ? -sm[half] : sm[half]) + 2.0 * t) / f * pl.hann[i];
+        taps[(size_t)plane * f + i] = (float)v;
+    }
 }
 
 // ---------------------------------------------------------------------------

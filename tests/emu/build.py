@@ -5,7 +5,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 OUT = os.path.join(HERE, "libmgx_emu.so")
-SOURCES = [os.path.join(HERE, "emu.cpp"), os.path.join(ROOT, "matchering_amd", "csrc", "fir_design.cpp")]
+SOURCES = [os.path.join(HERE, "emu.cpp"), os.path.join(ROOT, "matchering_amd", "csrc", "fir_design.cpp"),
+           os.path.join(ROOT, "matchering_amd", "csrc", "fir_plan.cpp")]
 HEADERS = [os.path.join(ROOT, "matchering_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "matchering_amd", "csrc"))
            if f.endswith(".h")] + [os.path.join(ROOT, "include", "mgx.h")]
 

@@ -273,6 +273,13 @@ extern "C" int emu_design_fir(const mgx_config* cfg, const double* avg_target, c
     design_fir(avg_target, avg_reference, p, taps, curve_raw, curve_smooth);
     return 0;
 }
+extern "C" int emu_design_fir_direct(const mgx_config* cfg, const double* avg_target, const double* avg_reference,
+                                     double* taps, double* curve_raw, double* curve_smooth) {
+    FirDesignParams p{cfg->fft_size, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac,
+                      cfg->lowess_it, cfg->lowess_delta, cfg->min_value};
+    design_fir_direct(avg_target, avg_reference, p, taps, curve_raw, curve_smooth);
+    return 0;
+}
 extern "C" int emu_lowess(const double* y, int n, double frac, double delta, double* fit) {
     lowess_it0(y, n, frac, delta, fit);
     return 0;
