@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgx.so")
+LIB_PATH = os.environ.get("MGX_LIB") or os.path.join(_HERE, "libmgx.so")
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_double_p = ctypes.POINTER(ctypes.c_double)

@@ -15,18 +15,27 @@ def _deps():
     return deps
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP library in-tree.  Returns the path of the shared object."""
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in _deps()):
-        return OUT
+def build(force=False, verbose=False, out=None, extra_flags=()):
+    """Compile the HIP library in-tree.  Returns the path of the shared object.
+
+    ``out`` / ``extra_flags`` build an experimental variant next to the product (A/B runs of
+    compiler options on the GPU box: ``MGX_LIB=<path>`` makes ``_native`` load it)."""
+    out = out or OUT
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in _deps()):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
-           "-Wno-unused-result", "-Wno-unused-value", "-o", OUT] + SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+           "-Wno-unused-result", "-Wno-unused-value", *extra_flags, "-o", out] + SOURCES + [
+               "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose="-v" in sys.argv))
+    if "--variant" in sys.argv:        # python -m matchering_amd.build --variant NAME FLAG...
+        i = sys.argv.index("--variant")
+        print(build(force=True, out=os.path.join(HERE, f"libmgx_{sys.argv[i + 1]}.so"), extra_flags=sys.argv[i + 2:]))
+    else:
+        print(build(force=True, verbose="-v" in sys.argv))

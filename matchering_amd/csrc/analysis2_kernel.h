@@ -16,13 +16,14 @@
 // < F leftover frames of the piece (they count for RMS, not for the spectrum),
 // and the very last workgroup scans the ignored tail [D*p, n) for the peak.
 //
-// Per segment: z = mid + j*side, one complex FFT_F (two-for-one), then
-// |M_k| = |Z_k + conj Z_{F-k}|/2 and |S_k| = |Z_k - conj Z_{F-k}|/2 for
-// k = 0..F/2, accumulated in registers across the workgroup's segments (each
-// thread owns the same mirror pair of butterflies in every segment).
+// Per segment: z = mid + j*side, one complex FFT_F (two-for-one, fft2.h).  The last pass
+// leaves each thread with one row of 32 bins, which it writes back to LDS in position order;
+// after a barrier it reads the row holding the mirror bins F-k and accumulates
+// |M_k| = |Z_k + conj Z_{F-k}|/2 and |S_k| = |Z_k - conj Z_{F-k}|/2 in registers across the
+// workgroup's segments.
 #pragma once
 
-#include "fft_core.h"
+#include "fft2.h"
 
 namespace mgx {
 
@@ -43,110 +44,100 @@ struct AnalysisArgs {
 };
 
 template <int LOG2N>
-struct AnalysisBlock {
-    using F = Fft<LOG2N>;
+struct Analysis2Block {
+    using F = Fft2<LOG2N>;
     static constexpr int N = F::N;
     static constexpr int T = F::T;
-    static constexpr int P = F::P;
-    static constexpr int LAST = F::LAST;
-    static constexpr int RL = F::R(LAST);
-    static constexpr int LB = F::lr(LAST);
-    static constexpr int L = N / RL;
-    static constexpr int ITEMS = L / 2;
-    static constexpr int ITEM_CNT = ITEMS / T > 0 ? ITEMS / T : 1;
+    static constexpr int R0 = F::R0;
+    static constexpr int RL = F::RL;
+    static constexpr int S0 = F::S(0);
+    static constexpr int CNT0 = F::CNT(0);
 
+    struct Persist {
+        typename F::Tw0 tw0;
+    };
     struct Thread {
         double sumsq;
         float peak;
-        float acc_mid[ITEM_CNT][2 * RL];   // magnitudes of the bins this thread owns
-        float acc_side[ITEM_CNT][2 * RL];
+        float acc_mid[RL];        // magnitudes of the bins of this thread's row
+        float acc_side[RL];
+        float2 z[RL];             // the row's bins of the current segment, index = position in row
     };
 
+    static MGX_HD bool active0(int tid) { return !F::partial(0) || tid < F::NB(0); }
+
+    static MGX_HD void load_persist(int tid, const float2* tw, float2* mid_table, Persist& ps) {
+        F::load_tw0(tid, tw, ps.tw0);
+        F::fill_mid_table(tid, tw, mid_table);
+    }
     static MGX_HD void init(Thread& t) {
         t.sumsq = 0.0;
         t.peak = 0.f;
         MGX_UNROLL
-        for (int i = 0; i < ITEM_CNT; ++i) {
-            MGX_UNROLL
-            for (int q = 0; q < 2 * RL; ++q) { t.acc_mid[i][q] = 0.f; t.acc_side[i][q] = 0.f; }
-        }
+        for (int q = 0; q < RL; ++q) { t.acc_mid[q] = 0.f; t.acc_side[q] = 0.f; }
     }
-
     static MGX_HD void to_ms(float2 lr, float& m, float& s) {
         m = (lr.x + lr.y) * 0.5f;      // dsp.py:59-60
         s = m - lr.y;                  // dsp.py:62
     }
 
     // segment starting at frame `start` (always fully inside the track)
-    static MGX_HD void phase_load(int tid, long long start, const AnalysisArgs& a, Thread& t,
-                                  float2* lds) {
+    static MGX_HD void phase_load(int tid, long long start, const AnalysisArgs& a, const Persist& ps,
+                                  Thread& t, float2* lds) {
+        if (!active0(tid)) return;
         MGX_UNROLL
-        for (int i = 0; i < F::CNT(0); ++i) {
-            const int u = tid + i * T;
-            if (u < F::NB(0)) {
-                float2 v[F::R(0)];
-                float ss = 0.f;
-                MGX_UNROLL
-                for (int j = 0; j < F::R(0); ++j) {
-                    const float2 lr = a.x[start + u + (long long)j * F::S(0)];
-                    float m, s;
-                    to_ms(lr, m, s);
-                    v[j] = make_float2(m, s);
-                    ss = fmaf(m, m, ss);
-                    t.peak = fmaxf(t.peak, fmaxf(fabsf(lr.x), fabsf(lr.y)));
-                }
-                t.sumsq += (double)ss;
-                F::template fwd_store<0>(v, u, lds, a.tw);
+        for (int c = 0; c < CNT0; ++c) {
+            const int u = tid + c * T;
+            float2 v[R0];
+            float ss = 0.f;
+            MGX_UNROLL
+            for (int j = 0; j < R0; ++j) {
+                const float2 lr = a.x[start + u + (long long)j * S0];
+                float m, s;
+                to_ms(lr, m, s);
+                v[j] = make_float2(m, s);
+                ss = fmaf(m, m, ss);
+                t.peak = fmaxf(t.peak, fmaxf(fabsf(lr.x), fabsf(lr.y)));
             }
+            t.sumsq += (double)ss;
+            F::fwd0_store(v, tid, c, ps.tw0, lds);
         }
     }
-
-    static MGX_HD void phase_fwd_mid(int tid, float2* lds, const float2* tw) {
-        if (P == 3) F::template fwd_pass_lds<(P == 3 ? 1 : 0)>(tid, lds, tw);
+    static MGX_HD void phase_fwd_mid(int tid, float2* lds, const float2* mid_table) {
+        if (F::P == 3) F::fwd_mid(tid, lds, mid_table);
     }
-
-    // last forward pass + magnitude accumulation
-    static MGX_HD void phase_magnitudes(int tid, Thread& t, const float2* lds) {
+    // last forward pass on the thread's row; bins go back to LDS in position order.  Row 0 holds
+    // its own mirror bins, (0,q) <-> (0,(RL-q)%RL); thread 0 therefore stores its row rotated by
+    // one so that the uniform rule "mirror of (row,q) sits at (mirror_row, RL-1-q)" also covers
+    // it (nobody else reads row 0).
+    static MGX_HD void phase_row(int tid, Thread& t, float2* lds) {
+        if (!F::has_row(tid)) return;
+        float2 v[RL];
+        F::load_row(v, tid, lds);
+        dft_regs<RL, false>(v);
         MGX_UNROLL
-        for (int i = 0; i < ITEM_CNT; ++i) {
-            const int it = tid + i * T;
-            if (it >= ITEMS) continue;
-            const int ka = it == 0 ? 0 : it;
-            const int kb = it == 0 ? L / 2 : L - it;
-            const int ua = F::position_of(ka) / RL, ub = F::position_of(kb) / RL;
-            float2 va[RL], vb[RL];
-            F::template load_natural<LAST>(va, ua, lds);
-            F::template load_natural<LAST>(vb, ub, lds);
-            dft_regs<RL, false>(va);
-            dft_regs<RL, false>(vb);
-            MGX_UNROLL
-            for (int q = 0; q < RL; ++q) {
-                // slot q: bin of A (k = ka + L*q) against its mirror; slot RL+q: same for B
-                float2 za, zam, zb, zbm;
-                if (it != 0) {
-                    za = va[bitrev(q, LB)];
-                    zam = vb[bitrev(RL - 1 - q, LB)];
-                    zb = za;  zbm = zam;               // B's bins are A's mirrors: nothing new
-                } else {
-                    za = va[bitrev(q, LB)];
-                    zam = va[bitrev((RL - q) % RL, LB)];
-                    zb = vb[bitrev(q, LB)];
-                    zbm = vb[bitrev(RL - 1 - q, LB)];
-                }
-                // M = (Z + conj Zm)/2, S = (Z - conj Zm)/(2j): |.| only
-                {
-                    const float mx = za.x + zam.x, my = za.y - zam.y;
-                    const float sx = za.x - zam.x, sy = za.y + zam.y;
-                    t.acc_mid[i][q] += 0.5f * sqrtf(fmaf(mx, mx, my * my));
-                    t.acc_side[i][q] += 0.5f * sqrtf(fmaf(sx, sx, sy * sy));
-                }
-                if (it == 0) {
-                    const float mx = zb.x + zbm.x, my = zb.y - zbm.y;
-                    const float sx = zb.x - zbm.x, sy = zb.y + zbm.y;
-                    t.acc_mid[i][RL + q] += 0.5f * sqrtf(fmaf(mx, mx, my * my));
-                    t.acc_side[i][RL + q] += 0.5f * sqrtf(fmaf(sx, sx, sy * sy));
-                }
-            }
+        for (int q = 0; q < RL; ++q) t.z[q] = v[bitrev(q, F::lr(F::LAST))];
+        const bool r0 = tid == 0;
+        MGX_UNROLL
+        for (int e = 0; e < RL; ++e) {
+            const float2 a = t.z[e], b = t.z[(e + 1) % RL];
+            v[e] = make_float2(r0 ? b.x : a.x, r0 ? b.y : a.y);
+        }
+        F::store_row(v, tid, lds);
+    }
+    // mirror bins -> magnitudes
+    static MGX_HD void phase_magnitudes(int tid, Thread& t, const float2* lds) {
+        if (!F::has_row(tid)) return;
+        float2 m[RL];
+        F::load_row(m, F::mirror_row(tid), lds);
+        MGX_UNROLL
+        for (int q = 0; q < RL; ++q) {
+            const float2 z = t.z[q], zm = m[RL - 1 - q];
+            // M = (Z + conj Zm)/2, S = (Z - conj Zm)/(2j): |.| only
+            const float mx = z.x + zm.x, my = z.y - zm.y;
+            const float sx = z.x - zm.x, sy = z.y + zm.y;
+            t.acc_mid[q] += 0.5f * sqrtf(fmaf(mx, mx, my * my));
+            t.acc_side[q] += 0.5f * sqrtf(fmaf(sx, sx, sy * sy));
         }
     }
 
@@ -162,36 +153,24 @@ struct AnalysisBlock {
         }
     }
 
-    // write this thread's spectrum sums: every bin k in [0, F/2] is owned by exactly one slot
+    // write this thread's spectrum sums: bin k <= F/2 is written by the thread whose row holds it
     static MGX_HD void phase_write_spectrum(int tid, int wg, const AnalysisArgs& a, const Thread& t) {
+        if (!F::has_row(tid)) return;
         const int half = N / 2;
         float* mid = a.wg_spec + (size_t)wg * 2 * (half + 1);
         float* side = mid + (half + 1);
+        const int k0 = F::frequency_at(tid * RL);                // low digits of the row's bins
         MGX_UNROLL
-        for (int i = 0; i < ITEM_CNT; ++i) {
-            const int it = tid + i * T;
-            if (it >= ITEMS) continue;
-            const int ka = it == 0 ? 0 : it;
-            MGX_UNROLL
-            for (int q = 0; q < RL; ++q) {
-                const int k = ka + L * q;
-                if (it != 0) {
-                    const int kk = k <= half ? k : N - k;          // |X_k| = |X_{N-k}| for real input
-                    mid[kk] = t.acc_mid[i][q];
-                    side[kk] = t.acc_side[i][q];
-                } else {
-                    if (k <= half) { mid[k] = t.acc_mid[i][q]; side[k] = t.acc_side[i][q]; }
-                    const int k2 = L / 2 + L * q;
-                    if (k2 <= half) { mid[k2] = t.acc_mid[i][RL + q]; side[k2] = t.acc_side[i][RL + q]; }
-                }
-            }
+        for (int q = 0; q < RL; ++q) {
+            const int k = k0 + q * F::L;
+            if (k <= half) { mid[k] = t.acc_mid[q]; side[k] = t.acc_side[q]; }
         }
     }
 };
 
 // ---------------------------------------------------------------------------
-// Scalar epilogue of the analysis (one workgroup, thread 0 does the decisions).
-// match_levels.py:62-71,93-103 and the mean of match_frequencies.py:42.
+// Scalar epilogue of the analysis (host restatement used by the CPU emulation; the device
+// version is k_levels in mgx_kernels.h).  match_levels.py:62-71,93-103.
 // ---------------------------------------------------------------------------
 struct TrackStats {
     double peak;             // max |x| over the whole track (dsp.py:97)

@@ -1,0 +1,246 @@
+// Matching-EQ FIR convolution: overlap-save in LDS, two output blocks per complex FFT.
+//
+// Replaces matchering/stage_helpers/match_frequencies.py:104-119 (`convolve`: two scipy
+// fftconvolve(..., "same") calls of ONE giant FFT each, then dsp.py:67-68 ms_to_lr).
+// Restructured for the GPU:
+//
+//  * Block size N = 2F (F = taps = config.fft_size), F fresh output frames per block.  The F-tap
+//    filter is treated as F+1 taps with a leading zero (h'[k+1] = h[k]), which turns scipy's
+//    "same" offset (F-1)//2 into F/2 and makes every global access aligned: block b reads the N
+//    input frames starting at b*F - F/2 (zeros outside the track) and keeps circular outputs
+//    [F, 2F) = y[b*F ... (b+1)*F).
+//  * A workgroup takes a PAIR of neighbouring blocks (A, B).  For each channel c in (mid, side)
+//    it transforms z = c_A + j*c_B with ONE complex FFT; both blocks see the same real filter, so
+//    the spectrum is simply multiplied by H_c (no mirror-bin bookkeeping, one complex multiply
+//    per bin) and the inverse transform returns y_A in the real and y_B in the imaginary part.
+//    dsp.py:57-64 lr_to_ms is applied as the frames are loaded, dsp.py:67-68 ms_to_lr as they are
+//    stored; the mid result of both blocks waits in registers while the side channel runs.
+//  * The level gain of stages.py:80-88 is folded into H by the filter preparation.
+//  * The last forward pass, the multiplication by H and the first inverse pass are fused in
+//    registers on one contiguous LDS row per thread (fft2.h).
+//
+// HBM traffic per output frame: 8 B read (the half-block overlaps and the second channel's
+// re-read come from L2) + 8 B write + 4 B for the mid plane the level-correction loop reads
+// (stages.py:138-170).
+#pragma once
+
+#include "fft2.h"
+
+namespace mgx {
+
+struct Conv2Args {
+    const float2* x;       // (n,2) interleaved L/R input frames
+    long long n;           // frames
+    float2* y;             // (n,2) interleaved L/R output frames
+    float* ymid;           // (n,) mid of the output, or nullptr
+    const float2* h_mid;   // filter spectra, [RL][N/RL] (bin at position row*RL+q stored at q*L+row),
+    const float2* h_side;  //   already scaled by gain/N
+    const float2* tw;      // exp(-2 pi i k / N), k = 0..N-1
+    long long npairs;      // ceil(n / (2F))
+    float* pair_peak;      // [npairs] max(|yL|,|yR|) per pair, or nullptr
+};
+
+template <int LOG2N>
+struct Conv2Block {
+    using F = Fft2<LOG2N>;
+    static constexpr int N = F::N;
+    static constexpr int T = F::T;
+    static constexpr int TAPS = N / 2;
+    static constexpr int R0 = F::R0;
+    static constexpr int RL = F::RL;
+    static constexpr int S0 = F::S(0);
+    static constexpr int CNT0 = F::CNT(0);
+    static constexpr int HALF = R0 / 2;              // outputs kept per pass-0 butterfly
+    static constexpr int NLOAD = R0 + HALF;          // frames loaded per pass-0 butterfly
+
+    struct Persist {
+        typename F::Tw0 tw0;
+    };
+    struct Kept {                                     // mid results of the pair: (y_A, y_B)
+        float2 v[CNT0][HALF];
+    };
+
+    static MGX_HD bool active0(int tid) { return !F::partial(0) || tid < F::NB(0); }
+
+    static MGX_HD void load_persist(int tid, const float2* tw, float2* mid_table, Persist& ps) {
+        F::load_tw0(tid, tw, ps.tw0);
+        F::fill_mid_table(tid, tw, mid_table);
+    }
+
+    // frames of the pair: block A outputs [pair*2F, pair*2F + F), block B the next F
+    static MGX_HD long long first_output(long long pair) { return pair * (long long)N; }
+    static MGX_HD long long first_input(long long pair) { return pair * (long long)N - TAPS / 2; }
+    // every frame the pair touches lies inside the track: no bounds checks needed
+    static MGX_HD bool interior(long long pair, long long n) {
+        return first_input(pair) >= 0 && first_input(pair) + N + TAPS <= n;
+    }
+
+    // ---- phase F0: global -> registers -> pass 0 -> LDS, channel SIDE ? side : mid --------
+    // `edge` is uniform over the workgroup: only pairs touching the ends of the track pay for
+    // bounds checks.
+    template <bool SIDE>
+    static MGX_HD void phase_load(int tid, long long pair, bool edge, const Conv2Args& a, const Persist& ps,
+                                  float2* lds) {
+        if (!active0(tid)) return;
+        const long long i0 = first_input(pair);
+        MGX_UNROLL
+        for (int c = 0; c < CNT0; ++c) {
+            const int u = tid + c * T;
+            float2 f[NLOAD];
+            if (edge) {
+                MGX_UNROLL
+                for (int j = 0; j < NLOAD; ++j) {
+                    const long long g = i0 + u + (long long)j * S0;
+                    const bool ok = g >= 0 && g < a.n;
+                    const float2 t = a.x[ok ? g : 0];
+                    f[j] = make_float2(ok ? t.x : 0.f, ok ? t.y : 0.f);
+                }
+            } else {
+                // uniform displacement + one 32-bit lane offset (mgx_hd.h MemView)
+                const MemView src = mem_view(a.x, a.n * 8);
+                const unsigned lane = ((unsigned)i0 + (unsigned)u) * 8u;     // displacements below are literals
+                MGX_UNROLL
+                for (int j = 0; j < NLOAD; ++j) f[j] = ld_f2(src, lane, (unsigned)(j * S0 * 8));
+            }
+            float ch[NLOAD];
+            MGX_UNROLL
+            for (int j = 0; j < NLOAD; ++j) {
+                const float m = (f[j].x + f[j].y) * 0.5f;        // dsp.py:59-60
+                ch[j] = SIDE ? m - f[j].y : m;                   // dsp.py:62
+            }
+            float2 v[R0];
+            MGX_UNROLL
+            for (int j = 0; j < R0; ++j) v[j] = make_float2(ch[j], ch[j + HALF]);
+            F::fwd0_store(v, tid, c, ps.tw0, lds);
+        }
+    }
+
+    // ---- middle passes --------------------------------------------------------------------------
+    static MGX_HD void phase_fwd_mid(int tid, float2* lds, const float2* mid_table) {
+        if (F::P == 3) F::fwd_mid(tid, lds, mid_table);
+    }
+    static MGX_HD void phase_inv_mid(int tid, float2* lds, const float2* mid_table) {
+        if (F::P == 3) F::inv_mid(tid, lds, mid_table);
+    }
+
+    // ---- phase FPI: last forward pass, times H, first inverse pass, on the thread's row -------
+    static MGX_HD void phase_filter(int tid, const float2* h, float2* lds) {
+        if (!F::has_row(tid)) return;
+        float2 hq[RL];
+        const MemView hv = mem_view(h, (long long)N * 8);
+        MGX_UNROLL
+        for (int q = 0; q < RL; ++q) hq[q] = ld_f2(hv, (unsigned)tid * 8u, (unsigned)(q * F::L * 8));
+        float2 v[RL];
+        F::load_row(v, tid, lds);
+        dft_regs<RL, false>(v);
+        MGX_UNROLL
+        for (int q = 0; q < RL; ++q) {
+            const int i = bitrev(q, F::lr(F::LAST));
+            v[i] = cmul(v[i], hq[q]);
+        }
+        dft_regs<RL, true>(v);
+        F::store_row(v, tid, lds);
+    }
+
+    // ---- phase I0 (mid channel): inverse pass 0, keep the valid half in registers --------------
+    static MGX_HD void phase_keep_mid(int tid, const Persist& ps, const float2* lds, Kept& k) {
+        if (!active0(tid)) return;
+        MGX_UNROLL
+        for (int c = 0; c < CNT0; ++c) {
+            float2 v[R0];
+            F::inv0_load(v, tid, c, ps.tw0, lds);
+            MGX_UNROLL
+            for (int j = 0; j < HALF; ++j) k.v[c][j] = v[HALF + j];
+        }
+    }
+
+    // ---- phase I0 (side channel) + epilogue: L = mid + side, R = mid - side (dsp.py:67-68) ----
+    // returns this thread's max(|yL|,|yR|) over the frames it stored
+    static MGX_HD float phase_store(int tid, long long pair, bool edge, const Conv2Args& a, const Persist& ps,
+                                    const float2* lds, const Kept& k) {
+        float peak = 0.f;
+        if (!active0(tid)) return peak;
+        const long long o0 = first_output(pair);
+        MGX_UNROLL
+        for (int c = 0; c < CNT0; ++c) {
+            const int u = tid + c * T;
+            float2 v[R0];
+            F::inv0_load(v, tid, c, ps.tw0, lds);
+            float2 ya[HALF], yb[HALF];
+            MGX_UNROLL
+            for (int j = 0; j < HALF; ++j) {
+                const float2 m = k.v[c][j], s = v[HALF + j];
+                ya[j] = make_float2(m.x + s.x, m.x - s.x);
+                yb[j] = make_float2(m.y + s.y, m.y - s.y);
+            }
+            const long long oa = o0 + u;
+            if (edge) {
+                MGX_UNROLL
+                for (int j = 0; j < HALF; ++j) {
+                    const long long fa = oa + (long long)j * S0, fb = fa + TAPS;
+                    if (fa < a.n) {
+                        a.y[fa] = ya[j];
+                        if (a.ymid) a.ymid[fa] = k.v[c][j].x;
+                        peak = fmaxf(peak, fmaxf(fabsf(ya[j].x), fabsf(ya[j].y)));
+                    }
+                    if (fb < a.n) {
+                        a.y[fb] = yb[j];
+                        if (a.ymid) a.ymid[fb] = k.v[c][j].y;
+                        peak = fmaxf(peak, fmaxf(fabsf(yb[j].x), fabsf(yb[j].y)));
+                    }
+                }
+            } else {
+                const MemView dst = mem_view(a.y, a.n * 8);
+                const unsigned lane = ((unsigned)o0 + (unsigned)u) * 8u;
+                MGX_UNROLL
+                for (int j = 0; j < HALF; ++j) {
+                    st_f2(dst, lane, (unsigned)(j * S0 * 8), ya[j]);
+                    st_f2(dst, lane, (unsigned)((j * S0 + TAPS) * 8), yb[j]);
+                    peak = fmaxf(peak, fmaxf(fmaxf(fabsf(ya[j].x), fabsf(ya[j].y)),
+                                             fmaxf(fabsf(yb[j].x), fabsf(yb[j].y))));
+                }
+                if (a.ymid) {
+                    const MemView dm = mem_view(a.ymid, a.n * 4);
+                    const unsigned lane4 = ((unsigned)o0 + (unsigned)u) * 4u;
+                    MGX_UNROLL
+                    for (int j = 0; j < HALF; ++j) {
+                        st_f1(dm, lane4, (unsigned)(j * S0 * 4), k.v[c][j].x);
+                        st_f1(dm, lane4, (unsigned)((j * S0 + TAPS) * 4), k.v[c][j].y);
+                    }
+                }
+            }
+        }
+        return peak;
+    }
+
+    // ---- filter preparation (one workgroup per channel, once per track) ------------------------
+    // taps[0..F) -> zero-extended, delayed by one sample -> pass 0 -> LDS
+    static MGX_HD void phase_load_taps(int tid, const float* taps, const Persist& ps, float2* lds) {
+        if (!active0(tid)) return;
+        MGX_UNROLL
+        for (int c = 0; c < CNT0; ++c) {
+            const int u = tid + c * T;
+            float2 v[R0];
+            MGX_UNROLL
+            for (int j = 0; j < R0; ++j) {
+                const int i = u + j * S0;                         // h'[i] = h[i-1], i in [1, F]
+                v[j] = make_float2((i >= 1 && i <= TAPS) ? taps[i - 1] : 0.f, 0.f);
+            }
+            F::fwd0_store(v, tid, c, ps.tw0, lds);
+        }
+    }
+    // last pass of the filter transform -> table in the layout phase_filter reads
+    static MGX_HD void phase_write_filter(int tid, const float2* lds, float scale, float2* h) {
+        if (!F::has_row(tid)) return;
+        float2 v[RL];
+        F::load_row(v, tid, lds);
+        dft_regs<RL, false>(v);
+        MGX_UNROLL
+        for (int q = 0; q < RL; ++q) {
+            const float2 x = v[bitrev(q, F::lr(F::LAST))];
+            h[q * F::L + tid] = make_float2(x.x * scale, x.y * scale);
+        }
+    }
+};
+
+}  // namespace mgx

@@ -66,7 +66,7 @@ struct mgx_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<int, float2*> twiddles;
     TrackWork track[2];
-    DevBuf y, mid, block_peak, fa, fc, taps, partial, cstate, scalars;
+    DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars;
     DevBuf lim_agg, lim_carry, lim_edge;
     DevBuf fir_scratch;
     std::map<const FirPlanHost*, void*> plan_dev;                 // uploaded plan blobs
@@ -154,7 +154,7 @@ template <int LOG2N>
 static int launch_analysis(mgx_handle* h, const AnalysisArgs& a, int nwg) {
     const size_t lds = analysis_lds_bytes<LOG2N>();
     MGX_TRY(allow_lds(k_analyze<LOG2N>, lds));
-    hipLaunchKernelGGL(k_analyze<LOG2N>, dim3(nwg), dim3(Fft<LOG2N>::T), lds, h->stream, a);
+    hipLaunchKernelGGL(k_analyze<LOG2N>, dim3(nwg), dim3(Fft2<LOG2N>::T), lds, h->stream, a);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -256,22 +256,26 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
 }
 
 template <int LOG2N>
-static int launch_conv(mgx_handle* h, ConvArgs a, const float* taps_mid, const float* taps_side, double gain,
-                       const double* gain_ptr, int repeat) {
+static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr,
+                       int repeat) {
+    using F = Fft2<LOG2N>;
     const size_t lds = conv_lds_bytes<LOG2N>();
     MGX_TRY(allow_lds(k_conv_prep<LOG2N>, lds));
     MGX_TRY(allow_lds(k_conv<LOG2N>, lds));
-    hipLaunchKernelGGL(k_conv_prep<LOG2N>, dim3(1), dim3(Fft<LOG2N>::T), lds, h->stream, taps_mid, taps_side,
-                       a.taps, a.tw, (float2*)h->fa.p, (float2*)h->fc.p, gain_ptr, gain);
+    hipLaunchKernelGGL(k_conv_prep<LOG2N>, dim3(2), dim3(F::T), lds, h->stream, taps_dev, a.tw, (float2*)h->filt.p,
+                       gain_ptr, gain);
     HIP_TRY(hipGetLastError());
-    const long long lout = ConvBlock<LOG2N>::lout(a.taps);
-    a.nblocks = (a.n + lout - 1) / lout;
-    MGX_TRY(ensure(h, h->block_peak, (size_t)a.nblocks * sizeof(float)));
-    a.block_peak = (float*)h->block_peak.p;
-    const unsigned grid = (unsigned)std::min<long long>(a.nblocks, 1 << 20);
+    MGX_TRY(ensure(h, h->block_peak, (size_t)a.npairs * sizeof(float)));
+    a.pair_peak = (float*)h->block_peak.p;
+    // persistent grid: as many workgroups as fit the chip at once (LDS-limited), a multiple of 8
+    int dev_cus = 256;
+    HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    const int per_cu = std::max(1, std::min(2048 / F::T, (int)((size_t)160 * 1024 / lds)));
+    const long long cap = (long long)dev_cus * per_cu;
+    const unsigned grid = (unsigned)(((std::min<long long>(a.npairs, cap) + 7) / 8) * 8);
     if (repeat > 1) HIP_TRY(hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < repeat; ++r)
-        hipLaunchKernelGGL(k_conv<LOG2N>, dim3(grid), dim3(Fft<LOG2N>::T), lds, h->stream, a);
+        hipLaunchKernelGGL(k_conv<LOG2N>, dim3(grid), dim3(F::T), lds, h->stream, a);
     if (repeat > 1) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -279,30 +283,27 @@ static int launch_conv(mgx_handle* h, ConvArgs a, const float* taps_mid, const f
 
 // taps_dev: [2][F] float (mid then side) already on the device
 static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const float* taps_dev, double gain,
-                    float* y, float* ymid, long long* nblocks_out, int repeat = 1,
+                    float* y, float* ymid, long long* npairs_out, int repeat = 1,
                     const double* gain_ptr = nullptr) {
     const int l = ilog2_exact(taps);
     if (l < 0) return fail(MGX_ERR_ARGUMENT, "FIR length must be a power of two");
     const int log2b = l + 1;
     const size_t nb = (size_t)1 << log2b;
-    MGX_TRY(ensure(h, h->fa, nb * sizeof(float2)));
-    MGX_TRY(ensure(h, h->fc, nb * sizeof(float2)));
-    ConvArgs a;
+    MGX_TRY(ensure(h, h->filt, 2 * nb * sizeof(float2)));
+    Conv2Args a;
     a.x = reinterpret_cast<const float2*>(x);
     a.n = n;
     a.y = reinterpret_cast<float2*>(y);
     a.ymid = ymid;
-    a.fa = (const float2*)h->fa.p;
-    a.fc = (const float2*)h->fc.p;
-    a.taps = taps;
-    a.nblocks = 0;
-    a.block_peak = nullptr;
+    a.h_mid = (const float2*)h->filt.p;
+    a.h_side = (const float2*)h->filt.p + nb;
+    a.npairs = (n + (long long)nb - 1) / (long long)nb;
+    a.pair_peak = nullptr;
     MGX_TRY(get_twiddles(h, log2b, &a.tw));
-    const long long lout = ((long long)1 << log2b) - taps + 1;
-    if (nblocks_out) *nblocks_out = (n + lout - 1) / lout;
+    if (npairs_out) *npairs_out = a.npairs;
     switch (log2b) {
-#define CASE(L) case L: return launch_conv<L>(h, a, taps_dev, taps_dev + taps, gain, gain_ptr, repeat);
-        CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+#define CASE(L) case L: return launch_conv<L>(h, a, taps_dev, gain, gain_ptr, repeat);
+        CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return fail(MGX_ERR_UNSUPPORTED, "FIR length not supported by the convolution kernel");
     }
@@ -425,12 +426,12 @@ int mgx_destroy(mgx_handle* h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
-    DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->fa, &h->fc, &h->taps, &h->partial, &h->cstate,
-                      &h->scalars, &h->lim_agg, &h->lim_carry, &h->lim_edge};
+    DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
+                      &h->scalars, &h->lim_agg, &h->lim_carry, &h->lim_edge, &h->fir_scratch};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (TrackWork& w : h->track) {
-        DevBuf* tb[] = {&w.wg_sumsq, &w.wg_peak, &w.wg_spec, &w.stats, &w.rms, &w.loud, &w.avg};
+        DevBuf* tb[] = {&w.wg_sumsq, &w.wg_peak, &w.wg_spec, &w.stats, &w.rms, &w.loud, &w.avg, &w.part};
         for (DevBuf* b : tb)
             if (b->p) hipFree(b->p);
     }

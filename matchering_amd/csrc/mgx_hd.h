@@ -46,6 +46,61 @@ MGX_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 MGX_HD float2 cmul_i(float2 a) { return make_float2(-a.y, a.x); }
 MGX_HD float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }
 
+
+// ---------------------------------------------------------------------------
+// Uniform-base global memory views.
+//
+// On gfx950 a view is a buffer resource (4 SGPRs): every access is
+//     buffer_load/store  vdata, voffset(VGPR, bytes), rsrc, soffset(SGPR, bytes)
+// so a thread keeps ONE 32-bit lane offset and the per-access displacement is a scalar add
+// -- no 64-bit vector address arithmetic and nothing for the compiler to hoist into VGPRs.
+// Offsets are unsigned 32-bit byte counts (a 15-minute 96 kHz stereo float track is 691 MB).
+// The hardware range check is not relied upon: callers only issue in-range accesses.
+// Under the host emulation a view is a plain pointer.
+// ---------------------------------------------------------------------------
+#if defined(__HIPCC__) && !defined(MGX_HOST_EMU)
+struct MemView {
+    __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ MemView mem_view(const void* p, long long bytes) {
+    const long long cap = 0xfffffff0ll;
+    MemView v;
+    v.r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)(bytes < cap ? bytes : cap),
+                                            0x00020000);
+    return v;
+}
+__device__ __forceinline__ float2 ld_f2(MemView m, unsigned voff, unsigned soff) {
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    const u2_t t = __builtin_amdgcn_raw_buffer_load_b64(m.r, voff, soff, 0);
+    const unsigned a = t.x, b = t.y;
+    return make_float2(__uint_as_float(a), __uint_as_float(b));
+}
+__device__ __forceinline__ void st_f2(MemView m, unsigned voff, unsigned soff, float2 v) {
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    u2_t t;
+    t.x = __float_as_uint(v.x);
+    t.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(t, m.r, voff, soff, 0);
+}
+__device__ __forceinline__ void st_f1(MemView m, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), m.r, voff, soff, 0);
+}
+#else
+struct MemView {
+    char* p;
+};
+inline MemView mem_view(const void* p, long long) { return MemView{const_cast<char*>(static_cast<const char*>(p))}; }
+inline float2 ld_f2(MemView m, unsigned voff, unsigned soff) {
+    return *reinterpret_cast<const float2*>(m.p + (size_t)voff + (size_t)soff);
+}
+inline void st_f2(MemView m, unsigned voff, unsigned soff, float2 v) {
+    *reinterpret_cast<float2*>(m.p + (size_t)voff + (size_t)soff) = v;
+}
+inline void st_f1(MemView m, unsigned voff, unsigned soff, float v) {
+    *reinterpret_cast<float*>(m.p + (size_t)voff + (size_t)soff) = v;
+}
+#endif
+
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 constexpr int bitrev(int v, int bits) {
     int r = 0;

@@ -6,8 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
-#include "analysis_kernel.h"
-#include "conv_kernel.h"
+#include "analysis2_kernel.h"
+#include "conv2_kernel.h"
 #include "fir_plan.h"
 #include "limiter_kernel.h"
 
@@ -55,85 +55,138 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // convolution
 // ---------------------------------------------------------------------------
 template <int LOG2N>
-constexpr size_t conv_lds_bytes() { return (size_t)Fft<LOG2N>::LDS_ELEMS * sizeof(float2) + 64; }
+constexpr size_t conv_lds_bytes() {
+    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 64;
+}
 
+// one pair of output blocks: mid channel, then side channel + epilogue (conv2_kernel.h)
 template <int LOG2N>
-__global__ __launch_bounds__(Fft<LOG2N>::T) void k_conv(ConvArgs a) {
-    using CB = ConvBlock<LOG2N>;
-    using F = Fft<LOG2N>;
+__device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2Args& a,
+                                           const typename Conv2Block<LOG2N>::Persist& ps, float2* lds,
+                                           const float2* mid_table) {
+    using CB = Conv2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
+    const bool edge = !CB::interior(pair, a.n);
+    typename CB::Kept kept;
+    CB::template phase_load<false>(tid, pair, edge, a, ps, lds);
+    __syncthreads();
+    if (F::P == 3) {
+        CB::phase_fwd_mid(tid, lds, mid_table);
+        __syncthreads();
+    }
+    CB::phase_filter(tid, a.h_mid, lds);
+    __syncthreads();
+    if (F::P == 3) {
+        CB::phase_inv_mid(tid, lds, mid_table);
+        __syncthreads();
+    }
+    CB::phase_keep_mid(tid, ps, lds, kept);
+    __syncthreads();
+    CB::template phase_load<true>(tid, pair, edge, a, ps, lds);
+    __syncthreads();
+    if (F::P == 3) {
+        CB::phase_fwd_mid(tid, lds, mid_table);
+        __syncthreads();
+    }
+    CB::phase_filter(tid, a.h_side, lds);
+    __syncthreads();
+    if (F::P == 3) {
+        CB::phase_inv_mid(tid, lds, mid_table);
+        __syncthreads();
+    }
+    return CB::phase_store(tid, pair, edge, a, ps, lds, kept);
+}
+
+// Persistent workgroups.  gridDim.x is a multiple of 8; workgroup w is (observed to be) placed on
+// XCD w % 8, so XCD x walks its own contiguous eighth of the track and the workgroups resident on
+// it work on neighbouring pairs: the overlap between neighbours is re-read from that XCD's L2,
+// not from HBM.  Placement only affects speed, never results.
+template <int LOG2N>
+__global__ __launch_bounds__(Fft2<LOG2N>::T, 2) void k_conv(Conv2Args a) {
+    using CB = Conv2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
-    float* scratch = reinterpret_cast<float*>(mgx_smem + (size_t)F::LDS_ELEMS * sizeof(float2));
+    float2* mid_table = lds + F::LDS_ELEMS;
+    float* scratch = reinterpret_cast<float*>(mid_table + F::MID_TABLE);
     const int tid = threadIdx.x;
-    for (long long blk = blockIdx.x; blk < a.nblocks; blk += gridDim.x) {
-        CB::phase_load(tid, blk, a, lds);
-        __syncthreads();
-        if (F::P == 3) {
-            CB::phase_fwd_mid(tid, lds, a.tw);
-            __syncthreads();
-        }
-        CB::phase_pointwise(tid, a, lds);
-        __syncthreads();
-        if (F::P == 3) {
-            CB::phase_inv_mid(tid, lds, a.tw);
-            __syncthreads();
-        }
-        const float pk = CB::phase_store(tid, blk, a, lds);
+    typename CB::Persist ps;
+    CB::load_persist(tid, a.tw, mid_table, ps);
+    __syncthreads();
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const long long per = (a.npairs + 7) >> 3;
+    const long long end = min(a.npairs, (xcd + 1) * per);
+    for (long long pair = xcd * per + slot; pair < end; pair += slots) {
+        // The pass-0 twiddles stay in registers across pairs, but nothing derived from them (or
+        // from the thread id) should: hoisted out of this loop it would sit in VGPRs it does
+        // not have.  An empty asm makes the values opaque per iteration.
+#pragma unroll
+        for (int q = 0; q < F::R0 - 1; ++q) asm volatile("" : "+v"(ps.tw0.w[q].x), "+v"(ps.tw0.w[q].y));
+        const float pk = conv_pair<LOG2N>(tid, pair, a, ps, lds, mid_table);
         const float bp = block_max<F::T>(pk, scratch);
-        if (tid == 0 && a.block_peak) a.block_peak[blk] = bp;
+        if (tid == 0 && a.pair_peak) a.pair_peak[pair] = bp;
         __syncthreads();
     }
 }
 
+// filter spectra: grid = 2 (mid, side); taps = [2][F] float, tables = [2][N] float2
 template <int LOG2N>
-__global__ __launch_bounds__(Fft<LOG2N>::T) void k_conv_prep(const float* h_mid, const float* h_side, int taps,
-                                                             const float2* tw, float2* fa, float2* fc,
-                                                             const double* gain_ptr, double gain) {
-    using CB = ConvBlock<LOG2N>;
-    using F = Fft<LOG2N>;
+__global__ __launch_bounds__(Fft2<LOG2N>::T) void k_conv_prep(const float* taps, const float2* tw, float2* tables,
+                                                              const double* gain_ptr, double gain) {
+    using CB = Conv2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
-    const int tid = threadIdx.x;
-    CB::phase_load_taps(tid, h_mid, h_side, taps, lds, tw);
+    float2* mid_table = lds + F::LDS_ELEMS;
+    const int tid = threadIdx.x, ch = blockIdx.x;
+    typename CB::Persist ps;
+    CB::load_persist(tid, tw, mid_table, ps);
+    CB::phase_load_taps(tid, taps + (size_t)ch * CB::TAPS, ps, lds);
     __syncthreads();
     if (F::P == 3) {
-        CB::phase_fwd_mid(tid, lds, tw);
+        CB::phase_fwd_mid(tid, lds, mid_table);
         __syncthreads();
     }
-    F::template fwd_pass_lds<F::LAST>(tid, lds, tw);
-    __syncthreads();
     const double g = gain_ptr ? *gain_ptr * gain : gain;
-    CB::phase_split_filters(tid, lds, fa, fc, (float)(g / (double)F::N));
+    CB::phase_write_filter(tid, lds, (float)(g / (double)F::N), tables + (size_t)ch * F::N);
 }
 
 // ---------------------------------------------------------------------------
 // analysis
 // ---------------------------------------------------------------------------
 template <int LOG2N>
-constexpr size_t analysis_lds_bytes() { return (size_t)Fft<LOG2N>::LDS_ELEMS * sizeof(float2) + 128; }
+constexpr size_t analysis_lds_bytes() {
+    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 128;
+}
 
 template <int LOG2N>
-__global__ __launch_bounds__(Fft<LOG2N>::T) void k_analyze(AnalysisArgs a) {
-    using AB = AnalysisBlock<LOG2N>;
-    using F = Fft<LOG2N>;
+__global__ __launch_bounds__(Fft2<LOG2N>::T, 2) void k_analyze(AnalysisArgs a) {
+    using AB = Analysis2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
-    double* dscratch = reinterpret_cast<double*>(mgx_smem + (size_t)F::LDS_ELEMS * sizeof(float2));
+    float2* mid_table = lds + F::LDS_ELEMS;
+    double* dscratch = reinterpret_cast<double*>(mid_table + F::MID_TABLE);
     float* fscratch = reinterpret_cast<float*>(dscratch + 8);
     const int tid = threadIdx.x, wg = blockIdx.x;
     const int d = wg / a.chunks_per_piece, ch = wg % a.chunks_per_piece;
     typename AB::Thread th;
     AB::init(th);
+    typename AB::Persist ps;
+    AB::load_persist(tid, a.tw, mid_table, ps);
+    __syncthreads();
     const int s0 = ch * a.segs_per_wg;
     const int s1 = min(a.segs_per_piece, s0 + a.segs_per_wg);
     for (int s = s0; s < s1; ++s) {
         const long long start = (long long)d * a.piece + (long long)s * F::N;
-        AB::phase_load(tid, start, a, th, lds);
+        AB::phase_load(tid, start, a, ps, th, lds);
         __syncthreads();
         if (F::P == 3) {
-            AB::phase_fwd_mid(tid, lds, a.tw);
+            AB::phase_fwd_mid(tid, lds, mid_table);
             __syncthreads();
         }
+        AB::phase_row(tid, th, lds);
+        __syncthreads();
         AB::phase_magnitudes(tid, th, lds);
         __syncthreads();
     }

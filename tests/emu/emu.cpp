@@ -11,8 +11,8 @@
 #include <cstring>
 #include <vector>
 
-#include "../../matchering_amd/csrc/analysis_kernel.h"
-#include "../../matchering_amd/csrc/conv_kernel.h"
+#include "../../matchering_amd/csrc/analysis2_kernel.h"
+#include "../../matchering_amd/csrc/conv2_kernel.h"
 #include "../../matchering_amd/csrc/fir_design.h"
 #include "../../matchering_amd/csrc/host_params.h"
 #include "../../matchering_amd/csrc/limiter_kernel.h"
@@ -33,36 +33,43 @@ static std::vector<float2> twiddles(int n) {
 template <int LOG2N>
 static int conv_impl(const float* x, long long n, const double* fir_mid, const double* fir_side, int taps,
                      double gain, float* y, float* ymid, double* peak) {
-    using CB = ConvBlock<LOG2N>;
+    using CB = Conv2Block<LOG2N>;
     using F = typename CB::F;
     const std::vector<float2> tw = twiddles(F::N);
-    std::vector<float2> lds(F::LDS_ELEMS), fa(F::N), fc(F::N);
-    std::vector<float> hm(taps), hs(taps);
-    for (int i = 0; i < taps; ++i) { hm[i] = (float)fir_mid[i]; hs[i] = (float)fir_side[i]; }
-    FOR_THREADS(F::T) CB::phase_load_taps(tid, hm.data(), hs.data(), taps, lds.data(), tw.data());
-    FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), tw.data());
-    FOR_THREADS(F::T) F::template fwd_pass_lds<F::LAST>(tid, lds.data(), tw.data());
-    FOR_THREADS(F::T) CB::phase_split_filters(tid, lds.data(), fa.data(), fc.data(), (float)(gain / F::N));
-
-    ConvArgs a;
+    std::vector<float2> lds(F::LDS_ELEMS), mid_table(F::MID_TABLE + 1), tables(2 * F::N);
+    std::vector<float> h(2 * taps);
+    for (int i = 0; i < taps; ++i) { h[i] = (float)fir_mid[i]; h[taps + i] = (float)fir_side[i]; }
+    std::vector<typename CB::Persist> ps(F::T);
+    FOR_THREADS(F::T) CB::load_persist(tid, tw.data(), mid_table.data(), ps[tid]);
+    for (int ch = 0; ch < 2; ++ch) {
+        FOR_THREADS(F::T) CB::phase_load_taps(tid, h.data() + ch * taps, ps[tid], lds.data());
+        FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
+        FOR_THREADS(F::T) CB::phase_write_filter(tid, lds.data(), (float)(gain / F::N), tables.data() + ch * F::N);
+    }
+    Conv2Args a;
     a.x = reinterpret_cast<const float2*>(x);
     a.n = n;
     a.y = reinterpret_cast<float2*>(y);
     a.ymid = ymid;
-    a.fa = fa.data();
-    a.fc = fc.data();
+    a.h_mid = tables.data();
+    a.h_side = tables.data() + F::N;
     a.tw = tw.data();
-    a.taps = taps;
-    const long long lout = CB::lout(taps);
-    a.nblocks = (n + lout - 1) / lout;
-    a.block_peak = nullptr;
+    a.npairs = (n + F::N - 1) / F::N;
+    a.pair_peak = nullptr;
     float pk = 0.f;
-    for (long long blk = 0; blk < a.nblocks; ++blk) {
-        FOR_THREADS(F::T) CB::phase_load(tid, blk, a, lds.data());
-        FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), a.tw);
-        FOR_THREADS(F::T) CB::phase_pointwise(tid, a, lds.data());
-        FOR_THREADS(F::T) CB::phase_inv_mid(tid, lds.data(), a.tw);
-        FOR_THREADS(F::T) pk = std::fmax(pk, CB::phase_store(tid, blk, a, lds.data()));
+    std::vector<typename CB::Kept> kept(F::T);
+    for (long long pair = 0; pair < a.npairs; ++pair) {
+        const bool edge = !CB::interior(pair, n);
+        FOR_THREADS(F::T) CB::template phase_load<false>(tid, pair, edge, a, ps[tid], lds.data());
+        FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
+        FOR_THREADS(F::T) CB::phase_filter(tid, a.h_mid, lds.data());
+        FOR_THREADS(F::T) CB::phase_inv_mid(tid, lds.data(), mid_table.data());
+        FOR_THREADS(F::T) CB::phase_keep_mid(tid, ps[tid], lds.data(), kept[tid]);
+        FOR_THREADS(F::T) CB::template phase_load<true>(tid, pair, edge, a, ps[tid], lds.data());
+        FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
+        FOR_THREADS(F::T) CB::phase_filter(tid, a.h_side, lds.data());
+        FOR_THREADS(F::T) CB::phase_inv_mid(tid, lds.data(), mid_table.data());
+        FOR_THREADS(F::T) pk = std::fmax(pk, CB::phase_store(tid, pair, edge, a, ps[tid], lds.data(), kept[tid]));
     }
     if (peak) *peak = pk;
     return 0;
@@ -74,7 +81,7 @@ extern "C" int emu_convolve(const float* x, long long n, const double* fir_mid, 
     if (l < 0) return -1;
     switch (l + 1) {
 #define CASE(L) case L: return conv_impl<L>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
-        CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
+        CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return -4;
     }
@@ -85,7 +92,7 @@ template <int LOG2N>
 static int analyze_impl(const float* x, long long n, const mgx_config* cfg, int is_reference, double* peak,
                         double* amplitude_c, double* match_rms, int* divisions_out, long long* piece_out,
                         double* piece_rms, int* loud, double* avg_mid, double* avg_side) {
-    using AB = AnalysisBlock<LOG2N>;
+    using AB = Analysis2Block<LOG2N>;
     using F = typename AB::F;
     const std::vector<float2> tw = twiddles(F::N);
     int divisions;
@@ -109,14 +116,18 @@ static int analyze_impl(const float* x, long long n, const mgx_config* cfg, int 
     a.tw = tw.data();
     std::vector<float2> lds(F::LDS_ELEMS);
     std::vector<typename AB::Thread> th(F::T);
+    std::vector<typename AB::Persist> ps(F::T);
+    std::vector<float2> mid_table(F::MID_TABLE + 1);
+    FOR_THREADS(F::T) AB::load_persist(tid, a.tw, mid_table.data(), ps[tid]);
     for (int wg = 0; wg < nwg; ++wg) {
         const int d = wg / a.chunks_per_piece, ch = wg % a.chunks_per_piece;
         FOR_THREADS(F::T) AB::init(th[tid]);
         const int s0 = ch * a.segs_per_wg, s1 = std::min(a.segs_per_piece, s0 + a.segs_per_wg);
         for (int s = s0; s < s1; ++s) {
             const long long start = d * piece + (long long)s * F::N;
-            FOR_THREADS(F::T) AB::phase_load(tid, start, a, th[tid], lds.data());
-            FOR_THREADS(F::T) AB::phase_fwd_mid(tid, lds.data(), a.tw);
+            FOR_THREADS(F::T) AB::phase_load(tid, start, a, ps[tid], th[tid], lds.data());
+            FOR_THREADS(F::T) AB::phase_fwd_mid(tid, lds.data(), mid_table.data());
+            FOR_THREADS(F::T) AB::phase_row(tid, th[tid], lds.data());
             FOR_THREADS(F::T) AB::phase_magnitudes(tid, th[tid], lds.data());
         }
         if (ch == a.chunks_per_piece - 1) {

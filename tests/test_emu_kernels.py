@@ -1,0 +1,140 @@
+"""Kernel index arithmetic on the CPU: tests/emu/libmgx_emu.so drives the SAME per-thread phase
+functions the HIP kernels inline (matchering_amd/csrc/*_kernel.h), with a loop over thread ids
+where the GPU has a workgroup.  Checked against the oracle here so that a GPU run is spent on
+performance, not on off-by-one hunting.  The emulation is test infrastructure only: the shipped
+library (libmgx.so) contains no host implementation of any kernel.
+"""
+
+import ctypes
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import mastering_oracle as mo
+from cases import CASES, build_inputs, oracle_params
+from conftest import ROOT, rms_error
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    spec = importlib.util.spec_from_file_location("mgx_emu_build", os.path.join(ROOT, "tests", "emu", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return ctypes.CDLL(mod.build())
+
+
+def _fp(a):
+    return a.ctypes.data_as(c_float_p)
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def emu_convolve(emu, x, hm, hs, gain=1.0):
+    n = x.shape[0]
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.zeros((n, 2), dtype=np.float32)
+    ymid = np.zeros(n, dtype=np.float32)
+    peak = ctypes.c_double()
+    hm = np.ascontiguousarray(hm, dtype=np.float64)
+    hs = np.ascontiguousarray(hs, dtype=np.float64)
+    rc = emu.emu_convolve(_fp(x), ctypes.c_longlong(n), _dp(hm), _dp(hs), ctypes.c_int(len(hm)),
+                          ctypes.c_double(gain), _fp(y), _fp(ymid), ctypes.byref(peak))
+    assert rc == 0
+    return y, ymid, peak.value
+
+
+@pytest.mark.parametrize("taps,n", [(64, 1), (64, 333), (128, 1000), (256, 2100), (512, 2048 + 77),
+                                    (1024, 5000), (2048, 9001), (4096, 3 * 8192 + 5)])
+def test_convolution_phases(emu, taps, n):
+    rng = np.random.RandomState(taps + n)
+    x = (0.3 * rng.randn(n, 2)).astype(np.float32)
+    hm, hs = rng.randn(taps) / np.sqrt(taps), rng.randn(taps) / np.sqrt(taps)
+    y, ymid, peak = emu_convolve(emu, x, hm, hs, gain=1.7)
+    mid, side = mo.mid_side(x.astype(np.float64))
+    want, want_mid = mo.convolve_same(mid * 1.7, hm, side * 1.7, hs)
+    assert rms_error(y, want) <= 1e-6
+    assert rms_error(ymid, want_mid) <= 1e-6
+    assert abs(peak - np.abs(y).max()) <= 1e-6
+
+
+def test_convolution_identity(emu):
+    # scipy "same" centring (match_frequencies.py:112): delta at (F-1)//2 is the identity
+    rng = np.random.RandomState(5)
+    f = 256
+    x = (0.4 * rng.randn(3001, 2)).astype(np.float32)
+    delta = np.zeros(f)
+    delta[(f - 1) // 2] = 1.0
+    y, ymid, _ = emu_convolve(emu, x, delta, delta)
+    assert np.abs(y - x).max() <= 2e-6
+    assert np.abs(ymid - 0.5 * (x[:, 0] + x[:, 1])).max() <= 2e-6
+
+
+def _native_config(case_cfg):
+    import matchering_amd as mg
+
+    kw = dict(case_cfg)
+    lim = kw.pop("limiter", None)
+    if lim is not None:
+        kw["limiter"] = mg.LimiterConfig(**lim)
+    return mg.Config(**kw)
+
+
+@pytest.mark.parametrize("name", ["hot_lowrate", "quiet_reference", "custom_limiter", "cd_default"])
+def test_analysis_phases(emu, name):
+    t, r = build_inputs(CASES[name])
+    cfg = _native_config(CASES[name]["config"])
+    ocfg = oracle_params(CASES[name]["config"])
+    native = cfg.to_native()
+    for x, is_ref in ((t, 0), (r, 1)):
+        x32 = np.ascontiguousarray(x, dtype=np.float32)
+        n = x32.shape[0]
+        max_div = int(n / cfg.max_piece_size) + 1
+        half = cfg.fft_size // 2
+        peak, amp, match = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        div, piece = ctypes.c_int(), ctypes.c_longlong()
+        rms = np.zeros(max_div)
+        loud = np.zeros(max_div, dtype=np.int32)
+        avg_mid, avg_side = np.zeros(half + 1), np.zeros(half + 1)
+        rc = emu.emu_analyze(_fp(x32), ctypes.c_longlong(n), ctypes.byref(native), is_ref, ctypes.byref(peak),
+                             ctypes.byref(amp), ctypes.byref(match), ctypes.byref(div), ctypes.byref(piece),
+                             _dp(rms), loud.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _dp(avg_mid),
+                             _dp(avg_side))
+        assert rc == 0
+        x64 = x32.astype(np.float64)
+        c = 1.0
+        if is_ref:
+            x64, c = mo.peak_normalize(x64, ocfg.threshold, ocfg.min_value, False)
+        a = mo.analyze(x64, ocfg)
+        assert div.value == a.divisions and piece.value == a.piece
+        assert abs(amp.value - c) <= 1e-7
+        assert np.array_equal(np.flatnonzero(loud[: a.divisions]), a.loud_idx)
+        assert np.abs(rms[: a.divisions] / a.rmses - 1).max() <= 1e-6
+        assert abs(match.value / a.match_rms - 1) <= 1e-6
+        for mine, rows in ((avg_mid, a.mid_loud), (avg_side, a.side_loud)):
+            want = mo.average_spectrum(rows, ocfg.fft_size)
+            assert np.abs(mine - want).max() <= 2e-6 * want.max()
+
+
+@pytest.mark.parametrize("name", ["hot_lowrate", "custom_limiter"])
+def test_limiter_phases(emu, name):
+    t, r = build_inputs(CASES[name])
+    ocfg = oracle_params(CASES[name]["config"])
+    cfg = _native_config(CASES[name]["config"])
+    native = cfg.to_native()
+    tr = {}
+    mo.master(t, r, ocfg, True, True, False, trace=tr)
+    y = np.ascontiguousarray(tr["result_no_limiter"], dtype=np.float32)
+    out = np.zeros_like(y)
+    rc = emu.emu_limit(_fp(y), ctypes.c_longlong(y.shape[0]), ctypes.byref(native), ctypes.c_double(1.0),
+                       ctypes.c_double(0.9), _fp(out), None, None)
+    assert rc == 0
+    want = mo.limit(y.astype(np.float64), ocfg) * 0.9
+    assert rms_error(out, want) <= 1e-6
+    assert np.abs(out - want).max() <= 5e-6
