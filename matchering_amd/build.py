@@ -24,8 +24,10 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in _deps()):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # -fno-slp-vectorize: packing the butterflies' float pairs into v_pk_* costs more v_mov shuffles
+    # than it saves on gfx950 (k_conv 233 -> 196 us, k_analyze 108 -> 65 us, profiles/r01_d_*)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
-           "-Wno-unused-result", "-Wno-unused-value", *extra_flags, "-o", out] + SOURCES + [
+           "-fno-slp-vectorize", "-Wno-unused-result", "-Wno-unused-value", *extra_flags, "-o", out] + SOURCES + [
                "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

@@ -17,10 +17,13 @@
 // and the very last workgroup scans the ignored tail [D*p, n) for the peak.
 //
 // Per segment: z = mid + j*side, one complex FFT_F (two-for-one, fft2.h).  The last pass
-// leaves each thread with one row of 32 bins, which it writes back to LDS in position order;
-// after a barrier it reads the row holding the mirror bins F-k and accumulates
-// |M_k| = |Z_k + conj Z_{F-k}|/2 and |S_k| = |Z_k - conj Z_{F-k}|/2 in registers across the
-// workgroup's segments.
+// leaves each thread with one row of RL bins, which it writes back to LDS in position order;
+// after a barrier it reads the upper half of the row holding the mirror bins F-k and accumulates
+// |M_k| = |Z_k + conj Z_{F-k}|/2 and |S_k| = |Z_k - conj Z_{F-k}|/2 for the LOWER half of its own
+// row in registers across the workgroup's segments.  Bin (row, q) mirrors to
+// (mirror_row, RL-1-q), so the lower halves of all rows cover every pair {k, F-k} exactly once
+// (|X_k| = |X_{F-k}| for the real signals mid and side); the self-mirrored bin F/2 = (0, RL/2) is
+// one extra accumulator of thread 0.
 #pragma once
 
 #include "fft2.h"
@@ -59,9 +62,9 @@ struct Analysis2Block {
     struct Thread {
         double sumsq;
         float peak;
-        float acc_mid[RL];        // magnitudes of the bins of this thread's row
-        float acc_side[RL];
-        float2 z[RL];             // the row's bins of the current segment, index = position in row
+        float acc_mid[RL / 2 + 1];     // magnitudes of bins (row, q < RL/2); [RL/2]: bin F/2 on thread 0
+        float acc_side[RL / 2 + 1];
+        float2 z[RL / 2 + 1];          // those bins of the current segment
     };
 
     static MGX_HD bool active0(int tid) { return !F::partial(0) || tid < F::NB(0); }
@@ -74,7 +77,7 @@ struct Analysis2Block {
         t.sumsq = 0.0;
         t.peak = 0.f;
         MGX_UNROLL
-        for (int q = 0; q < RL; ++q) { t.acc_mid[q] = 0.f; t.acc_side[q] = 0.f; }
+        for (int q = 0; q <= RL / 2; ++q) { t.acc_mid[q] = 0.f; t.acc_side[q] = 0.f; }
     }
     static MGX_HD void to_ms(float2 lr, float& m, float& s) {
         m = (lr.x + lr.y) * 0.5f;      // dsp.py:59-60
@@ -112,15 +115,17 @@ struct Analysis2Block {
     // it (nobody else reads row 0).
     static MGX_HD void phase_row(int tid, Thread& t, float2* lds) {
         if (!F::has_row(tid)) return;
-        float2 v[RL];
+        float2 v[RL], w[RL];
         F::load_row(v, tid, lds);
         dft_regs<RL, false>(v);
         MGX_UNROLL
-        for (int q = 0; q < RL; ++q) t.z[q] = v[bitrev(q, F::lr(F::LAST))];
+        for (int q = 0; q < RL; ++q) w[q] = v[bitrev(q, F::lr(F::LAST))];
+        MGX_UNROLL
+        for (int q = 0; q <= RL / 2; ++q) t.z[q] = w[q];
         const bool r0 = tid == 0;
         MGX_UNROLL
         for (int e = 0; e < RL; ++e) {
-            const float2 a = t.z[e], b = t.z[(e + 1) % RL];
+            const float2 a = w[e], b = w[(e + 1) % RL];
             v[e] = make_float2(r0 ? b.x : a.x, r0 ? b.y : a.y);
         }
         F::store_row(v, tid, lds);
@@ -128,17 +133,20 @@ struct Analysis2Block {
     // mirror bins -> magnitudes
     static MGX_HD void phase_magnitudes(int tid, Thread& t, const float2* lds) {
         if (!F::has_row(tid)) return;
-        float2 m[RL];
-        F::load_row(m, F::mirror_row(tid), lds);
+        float2 m[RL / 2];                                   // mirror row, elements RL/2 .. RL-1
+        F::template load_row_part<RL / 2, RL / 2>(m, F::mirror_row(tid), lds);
         MGX_UNROLL
-        for (int q = 0; q < RL; ++q) {
-            const float2 z = t.z[q], zm = m[RL - 1 - q];
+        for (int q = 0; q < RL / 2; ++q) {
+            const float2 z = t.z[q], zm = m[RL / 2 - 1 - q];      // = mirror element RL-1-q
             // M = (Z + conj Zm)/2, S = (Z - conj Zm)/(2j): |.| only
             const float mx = z.x + zm.x, my = z.y - zm.y;
             const float sx = z.x - zm.x, sy = z.y + zm.y;
-            t.acc_mid[q] += 0.5f * sqrtf(fmaf(mx, mx, my * my));
-            t.acc_side[q] += 0.5f * sqrtf(fmaf(sx, sx, sy * sy));
+            t.acc_mid[q] += 0.5f * fast_sqrt(fmaf(mx, mx, my * my));
+            t.acc_side[q] += 0.5f * fast_sqrt(fmaf(sx, sx, sy * sy));
         }
+        // bin F/2 mirrors into itself: M = Re Z, S = Im Z (meaningful on thread 0 only)
+        t.acc_mid[RL / 2] += fabsf(t.z[RL / 2].x);
+        t.acc_side[RL / 2] += fabsf(t.z[RL / 2].y);
     }
 
     // frames outside whole segments: RMS (optional) and peak only
@@ -153,7 +161,7 @@ struct Analysis2Block {
         }
     }
 
-    // write this thread's spectrum sums: bin k <= F/2 is written by the thread whose row holds it
+    // write this thread's spectrum sums: the pair {k, F-k} of bin (row, q < RL/2) goes to min(k, F-k)
     static MGX_HD void phase_write_spectrum(int tid, int wg, const AnalysisArgs& a, const Thread& t) {
         if (!F::has_row(tid)) return;
         const int half = N / 2;
@@ -161,10 +169,13 @@ struct Analysis2Block {
         float* side = mid + (half + 1);
         const int k0 = F::frequency_at(tid * RL);                // low digits of the row's bins
         MGX_UNROLL
-        for (int q = 0; q < RL; ++q) {
+        for (int q = 0; q < RL / 2; ++q) {
             const int k = k0 + q * F::L;
-            if (k <= half) { mid[k] = t.acc_mid[q]; side[k] = t.acc_side[q]; }
+            const int kk = k <= half ? k : N - k;
+            mid[kk] = t.acc_mid[q];
+            side[kk] = t.acc_side[q];
         }
+        if (tid == 0) { mid[half] = t.acc_mid[RL / 2]; side[half] = t.acc_side[RL / 2]; }
     }
 };
 

@@ -14,13 +14,14 @@
 // After the last pass position q_0*S_0 + q_1*S_1 + ... holds X[q_0 + R_0*q_1 + R_0*R_1*q_2].
 //
 // Design rules (tools/lds_conflicts.py checks the LDS ones against the gfx950 bank model):
-//  * T = N/32 threads (>= 64).  Thread t owns butterflies u = t + c*T, c < CNT_p, in every
-//    pass, so consecutive lanes touch consecutive float2 in the strided passes (ds_read_b64 /
-//    ds_write_b64, conflict-free) and the twiddle index n = u % S_p is the same for all c
-//    (T is a multiple of S_p for p >= 1).
-//  * The last pass is radix 32 whenever N >= 512: S = 1, so a thread owns ONE contiguous row of
-//    32 float2 which it moves with 16-byte LDS accesses; with pad(i) = i + 2*(i >> 5) a row is
-//    272 bytes and both ds_read_b128 and ds_write_b128 are conflict-free.
+//  * The last pass has S = 1: a thread owns ONE contiguous row of RL float2 (RL = 32, or 16 for
+//    N = 4096) which it moves with 16-byte LDS accesses; T = N/RL threads (>= 64).  Thread t owns
+//    butterflies u = t + c*T, c < CNT_p, in the other passes, so consecutive lanes touch
+//    consecutive float2 (ds_read_b64 / ds_write_b64) and the twiddle index n = u % S_p is the
+//    same for all c (T is a multiple of S_p for p >= 1).
+//  * Two float2 of padding follow every row: pad(i) = i + 2*(i / RL).  A row is then 272 (144)
+//    bytes, ds_read_b128 / ds_write_b128 of rows are conflict-free and so are all strided
+//    writes; only the strided reads of the 4096-point plan pay a 2-way conflict.
 //  * Pass-0 twiddles w_N^(q*t) depend on the thread only: R_0-1 float2 held in VGPRs for the
 //    lifetime of a persistent workgroup; butterfly c > 0 needs w_N^(q*(t+c*T)) = that times
 //    w_32^(q*c), a literal.  Pass-1 twiddles depend on (q, n < S_1) only: a small LDS table.
@@ -125,7 +126,7 @@ MGX_PLAN(8, 2, 4, 4, 0)
 MGX_PLAN(9, 2, 4, 5, 0)
 MGX_PLAN(10, 2, 5, 5, 0)
 MGX_PLAN(11, 3, 3, 3, 5)
-MGX_PLAN(12, 3, 4, 3, 5)
+MGX_PLAN(12, 3, 4, 4, 4)
 MGX_PLAN(13, 3, 4, 4, 5)
 MGX_PLAN(14, 3, 4, 5, 5)
 #undef MGX_PLAN
@@ -135,8 +136,9 @@ struct Fft2 {
     using Plan = Fft2Plan<LOG2N>;
     static constexpr int N = 1 << LOG2N;
     static constexpr int P = Plan::P;
-    static constexpr int T = (N / 32) < 64 ? 64 : (N / 32);   // threads per workgroup
     static constexpr int LAST = P - 1;
+    static constexpr int L_ROWS = N >> Plan::LR[P - 1];
+    static constexpr int T = L_ROWS < 64 ? 64 : L_ROWS;        // threads per workgroup = rows of the last pass
 
     static constexpr int lr(int p) { return Plan::LR[p]; }
     static constexpr int R(int p) { return 1 << Plan::LR[p]; }
@@ -154,7 +156,7 @@ struct Fft2 {
     static constexpr int R0 = 1 << Plan::LR[0];
     static constexpr int RL = 1 << Plan::LR[P - 1];
     static constexpr int L = N / RL;                                             // rows of the last pass
-    static_assert(CNT(0) == 1 || N / T == 32, "pass-0 twiddle step must be a 32nd root of unity");
+    static_assert(CNT(0) == 1 || T == L, "pass-0 twiddle step between a thread's butterflies is w_RL");
     static_assert(S(LAST) == 1, "last pass works on contiguous rows");
 
     // LDS layout: two float2 of padding after every 32 (keeps 16-byte alignment of even indices).
@@ -164,8 +166,9 @@ struct Fft2 {
     // (compile time, folded into the DS instruction's immediate offset):
     //     pad(base + e*S) = pad(base) + e*(S + S/16),      pad(row*32 + e) = row*34 + e
     static constexpr bool PADDED = N >= 512;
-    static MGX_HD int pad(int i) { return PADDED ? i + ((i >> 5) << 1) : i; }
-    static constexpr int LDS_ELEMS = (PADDED ? N + ((N >> 5) << 1) : N) + 2;
+    static constexpr int LRL = Plan::LR[P - 1];               // log2 of the row length
+    static MGX_HD int pad(int i) { return PADDED ? i + ((i >> LRL) << 1) : i; }
+    static constexpr int LDS_ELEMS = (PADDED ? N + ((N >> LRL) << 1) : N) + 2;
 
     template <int PASS>
     static MGX_HD int base(int u) {              // padded index of element 0 of butterfly u
@@ -174,12 +177,11 @@ struct Fft2 {
     }
     template <int PASS>
     static constexpr int off(int e) {            // padded distance of element e from element 0
-        return PADDED ? e * S(PASS) + (((e * S(PASS)) >> 5) << 1) : e * S(PASS);
+        return PADDED ? e * S(PASS) + (((e * S(PASS)) >> LRL) << 1) : e * S(PASS);
     }
-    static_assert(!PADDED || (RL == 32), "padded plans end with a radix-32 row pass");
-    static_assert(!PADDED || P == 1 || S(0) % 32 == 0, "padded strides are multiples of 32");
+    static_assert(!PADDED || P == 1 || S(0) % RL == 0, "padded strides are multiples of the row length");
     static_assert(P < 3 || T % S(1) == 0, "one middle-pass twiddle set per thread");
-    static_assert(!PADDED || P < 3 || S(1) % 32 == 0, "padded strides are multiples of 32");
+    static_assert(!PADDED || P < 3 || S(1) % RL == 0, "padded strides are multiples of the row length");
 
     // twiddle exponent (units of 2*pi/N) for output q of butterfly u in pass p: (u % S)*q*(N/M)
     template <int PASS>
@@ -219,7 +221,7 @@ struct Fft2 {
             float2 x = v[bitrev(q, bits)];
             if (P > 1 && q != 0) {
                 float2 w = t.w[q - 1];
-                if (c != 0) w = cmulc(w, unit32(q * c));        // w_N^(q*c*T) = exp(-2 pi i q c/32)
+                if (c != 0) w = cmulc(w, unit32(q * c * (32 / RL)));   // w_N^(q*c*T) = exp(-2 pi i q c/RL)
                 x = cmul(x, w);
             }
             p[off<0>(q)] = x;
@@ -234,7 +236,7 @@ struct Fft2 {
             float2 x = p[off<0>(q)];
             if (P > 1 && q != 0) {
                 float2 w = t.w[q - 1];
-                if (c != 0) w = cmulc(w, unit32(q * c));
+                if (c != 0) w = cmulc(w, unit32(q * c * (32 / RL)));
                 x = cmulc(x, w);
             }
             v[bitrev(q, bits)] = x;
@@ -301,6 +303,22 @@ struct Fft2 {
         } else {
             MGX_UNROLL
             for (int e = 0; e < RL; ++e) v[e] = p[e];
+        }
+    }
+    // elements [E0, E0+CNT) of a row (E0, CNT even)
+    template <int E0, int CNT_>
+    static MGX_HD void load_row_part(float2 (&v)[CNT_], int row, const float2* lds) {
+        const float2* p = lds + base<LAST>(row) + E0;
+        if (PADDED) {
+            MGX_UNROLL
+            for (int e = 0; e < CNT_; e += 2) {
+                const float4 t = *reinterpret_cast<const float4*>(p + e);
+                v[e] = make_float2(t.x, t.y);
+                v[e + 1] = make_float2(t.z, t.w);
+            }
+        } else {
+            MGX_UNROLL
+            for (int e = 0; e < CNT_; ++e) v[e] = p[e];
         }
     }
     static MGX_HD void store_row(const float2 (&v)[RL], int row, float2* lds) {

@@ -101,6 +101,16 @@ inline void st_f1(MemView m, unsigned voff, unsigned soff, float v) {
 }
 #endif
 
+// sqrt to 1 ulp (v_sqrt_f32) for magnitudes; the library sqrtf adds a denormal-safe refinement
+// sequence that costs ~15 instructions
+MGX_HD float fast_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_HOST_EMU)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 constexpr int bitrev(int v, int bits) {
     int r = 0;

@@ -159,8 +159,16 @@ constexpr size_t analysis_lds_bytes() {
     return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 128;
 }
 
+// waves per SIMD the LDS footprint admits (4 SIMDs per CU): the register budget follows from it
 template <int LOG2N>
-__global__ __launch_bounds__(Fft2<LOG2N>::T, 2) void k_analyze(AnalysisArgs a) {
+constexpr int analysis_waves_per_simd() {
+    constexpr int wgs = (int)((size_t)160 * 1024 / analysis_lds_bytes<LOG2N>());
+    constexpr int w = (wgs > 8 ? 8 : wgs) * (Fft2<LOG2N>::T / 64) / 4;
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+
+template <int LOG2N>
+__global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) void k_analyze(AnalysisArgs a) {
     using AB = Analysis2Block<LOG2N>;
     using F = Fft2<LOG2N>;
     MGX_LDS;

@@ -15,3 +15,8 @@ fi
 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --workload 8min_full > $OUT/prof.log 2>&1
 DB=$(find $OUT/prof -name "*.db" | head -1)
 python tools/rocprof_stats.py $DB > $OUT/kernel_stats.txt 2>&1; cat $OUT/kernel_stats.txt
+if [ -n "$VARIANT" ]; then
+  MGX_LIB=$PWD/matchering_amd/libmgx_$VARIANT.so rocprofv3 --kernel-trace --stats -d $OUT/prof_$VARIANT -o r -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --workload 8min_full > $OUT/prof_$VARIANT.log 2>&1
+  DB=$(find $OUT/prof_$VARIANT -name "*.db" | head -1)
+  python tools/rocprof_stats.py $DB > $OUT/kernel_stats_$VARIANT.txt 2>&1; echo "variant $VARIANT"; head -12 $OUT/kernel_stats_$VARIANT.txt
+fi

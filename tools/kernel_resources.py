@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from matchering_amd import build as b
 
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
        "-Rpass-analysis=kernel-resource-usage", "-Wno-unused-value", "-o", "/tmp/libmgx_res.so"] + b.SOURCES + ["-L/opt/rocm/lib", "-lrccl"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = {}

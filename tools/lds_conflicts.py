@@ -41,19 +41,20 @@ def cycles(byte_addr_of_lane, kind):
     return total, len(groups)
 
 
-PLANS = {6: (3, 3), 7: (3, 4), 8: (4, 4), 9: (4, 5), 10: (3, 3, 4), 11: (3, 4, 4), 12: (4, 4, 4),
-         13: (4, 4, 5), 14: (4, 5, 5)}
+PLANS = {9: (4, 5), 10: (5, 5), 11: (3, 3, 5), 12: (4, 4, 4), 13: (4, 4, 5), 14: (4, 5, 5)}   # fft2.h
 
 
-def pad(i):
-    return i + ((i >> 5) << 1)
+def pad(i, lrl):
+    return i + ((i >> lrl) << 1)
 
 
 def report(log2n, threads):
     n = 1 << log2n
     plan = PLANS[log2n]
     t = threads
-    print(f"N=2^{log2n} plan={plan} T={t}  LDS elems {pad(n)}")
+    lrl = plan[-1]
+    pad_ = lambda i: pad(i, lrl)
+    print(f"N=2^{log2n} plan={plan} T={t}  LDS elems {pad_(n)}")
     m = n
     for p, lr in enumerate(plan):
         r = 1 << lr
@@ -72,7 +73,7 @@ def report(log2n, threads):
                     for e in range(0, r, 2):
                         def addr(lane, e=e):
                             u = u_of(lane)
-                            return None if u is None else 8 * pad((u // s) * m + (u % s) + e * s)
+                            return None if u is None else 8 * pad_((u // s) * m + (u % s) + e * s)
                         for kind in ("r128", "w128"):
                             cyc, base = cycles(addr, kind)
                             worst[kind] = max(worst.get(kind, 0), cyc / base)
@@ -80,7 +81,7 @@ def report(log2n, threads):
                     for e in range(r):
                         def addr(lane, e=e):
                             u = u_of(lane)
-                            return None if u is None else 8 * pad((u // s) * m + (u % s) + e * s)
+                            return None if u is None else 8 * pad_((u // s) * m + (u % s) + e * s)
                         for kind in ("r64", "w64"):
                             cyc, base = cycles(addr, kind)
                             worst[kind] = max(worst.get(kind, 0), cyc / base)
@@ -91,6 +92,4 @@ def report(log2n, threads):
 
 if __name__ == "__main__":
     for l in sorted(PLANS):
-        n = 1 << l
-        report(l, max(64, n // 32))
-    report(12, 256)
+        report(l, max(64, (1 << l) >> PLANS[l][-1]))
