@@ -6,7 +6,9 @@
 #include <string>
 
 #include "../../include/mgx.h"
-#include "limiter_kernel.h"
+#include <vector>
+
+#include "limiter2_kernel.h"
 
 namespace mgx {
 
@@ -25,9 +27,33 @@ inline Iir1 butter1(double fc, double fs) {
 }
 
 struct LimiterParams {
-    int attack, hold, hw, hb;
+    int attack, hold, hw, hb, ha;
     Iir1 att, hold_f, rel_f;
+    Limiter2Block::Geometry geo;
+    std::vector<double> w_hold, w_rel;      // look-back weights (alpha^chunk)^m
 };
+
+inline Iir1f to_f32(const Iir1& f) {
+    Iir1f r;
+    r.b0 = (float)f.b0;
+    r.alpha = (float)f.alpha;
+    r.beta = (float)f.beta;
+    double p = 1.0;
+    for (int j = 0; j <= 16; ++j) { r.pw[j] = (float)p; p *= f.alpha; }
+    return r;
+}
+inline void powers(double alpha, double (&t)[17]) {
+    double p = 1.0;
+    for (int j = 0; j <= 16; ++j) { t[j] = p; p *= alpha; }
+}
+// (alpha^chunk)^m until it drops below 1e-10 (at least one entry, at most `cap`)
+inline std::vector<double> lookback_weights(double alpha, int chunk, int cap) {
+    const double ac = std::pow(alpha, (double)chunk);
+    std::vector<double> w;
+    double p = 1.0;
+    while ((int)w.size() < cap && (w.empty() || p > 1e-10)) { w.push_back(p); p *= ac; }
+    return w;
+}
 
 // utils.py:50-55, hyrax.py:43-75.  Returns an error text, empty when fine.
 inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
@@ -41,14 +67,42 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
     const int w = (p.attack & 1) ? p.attack : p.attack + 1;
     p.hw = w - 1;
     p.hb = p.hold - 1;
-    const LimiterBlock::Geometry g = LimiterBlock::geometry(p.hw, p.hb);
-    if (g.core_blocks < 64) return "limiter attack/hold windows too long for the chunked kernel";
+    if (2 * p.hw < 16) return "limiter attack window shorter than 17 samples is not implemented";
     const double rho = std::exp(c.attack_filter_coefficient / p.attack);
     if (!(rho > 0.0 && rho < 1.0)) return "attack_filter_coefficient must be negative";
     p.att = Iir1{1.0 - rho, rho, rho * (1.0 - rho)};
     p.hold_f = butter1(c.hold_filter_coefficient, sr);
     p.rel_f = butter1(c.release_filter_coefficient / c.release_ms, sr);
+    // frames after which the attack smoother has forgotten its state (rho^ha <= 1e-8)
+    p.ha = (int)std::ceil(std::log(1e-8) / std::log(rho));
+    p.geo = Limiter2Block::geometry(p.hw, p.hb, p.ha);
+    if (p.geo.core_blocks < 64) return "limiter attack/hold times too long for the chunked kernel";
+    if (!(p.hold_f.alpha > 0.0 && p.hold_f.alpha < 1.0 && p.rel_f.alpha > 0.0 && p.rel_f.alpha < 1.0))
+        return "hold/release filter is not a stable low-pass";
+    p.w_hold = lookback_weights(p.hold_f.alpha, p.geo.chunk, 1 << 16);
+    p.w_rel = lookback_weights(p.rel_f.alpha, p.geo.chunk, 1 << 16);
     return "";
+}
+
+// fills everything of Limiter2Args that derives from the parameters (pointers are the caller's)
+inline void limiter_fill(const LimiterParams& p, float threshold, Limiter2Args& a) {
+    a.threshold = threshold;
+    a.hw = p.hw;
+    a.hb = p.hb;
+    a.gl = p.geo.gl;
+    a.gr = p.geo.gr;
+    a.gw = p.geo.gw;
+    a.att = p.att;
+    a.hold = p.hold_f;
+    a.rel = p.rel_f;
+    a.attf = to_f32(p.att);
+    a.holdf = to_f32(p.hold_f);
+    a.relf = to_f32(p.rel_f);
+    powers(p.att.alpha, a.pa);
+    powers(p.hold_f.alpha, a.ph);
+    powers(p.rel_f.alpha, a.pr);
+    a.n_hold = (int)p.w_hold.size();
+    a.n_rel = (int)p.w_rel.size();
 }
 
 inline int ilog2_exact(int v) {

@@ -1,0 +1,539 @@
+// Hyrax brick-wall limiter (matchering/limiter/hyrax.py:78-99) in ONE streaming pass.
+//
+// Reference data flow (every array is length n, float64):
+//   rect  = max(|L|,|R|) floored at thr, / thr                    dsp.py:117-121
+//   g0    = 1 - 1/rect                                            hyrax.py:87
+//   sl    = centred sliding max of g0, window 2w-1, w = odd(att)  hyrax.py:35-37
+//   gA    = filtfilt(1-pole rho = exp(coef/att), sl)              hyrax.py:48-51
+//   sh    = trailing sliding max of sl over `hold` samples        hyrax.py:38-40
+//   ho    = lfilter(butter(hold order, hold Hz), sh)              hyrax.py:61-66
+//   ro    = lfilter(butter(rel order, rel Hz), max(sh, ho))       hyrax.py:68-73
+//   gain  = 1 - max(g0, gA, max(ho, ro));  out = x * gain         hyrax.py:75,97,99
+//
+// GPU formulation.  The track is cut into chunks of C = CB*16 frames; a chunk is one 512-thread
+// workgroup whose thread t owns "block" t = 16 consecutive frames, GL halo blocks before the
+// chunk's CB core blocks and GR after them.
+//
+//  * Frames are loaded coalesced (16 B per lane); only g0 travels through LDS to the owning
+//    thread.  The final gain travels back the same way and the frames are re-read (L2) for the
+//    coalesced store: 8 B/frame read + 8 B/frame written reach HBM.
+//  * Both sliding maxima are windows of g0 itself (sh[n] = max g0[n-hw-hb .. n+hw]): per-block
+//    prefix/suffix maxima in LDS give each output with two LDS reads (van Herk).
+//  * Every recurrence is first order (state z: y[n] = b0 x[n] + z[n-1], z[n] = alpha z[n-1] +
+//    beta x[n], scipy's transposed direct form II).  A thread runs its 16 frames in float32 from
+//    a zero state; its block acts on the carried state as an affine map, the maps are composed
+//    across the workgroup by an ordered float64 scan (scan_util.h), and the exact outputs are the
+//    local run plus alpha^j times the carry.  Rounding never accumulates beyond 16 frames.
+//  * The attack smoother's pole rho = exp(coef/attack) forgets quickly: rho^HA <= 1e-8 after
+//    HA ~ 9*attack frames.  The halos are HA (+ window) frames long, so the forward run started
+//    from zero at the left halo and the backward run started from zero at the right halo are
+//    exact (to 1e-8) inside the core: scipy.signal.filtfilt needs no hand-off between chunks.
+//    Its edge handling (odd extension by 6, steady-state initial conditions) is applied by the
+//    chunks that contain frame 0 / frame n-1.
+//  * The hold and release low-passes remember for seconds.  Each chunk publishes the state its
+//    frames produce from a zero carry (one float64 per filter, written once); a chunk's carry is
+//    sum_m (alpha^C)^m * published[chunk-1-m], truncated where (alpha^C)^m <= 1e-10 (3 chunks for
+//    the 7 Hz hold filter, ~70 for the 0.27 Hz release filter).  No chunk ever waits for another
+//    chunk's look-back of the same filter, so the dependency depth is two (release aggregates need
+//    the exact hold output) however long the track is.  Chunk numbers are drawn from an atomic
+//    ticket, so every chunk a workgroup waits for has already started.
+//
+// Published words are 8-byte granules whose value is the flag: the array is preset to all-ones
+// (not a finite double) before each launch and written with one relaxed agent-scope atomic store
+// (MI355X_MICROARCH.md, inter-workgroup visibility: a single naturally aligned 8-byte sc1 store,
+// polled with relaxed sc1 loads, needs no fence).  Every poll loop is bounded.
+#pragma once
+
+#include "scan_util.h"
+
+namespace mgx {
+
+struct Iir1 {
+    double b0, alpha, beta;        // y = b0*x + z_prev ; z = alpha*z_prev + beta*x
+};
+struct Iir1f {
+    float b0, alpha, beta;
+    float pw[17];                  // alpha^j, j = 0..16
+};
+
+struct Limiter2Args {
+    const float2* y;               // (n,2) level-corrected result before the final gains
+    long long n;
+    float2* out;                   // (n,2) limited output
+    const double* gain;            // device scalar: accumulated level-correction gain
+    const double* post_gain;       // device scalar: final amplitude coefficient (stages.py:203)
+    const int* active;             // device flag: 0 => limiter early-out (hyrax.py:83-85)
+    float threshold;
+    int hw;                        // attack half window = odd(attack) - 1
+    int hb;                        // hold look-back     = hold - 1
+    int gl, gr, gw;                // halo blocks left / right; blocks without a full sl window
+    Iir1 att, hold, rel;           // float64 coefficients (edge states, aggregates)
+    Iir1f attf, holdf, relf;       // float32 copies for the per-frame arithmetic
+    double pa[17], ph[17], pr[17]; // alpha^j in float64, j = 0..16 (aggregate of a partial block)
+    long long nchunks;
+    unsigned long long* published; // [2][nchunks]: hold, release chunk aggregates (bit patterns)
+    const double* w_hold;          // (alpha_hold^C)^m, m = 0..n_hold-1
+    const double* w_rel;
+    int n_hold, n_rel;
+    int* ticket;                   // chunk dispenser (zeroed before the launch)
+    int* error;                    // set to 1 if a bounded wait expired
+};
+
+constexpr unsigned long long LIMITER_UNPUBLISHED = ~0ull;
+
+// ---- inter-workgroup words ---------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_HOST_EMU)
+__device__ __forceinline__ void publish_word(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long poll_word(unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void backoff() { __builtin_amdgcn_s_sleep(8); }
+#else
+inline void publish_word(unsigned long long* p, unsigned long long v) { *p = v; }
+inline unsigned long long poll_word(unsigned long long* p) { return *p; }
+inline void backoff() {}
+#endif
+MGX_HD unsigned long long double_bits(double v) {
+    union { double d; unsigned long long u; } c;
+    c.d = v;
+    return c.u;
+}
+MGX_HD double bits_double(unsigned long long u) {
+    union { double d; unsigned long long u; } c;
+    c.u = u;
+    return c.d;
+}
+
+struct Limiter2Block {
+    static constexpr int T = 512;
+    static constexpr int E = 16;
+    static constexpr int STRIDE = E + 1;               // LDS row stride (floats): conflict-free columns
+    static constexpr int G = 16;
+    using Scan = WgScan<T, G, 2>;
+    static constexpr int FRAMES = T * E;               // frames a workgroup touches
+    static constexpr int PLANE = T * STRIDE;           // floats
+    static constexpr int MAX_SPINS = 1 << 20;            // x ~0.2 us of s_sleep: a fifth of a second
+
+    // LDS carve (floats unless noted).  The window planes are dead once sl/sh are in registers,
+    // so the scan scratch and the gain plane live in the same bytes.
+    //   [0, 2*PLANE)              planes: g0 -> prefix maxima | suffix maxima
+    //   [0, SCAN_FLOATS)          scan scratch (Affine = 4 floats), aliasing plane 0
+    //   [GAIN_OFF, +PLANE)        gain plane, aliasing the tail of plane 0 / plane 1
+    //   [2*PLANE, +T)             per-block maxima
+    //   [MISC_OFF, ...)           edge samples, look-back partials, broadcast scalars (never aliased)
+    static constexpr int SCAN_FLOATS = Scan::SCRATCH * 4;
+    static constexpr int GAIN_OFF = ((SCAN_FLOATS + 3) / 4) * 4;
+    static_assert(GAIN_OFF + PLANE <= 2 * PLANE, "gain plane must fit behind the scan scratch");
+    static constexpr int BM_OFF = 2 * PLANE;
+    static constexpr int MISC_OFF = BM_OFF + T;
+    static constexpr int MISC_FLOATS = 16 + 2 * 64 + 16;       // edge sl[14] | 64 doubles | 8 doubles
+    static constexpr size_t LDS_BYTES = (size_t)(MISC_OFF + MISC_FLOATS) * 4 + 16;
+
+    static MGX_HD float* plane(float* lds, int i) { return lds + i * PLANE; }
+    static MGX_HD float* block_max(float* lds) { return lds + BM_OFF; }
+    static MGX_HD Affine* scan_area(float* lds) { return reinterpret_cast<Affine*>(lds); }
+    static MGX_HD float* gain_plane(float* lds) { return lds + GAIN_OFF; }
+    static MGX_HD float* edge_sl(float* lds) { return lds + MISC_OFF; }                 // [14]
+    static MGX_HD double* partials(float* lds) { return reinterpret_cast<double*>(lds + MISC_OFF + 16); }   // [64]
+    static MGX_HD double* scalars(float* lds) { return reinterpret_cast<double*>(lds + MISC_OFF + 16 + 128); }
+    //   scalars: [0] hold chunk carry, [1] release chunk carry
+    static MGX_HD int gidx(int i) { return (i >> 4) * STRIDE + (i & 15); }
+
+    struct Geometry {
+        int gl, gr, gw, core_blocks, chunk;
+    };
+    // ha = frames after which the attack pole has decayed to 1e-8
+    static MGX_HD Geometry geometry(int hw, int hb, int ha) {
+        Geometry g;
+        g.gw = (hw + E - 1) / E;
+        const int hab = (ha + E - 1) / E;
+        const int left_window = (hw + hb + E - 1) / E;
+        g.gl = hab + g.gw > left_window ? hab + g.gw : left_window;
+        g.gr = hab + g.gw;
+        g.core_blocks = T - g.gl - g.gr;
+        g.chunk = g.core_blocks * E;
+        return g;
+    }
+
+    struct Thread {
+        long long base;           // first frame of this thread's block
+        int valid;                // frames of the block inside [0, n)
+        bool core, has_sl;
+        float g0[E], sl[E], sh[E];
+        float yf[E], x2[E], m[E];         // attack forward output; max(sh,ho); max(g0,ho)
+        float za[E], zb[E];               // zero-carry run states of the two recurrences in flight
+        bool inject_left, inject_right;   // this block starts at frame 0 / holds frame n-1
+        double edge_state;                // filtfilt state to inject (left: entering frame 0; right: entering n-1)
+    };
+
+    static MGX_HD long long region_start(long long chunk, const Limiter2Args& a) {
+        return chunk * (long long)((T - a.gl - a.gr) * E) - (long long)a.gl * E;
+    }
+
+    // ---- P1: coalesced load, g0 -> LDS (natural order) --------------------------------------
+    static MGX_HD float gain_of(float2 v, float thr) {
+        const float amax = fmaxf(fabsf(v.x), fabsf(v.y));
+        // 1 - 1/(amax/thr) = (amax - thr)/amax, zero at or below the threshold (dsp.py:117-121, hyrax.py:87)
+        return amax > thr ? (amax - thr) / amax : 0.f;
+    }
+    static MGX_HD float2 scaled(float2 y, double g) {
+        return make_float2((float)((double)y.x * g), (float)((double)y.y * g));
+    }
+    static MGX_HD void phase_load(int tid, long long chunk, const Limiter2Args& a, float* lds) {
+        const long long r0 = region_start(chunk, a);
+        const bool interior = r0 >= 0 && r0 + FRAMES <= a.n;
+        const double g = *a.gain;
+        float* gp = plane(lds, 0);
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) {
+            const int i = 2 * tid + 2 * T * j;               // two consecutive frames per lane
+            float2 v0 = make_float2(0.f, 0.f), v1 = v0;
+            if (interior) {
+                const float4 q = *reinterpret_cast<const float4*>(a.y + (r0 + i));
+                v0 = make_float2(q.x, q.y);
+                v1 = make_float2(q.z, q.w);
+            } else {
+                const long long f = r0 + i;
+                if (f >= 0 && f < a.n) v0 = a.y[f];
+                if (f + 1 >= 0 && f + 1 < a.n) v1 = a.y[f + 1];
+            }
+            gp[gidx(i)] = gain_of(scaled(v0, g), a.threshold);
+            gp[gidx(i + 1)] = gain_of(scaled(v1, g), a.threshold);
+        }
+    }
+
+    // ---- P2: own block of g0 -> registers; prefix/suffix maxima -> LDS -------------------------
+    static MGX_HD void phase_planes(int tid, long long chunk, const Limiter2Args& a, Thread& th, float* lds) {
+        th.base = region_start(chunk, a) + (long long)tid * E;
+        th.core = tid >= a.gl && tid < T - a.gr;
+        th.has_sl = tid >= a.gw && tid < T - a.gw;
+        const long long left = a.n - th.base;
+        th.valid = th.base < 0 ? 0 : (left >= E ? E : (left > 0 ? (int)left : 0));
+        float* gp = plane(lds, 0) + tid * STRIDE;
+        float* gs = plane(lds, 1) + tid * STRIDE;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) th.g0[j] = gp[j];
+        float run = 0.f;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) { run = fmaxf(run, th.g0[j]); gp[j] = run; }
+        block_max(lds)[tid] = run;
+        run = 0.f;
+        MGX_UNROLL
+        for (int j = E - 1; j >= 0; --j) { run = fmaxf(run, th.g0[j]); gs[j] = run; }
+    }
+
+    // max of g0 over [c - lw, c + rw] for the 16 frames c of block tid (van Herk: suffix maximum of
+    // the block holding the window's first frame, prefix maximum of the block holding its last
+    // frame, whole-block maxima in between).  Needs lw + rw >= 16, so that the two ends never
+    // share a block, and blocks tid-ceil(lw/16) .. tid+ceil(rw/16) inside the workgroup.
+    static MGX_HD void window_max(int tid, int lw, int rw, const float* lds, float (&out)[E]) {
+        const float* gp = plane(const_cast<float*>(lds), 0);
+        const float* gs = plane(const_cast<float*>(lds), 1);
+        const float* bm = block_max(const_cast<float*>(lds));
+        const int la = lw >> 4, lb = lw & 15, ra = rw >> 4, rb = rw & 15;
+        // blocks tid-la+1 .. tid+ra-1 lie strictly inside every window of this block
+        float core = 0.f;
+        for (int k = tid - la + 1; k <= tid + ra - 1; ++k) core = fmaxf(core, bm[k]);
+        const float ml = bm[tid - la], mr = bm[tid + ra];
+        const bool apart = la + ra > 0;                   // tid-la and tid+ra are different blocks
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) {
+            // first frame c - lw: block tid-la at offset j-lb, or (j < lb) one block further left
+            // last frame c + rw: block tid+ra at offset j+rb, or (j+rb >= 16) one block further right
+            const bool far_l = j < lb, far_r = j + rb >= E;
+            const float lft = far_l ? gs[(tid - la - 1) * STRIDE + (E + j - lb)] : gs[(tid - la) * STRIDE + (j - lb)];
+            const float rgt = far_r ? gp[(tid + ra + 1) * STRIDE + (j + rb - E)] : gp[(tid + ra) * STRIDE + (j + rb)];
+            float m = fmaxf(core, fmaxf(lft, rgt));
+            // block tid-la is whole inside the window when the window starts left of it and ends
+            // right of it; likewise block tid+ra
+            if (far_l && (apart || far_r)) m = fmaxf(m, ml);
+            if (far_r && (apart || far_l)) m = fmaxf(m, mr);
+            out[j] = m;
+        }
+    }
+
+    // first-order recurrence over a thread's frames from a zero state, float32:
+    // z[j] = state after frame j (frames >= count do not advance the state)
+    static MGX_HD float run_forward(const Iir1f& f, const float (&x)[E], int count, float (&z)[E]) {
+        float s = 0.f;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) {
+            if (j < count) s = fmaf(f.alpha, s, f.beta * x[j]);
+            z[j] = s;
+        }
+        return s;
+    }
+    static MGX_HD float run_backward(const Iir1f& f, const float (&x)[E], int count, float (&z)[E]) {
+        float s = 0.f;
+        MGX_UNROLL
+        for (int j = E - 1; j >= 0; --j) {
+            if (j < count) s = fmaf(f.alpha, s, f.beta * x[j]);
+            z[j] = s;
+        }
+        return s;
+    }
+    // outputs given the state entering the run
+    static MGX_HD void out_forward(const Iir1f& f, const float (&x)[E], const float (&z)[E], float carry,
+                                   float (&y)[E]) {
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) {
+            const float zprev = (j == 0 ? 0.f : z[j - 1]) + f.pw[j] * carry;
+            y[j] = fmaf(f.b0, x[j], zprev);
+        }
+    }
+    static MGX_HD void out_backward(const Iir1f& f, const float (&x)[E], const float (&z)[E], int count,
+                                    float carry, float (&y)[E]) {
+        float pw = 1.f;                       // alpha^(frames already processed): count-1-j at frame j
+        MGX_UNROLL
+        for (int j = E - 1; j >= 0; --j) {
+            if (j < count) {
+                const float znext = (j + 1 < count ? z[j + 1] : 0.f) + pw * carry;
+                y[j] = fmaf(f.b0, x[j], znext);
+                pw *= f.alpha;
+            } else {
+                y[j] = 0.f;
+            }
+        }
+    }
+    // alpha^count for the aggregate of a block with `count` valid frames: table[E] for a full block
+    static MGX_HD double block_decay(const double (&table)[17], double alpha, int count) {
+        if (count == E) return table[E];
+        double r = 1.0;
+        for (int i = 0; i < count; ++i) r *= alpha;
+        return r;
+    }
+
+    // scipy.signal.filtfilt edges (padtype 'odd', padlen 6, lfilter_zi), float64
+    static MGX_HD double filtfilt_left_state(const Iir1& f, const float* sl0 /* sl[0..6] */) {
+        const double x0 = (double)sl0[0];
+        const double zi = f.beta / (1.0 - f.alpha);
+        double z = 0.0;
+        for (int i = 0; i < 6; ++i) {
+            const double e = 2.0 * x0 - (double)sl0[6 - i];
+            if (i == 0) z = zi * e;
+            z = fma(f.alpha, z, f.beta * e);
+        }
+        return z;
+    }
+    // sl_end = sl[n-7 .. n-1]; z_end = forward state after frame n-1.  Returns the backward state
+    // entering frame n-1.
+    static MGX_HD double filtfilt_right_state(const Iir1& f, const float* sl_end, double z_end) {
+        const double xl = (double)sl_end[6];
+        const double zi = f.beta / (1.0 - f.alpha);
+        double yfe[6];
+        double z = z_end;
+        for (int i = 0; i < 6; ++i) {
+            const double e = 2.0 * xl - (double)sl_end[5 - i];
+            yfe[i] = fma(f.b0, e, z);
+            z = fma(f.alpha, z, f.beta * e);
+        }
+        double zb = zi * yfe[5];
+        for (int i = 5; i >= 0; --i) zb = fma(f.alpha, zb, f.beta * yfe[i]);
+        return zb;
+    }
+
+    // ---- P3: sl, sh, zero-carry runs of the forward attack smoother and the hold filter -------
+    static MGX_HD void phase_windows(int tid, const Limiter2Args& a, Thread& th, float* lds) {
+        th.inject_left = false;
+        th.inject_right = false;
+        th.edge_state = 0.0;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) { th.sl[j] = 0.f; th.sh[j] = 0.f; th.za[j] = 0.f; th.zb[j] = 0.f; }
+        if (th.has_sl) {
+            window_max(tid, a.hw, a.hw, lds, th.sl);
+            MGX_UNROLL
+            for (int j = 0; j < E; ++j)
+                if (j >= th.valid) th.sl[j] = 0.f;            // windows are truncated at the array ends
+            if (th.base < 0) {
+                MGX_UNROLL
+                for (int j = 0; j < E; ++j) th.sl[j] = 0.f;
+            }
+            // filtfilt edge samples sl[n-7 .. n-1] for whoever holds frame n-1
+            MGX_UNROLL
+            for (int j = 0; j < E; ++j) {
+                const long long f = th.base + j;
+                if (j < th.valid && f >= a.n - 7) edge_sl(lds)[7 + (int)(f - (a.n - 7))] = th.sl[j];
+            }
+            th.inject_left = th.base == 0;
+            th.inject_right = th.valid > 0 && th.base + th.valid == a.n;
+            run_forward(a.attf, th.sl, th.valid, th.za);
+        }
+        if (th.core) {
+            window_max(tid, a.hw + a.hb, a.hw, lds, th.sh);
+            MGX_UNROLL
+            for (int j = 0; j < E; ++j)
+                if (j >= th.valid) th.sh[j] = 0.f;
+            run_forward(a.holdf, th.sh, th.valid, th.zb);
+        }
+    }
+
+    // ---- P4: block aggregates of both runs -> scan scratch (aliases the planes: barrier first) --
+    static MGX_HD void phase_put_first(int tid, const Limiter2Args& a, Thread& th, float* lds) {
+        Affine m_att = affine_identity(), m_hold = affine_identity();
+        if (th.has_sl && th.valid > 0) {
+            const double decay = block_decay(a.pa, a.att.alpha, th.valid);
+            m_att = Affine{decay, (double)th.za[E - 1]};
+            if (th.inject_left) {
+                // state entering frame 0 is the filtfilt steady-state start, whatever precedes it
+                th.edge_state = filtfilt_left_state(a.att, th.sl);
+                m_att = Affine{0.0, fma(decay, th.edge_state, (double)th.za[E - 1])};
+            }
+        }
+        if (th.core && th.valid > 0) m_hold = Affine{block_decay(a.ph, a.hold.alpha, th.valid), (double)th.zb[E - 1]};
+        Affine* sc = scan_area(lds);
+        Scan::put(sc, 0, tid, m_att);
+        Scan::put(sc, 1, tid, m_hold);
+    }
+
+    // ---- chunk carries: publish this chunk's zero-carry state, gather the predecessors' --------
+    // slot 0 = hold, 1 = release.  Thread 0 publishes; threads 0..63 fetch; thread 0 reduces.
+    static MGX_HD void lookback_publish(int tid, long long chunk, int slot, const Limiter2Args& a, const float* lds) {
+        if (tid == 0) {
+            const Affine whole = Scan::whole(scan_area(const_cast<float*>(lds)), 1);
+            publish_word(a.published + (size_t)slot * a.nchunks + chunk, double_bits(whole.b));
+        }
+    }
+    static MGX_HD void lookback_fetch(int tid, long long chunk, int slot, const Limiter2Args& a, float* lds) {
+        if (tid >= 64) return;
+        const double* w = slot == 0 ? a.w_hold : a.w_rel;
+        const int count = slot == 0 ? a.n_hold : a.n_rel;
+        double acc = 0.0;
+        for (int m = tid; m < count; m += 64) {
+            const long long c = chunk - 1 - m;
+            if (c < 0) break;
+            unsigned long long* p = a.published + (size_t)slot * a.nchunks + c;
+            unsigned long long v = poll_word(p);
+            int spins = 0;
+            while (v == LIMITER_UNPUBLISHED && spins < MAX_SPINS) {
+                backoff();
+                v = poll_word(p);
+                ++spins;
+            }
+            if (v == LIMITER_UNPUBLISHED) {
+                *a.error = 1;
+                v = 0;
+            }
+            acc = fma(w[m], bits_double(v), acc);
+        }
+        partials(lds)[tid] = acc;
+    }
+    static MGX_HD void lookback_reduce(int tid, int slot, float* lds) {
+        if (tid != 0) return;
+        double s = 0.0;
+        for (int i = 0; i < 64; ++i) s += partials(lds)[i];
+        scalars(lds)[slot] = s;
+    }
+
+    // ---- P5: exact forward attack output and hold output; zero-carry runs of the backward attack
+    //          smoother (input yf) and the release filter (input max(sh, ho)) ----------------------
+    struct Second {
+        Affine m_bwd, m_rel;
+    };
+    static MGX_HD Second phase_exact_first(int tid, const Limiter2Args& a, Thread& th, const float* lds) {
+        Second r;
+        r.m_bwd = affine_identity();
+        r.m_rel = affine_identity();
+        const Affine* sc = scan_area(const_cast<float*>(lds));
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) { th.yf[j] = 0.f; th.x2[j] = 0.f; th.m[j] = th.g0[j]; }
+        if (th.has_sl) {
+            double c = affine_apply(Scan::prefix(sc, 0, tid), 0.0);
+            if (th.inject_left) c = th.edge_state;
+            out_forward(a.attf, th.sl, th.za, (float)c, th.yf);
+            MGX_UNROLL
+            for (int j = 0; j < E; ++j)
+                if (j >= th.valid) th.yf[j] = 0.f;
+            double z_end = 0.0;                        // forward state after frame n-1 (right filtfilt edge)
+            if (th.inject_right) {
+                float zl = 0.f;
+                MGX_UNROLL
+                for (int j = 0; j < E; ++j)
+                    if (j == th.valid - 1) zl = th.za[j];
+                z_end = fma(block_decay(a.pa, a.att.alpha, th.valid), c, (double)zl);
+            }
+            run_backward(a.attf, th.yf, th.valid, th.za);
+            if (th.valid > 0) {
+                const double decay = block_decay(a.pa, a.att.alpha, th.valid);
+                r.m_bwd = Affine{decay, (double)th.za[0]};
+                if (th.inject_right) {
+                    th.edge_state = filtfilt_right_state(a.att, edge_sl(const_cast<float*>(lds)) + 7, z_end);
+                    r.m_bwd = Affine{0.0, fma(decay, th.edge_state, (double)th.za[0])};
+                }
+            }
+        }
+        if (th.core) {
+            const double c = affine_apply(Scan::prefix(sc, 1, tid), scalars(const_cast<float*>(lds))[0]);
+            float ho[E];
+            out_forward(a.holdf, th.sh, th.zb, (float)c, ho);
+            MGX_UNROLL
+            for (int j = 0; j < E; ++j) {
+                th.x2[j] = fmaxf(th.sh[j], ho[j]);                 // hyrax.py:73
+                th.m[j] = fmaxf(th.g0[j], ho[j]);
+            }
+            run_forward(a.relf, th.x2, th.valid, th.zb);
+            if (th.valid > 0) r.m_rel = Affine{block_decay(a.pr, a.rel.alpha, th.valid), (double)th.zb[E - 1]};
+        }
+        return r;
+    }
+    static MGX_HD void phase_put_second(int tid, float* lds, const Second& s) {
+        Affine* sc = scan_area(lds);
+        Scan::put(sc, 0, T - 1 - tid, s.m_bwd);          // right-to-left scan order
+        Scan::put(sc, 1, tid, s.m_rel);
+    }
+
+    // ---- P7: exact backward attack output and release output -> gain -> LDS gain plane ---------
+    static MGX_HD void phase_gain(int tid, const Limiter2Args& a, Thread& th, float* lds) {
+        if (!th.core) return;
+        const Affine* sc = scan_area(lds);
+        double cb = affine_apply(Scan::prefix(sc, 0, T - 1 - tid), 0.0);
+        if (th.inject_right) cb = th.edge_state;
+        const double cr = affine_apply(Scan::prefix(sc, 1, tid), scalars(lds)[1]);
+        float yb[E], ro[E];
+        out_backward(a.attf, th.yf, th.za, th.valid, (float)cb, yb);
+        out_forward(a.relf, th.x2, th.zb, (float)cr, ro);
+        float* gn = gain_plane(lds) + tid * STRIDE;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j)
+            gn[j] = 1.0f - fmaxf(th.m[j], fmaxf(yb[j], ro[j]));   // hyrax.py:75,97
+    }
+
+    // ---- P8: coalesced reload, apply gain, store ------------------------------------------------
+    // with_gain = false: limiter early-out, the array only gets the final amplitude coefficient
+    static MGX_HD void phase_store(int tid, long long chunk, const Limiter2Args& a, bool with_gain, const float* lds) {
+        const long long r0 = region_start(chunk, a);
+        const long long c0 = r0 + (long long)a.gl * E, c1 = r0 + (long long)(T - a.gr) * E;   // core frames
+        const bool interior = r0 >= 0 && r0 + FRAMES <= a.n;
+        const double g = *a.gain, post = *a.post_gain;
+        const float* gn = gain_plane(const_cast<float*>(lds));
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) {
+            const int i = 2 * tid + 2 * T * j;
+            const long long f = r0 + i;
+            if (f < c0 || f >= c1) continue;                       // halo frames belong to the neighbours
+            const float k0 = with_gain ? gn[gidx(i)] : 1.f, k1 = with_gain ? gn[gidx(i + 1)] : 1.f;
+            if (interior) {
+                const float4 q = *reinterpret_cast<const float4*>(a.y + f);
+                const float2 v0 = scaled(make_float2(q.x, q.y), g), v1 = scaled(make_float2(q.z, q.w), g);
+                const double s0 = (double)k0 * post, s1 = (double)k1 * post;
+                *reinterpret_cast<float4*>(a.out + f) =
+                    make_float4((float)((double)v0.x * s0), (float)((double)v0.y * s0),
+                                (float)((double)v1.x * s1), (float)((double)v1.y * s1));
+            } else {
+                if (f < a.n) {
+                    const float2 v = scaled(a.y[f], g);
+                    const double s = (double)k0 * post;
+                    a.out[f] = make_float2((float)((double)v.x * s), (float)((double)v.y * s));
+                }
+                if (f + 1 < a.n) {
+                    const float2 v = scaled(a.y[f + 1], g);
+                    const double s = (double)k1 * post;
+                    a.out[f + 1] = make_float2((float)((double)v.x * s), (float)((double)v.y * s));
+                }
+            }
+        }
+    }
+};
+
+}  // namespace mgx

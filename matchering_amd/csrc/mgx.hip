@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -67,7 +68,8 @@ struct mgx_handle {
     std::map<int, float2*> twiddles;
     TrackWork track[2];
     DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars;
-    DevBuf lim_agg, lim_carry, lim_edge;
+    DevBuf lim_published, lim_ctrl, lim_weights;
+    std::vector<double> lim_weights_host;
     DevBuf fir_scratch;
     std::map<const FirPlanHost*, void*> plan_dev;                 // uploaded plan blobs
     std::vector<std::shared_ptr<FirPlanHost>> plans;              // keeps the host plans alive
@@ -328,36 +330,52 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     const std::string err = limiter_params(*cfg, lp);
     if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
     if (n < 8) return fail(MGX_ERR_ARGUMENT, "limiter input too short");
-    const LimiterBlock::Geometry geo = LimiterBlock::geometry(lp.hw, lp.hb);
-    LimiterArgs a;
+    Limiter2Args a;
+    limiter_fill(lp, (float)cfg->threshold, a);
     a.y = reinterpret_cast<const float2*>(y);
     a.n = n;
     a.out = reinterpret_cast<float2*>(out);
     a.gain = gain_dev;
     a.post_gain = post_dev;
     a.active = active_dev;
-    a.threshold = (float)cfg->threshold;
-    a.hw = lp.hw;
-    a.hb = lp.hb;
-    a.att = lp.att;
-    a.hold = lp.hold_f;
-    a.rel = lp.rel_f;
-    a.nchunks = (n + geo.chunk - 1) / geo.chunk;
-    MGX_TRY(ensure(h, h->lim_agg, (size_t)4 * a.nchunks * sizeof(Affine)));
-    MGX_TRY(ensure(h, h->lim_carry, (size_t)4 * a.nchunks * sizeof(double)));
-    MGX_TRY(ensure(h, h->lim_edge, 128));
-    a.agg = (Affine*)h->lim_agg.p;
-    a.carry = (double*)h->lim_carry.p;
-    a.edge_sl = (float*)h->lim_edge.p;
-    a.edge_state = (double*)((char*)h->lim_edge.p + 64);
-    const size_t lds = LimiterBlock::LDS_BYTES, lds_scan = ChunkScan::LDS_BYTES;
-    const dim3 grid((unsigned)a.nchunks), block(LimiterBlock::T);
-    hipLaunchKernelGGL(k_limit<1>, grid, block, lds, h->stream, a);
-    hipLaunchKernelGGL(k_limit_scan<1>, dim3(1), dim3(ChunkScan::T), lds_scan, h->stream, a);
-    hipLaunchKernelGGL(k_limit<2>, grid, block, lds, h->stream, a);
-    hipLaunchKernelGGL(k_limit_scan<2>, dim3(1), dim3(ChunkScan::T), lds_scan, h->stream, a);
-    hipLaunchKernelGGL(k_limit<3>, grid, block, lds, h->stream, a);
+    a.nchunks = (n + lp.geo.chunk - 1) / lp.geo.chunk;
+    // look-back weights: uploaded when the parameters change
+    const size_t wbytes = (lp.w_hold.size() + lp.w_rel.size()) * sizeof(double);
+    std::vector<double> w(lp.w_hold);
+    w.insert(w.end(), lp.w_rel.begin(), lp.w_rel.end());
+    if (h->lim_weights_host != w) {
+        MGX_TRY(ensure(h, h->lim_weights, wbytes));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(h->lim_weights.p, w.data(), wbytes, hipMemcpyHostToDevice));
+        h->lim_weights_host = w;
+    }
+    a.w_hold = (const double*)h->lim_weights.p;
+    a.w_rel = a.w_hold + lp.w_hold.size();
+    // published words preset to "unpublished", ticket and error zeroed, every launch
+    const size_t pub_bytes = (size_t)2 * a.nchunks * sizeof(unsigned long long);
+    MGX_TRY(ensure(h, h->lim_published, pub_bytes));
+    MGX_TRY(ensure(h, h->lim_ctrl, 64));
+    a.published = (unsigned long long*)h->lim_published.p;
+    a.ticket = (int*)h->lim_ctrl.p;
+    a.error = a.ticket + 1;
+    HIP_TRY(hipMemsetAsync(h->lim_published.p, 0xff, pub_bytes, h->stream));
+    HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 8, h->stream));       // ticket only: a raised error sticks
+    const size_t lds = Limiter2Block::LDS_BYTES;
+    MGX_TRY(allow_lds(k_limit, lds));
+    hipLaunchKernelGGL(k_limit, dim3((unsigned)a.nchunks), dim3(Limiter2Block::T), lds, h->stream, a);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// a look-back wait expired (never seen; the spin is bounded so that a lost chunk cannot hang the GPU)
+static int check_limiter_error(mgx_handle* h) {
+    if (!h->lim_ctrl.p) return 0;
+    int flags[2] = {0, 0};
+    HIP_TRY(hipMemcpy(flags, h->lim_ctrl.p, sizeof(flags), hipMemcpyDeviceToHost));
+    if (flags[1] != 0) {
+        HIP_TRY(hipMemset((int*)h->lim_ctrl.p + 1, 0, 4));
+        return fail(MGX_ERR_HIP, "limiter look-back timed out waiting for a predecessor chunk");
+    }
     return 0;
 }
 
@@ -427,7 +445,7 @@ int mgx_destroy(mgx_handle* h) {
     hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
-                      &h->scalars, &h->lim_agg, &h->lim_carry, &h->lim_edge, &h->fir_scratch};
+                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (TrackWork& w : h->track) {
@@ -622,6 +640,7 @@ int mgx_limit(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cf
     CorrectionState host_cs;
     HIP_TRY(hipMemcpyAsync(&host_cs, cs, sizeof(host_cs), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    MGX_TRY(check_limiter_error(h));
     if (active) *active = host_cs.limiter_active;
     return 0;
 }
@@ -701,6 +720,7 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         HIP_TRY(hipMemcpyAsync(hc, cs, sizeof(CorrectionState), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(c0, h->scalars.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        if (result_dev) MGX_TRY(check_limiter_error(h));
         std::memset(report, 0, sizeof(*report));
         report->final_amplitude_coefficient = st_r->amplitude_c;
         report->target_match_rms = st_t->match_rms;

@@ -9,7 +9,7 @@
 #include "analysis2_kernel.h"
 #include "conv2_kernel.h"
 #include "fir_plan.h"
-#include "limiter_kernel.h"
+#include "limiter2_kernel.h"
 
 namespace mgx {
 
@@ -582,78 +582,56 @@ __global__ __launch_bounds__(256) void k_frame_peaks(const float2* x, long long 
 }
 
 // ---------------------------------------------------------------------------
-// limiter
+// limiter (limiter2_kernel.h): one launch, grid = chunks
 // ---------------------------------------------------------------------------
-template <int PASS>
-__global__ __launch_bounds__(LimiterBlock::T) void k_limit(LimiterArgs a) {
-    using LB = LimiterBlock;
+__global__ __launch_bounds__(Limiter2Block::T, 4) void k_limit(Limiter2Args a) {
+    using LB = Limiter2Block;
     MGX_LDS;
     float* lds = reinterpret_cast<float*>(mgx_smem);
+    int& ticket = *reinterpret_cast<int*>(LB::scalars(lds) + 4);      // dynamic LDS only (16-byte aligned base)
     const int tid = threadIdx.x;
-    const long long chunk = blockIdx.x;
     const bool active = a.active ? (*a.active != 0) : true;
+    if (!active) {                       // hyrax.py:83-85: the array passes through, then stages.py:203
+        LB::phase_store(tid, blockIdx.x, a, false, lds);
+        return;
+    }
+    if (tid == 0) ticket = atomicAdd(a.ticket, 1);
+    __syncthreads();
+    const long long chunk = ticket;
     LB::Thread th;
-    if (!active) {
-        if (PASS == 3) {                 // hyrax.py:83-85: the array passes through, then stages.py:203
-            LB::phase_g0(tid, chunk, a, th, lds);
-            if (th.core) {
-                const double post = *a.post_gain;
-#pragma unroll
-                for (int j = 0; j < LB::E; ++j)
-                    if (j < th.valid)
-                        a.out[th.base + j] = make_float2((float)((double)th.v[j].x * post),
-                                                         (float)((double)th.v[j].y * post));
-            }
-        }
-        return;
-    }
-    LB::phase_g0(tid, chunk, a, th, lds);
+    LB::phase_load(tid, chunk, a, lds);
     __syncthreads();
-    LB::phase_sl(tid, a, th, lds);
+    LB::phase_planes(tid, chunk, a, th, lds);
     __syncthreads();
-    LB::phase_sh_runs(tid, a, th, lds);
+    LB::phase_windows(tid, a, th, lds);
+    __syncthreads();
+    LB::phase_put_first(tid, a, th, lds);
     __syncthreads();
     LB::Scan::scan_groups(LB::scan_area(lds), tid);
     __syncthreads();
     LB::Scan::scan_top(LB::scan_area(lds), tid);
     __syncthreads();
-    if (PASS == 1) {
-        LB::phase_publish(tid, chunk, a, lds, 0, 1);
-        return;
-    }
-    Affine m_ro, m_yb;
-    LB::phase_exact_first(tid, chunk, a, th, lds, m_ro, m_yb);
+    LB::lookback_publish(tid, chunk, 0, a, lds);
+    LB::lookback_fetch(tid, chunk, 0, a, lds);
     __syncthreads();
-    LB::phase_put_second(tid, lds, m_ro, m_yb);
+    LB::lookback_reduce(tid, 0, lds);
+    __syncthreads();
+    const LB::Second second = LB::phase_exact_first(tid, a, th, lds);
+    __syncthreads();
+    LB::phase_put_second(tid, lds, second);
     __syncthreads();
     LB::Scan::scan_groups(LB::scan_area(lds), tid);
     __syncthreads();
     LB::Scan::scan_top(LB::scan_area(lds), tid);
     __syncthreads();
-    if (PASS == 2) {
-        LB::phase_publish(tid, chunk, a, lds, 2, 3);
-        return;
-    }
-    LB::phase_output(tid, chunk, a, th, lds);
-}
-
-template <int STEP>
-__global__ __launch_bounds__(ChunkScan::T) void k_limit_scan(LimiterArgs a) {
-    MGX_LDS;
-    Affine* sc = reinterpret_cast<Affine*>(mgx_smem);
-    const int tid = threadIdx.x;
-    if (a.active && *a.active == 0) return;
-    const int sa = STEP == 1 ? 0 : 2, sb = STEP == 1 ? 1 : 3;
-    const bool fwd_b = STEP == 1;
-    ChunkScan::phase_put(tid, a, sa, sb, fwd_b, sc);
+    LB::lookback_publish(tid, chunk, 1, a, lds);
+    LB::lookback_fetch(tid, chunk, 1, a, lds);
     __syncthreads();
-    ChunkScan::Scan::scan_groups(sc, tid);
+    LB::lookback_reduce(tid, 1, lds);
     __syncthreads();
-    ChunkScan::Scan::scan_top(sc, tid);
+    LB::phase_gain(tid, a, th, lds);
     __syncthreads();
-    const double init_b = STEP == 1 ? ChunkScan::filtfilt_left_state(a)
-                                    : ChunkScan::filtfilt_right_state(a, a.edge_state[0]);
-    ChunkScan::phase_write(tid, a, sa, sb, fwd_b, 0.0, init_b, sc);
+    LB::phase_store(tid, chunk, a, true, lds);
 }
 
 }  // namespace mgx

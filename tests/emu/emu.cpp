@@ -15,7 +15,6 @@
 #include "../../matchering_amd/csrc/conv2_kernel.h"
 #include "../../matchering_amd/csrc/fir_design.h"
 #include "../../matchering_amd/csrc/host_params.h"
-#include "../../matchering_amd/csrc/limiter_kernel.h"
 
 using namespace mgx;
 
@@ -189,52 +188,30 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
                          float* out, float* dbg_sl, float* dbg_sh) {
     LimiterParams lp;
     if (!limiter_params(*cfg, lp).empty()) return -1;
-    using LB = LimiterBlock;
-    const LB::Geometry geo = LB::geometry(lp.hw, lp.hb);
-    LimiterArgs a;
+    using LB = Limiter2Block;
+    Limiter2Args a;
+    limiter_fill(lp, (float)cfg->threshold, a);
     a.y = reinterpret_cast<const float2*>(x);
     a.n = n;
     a.out = reinterpret_cast<float2*>(out);
     a.gain = &gain;
     a.post_gain = &post_gain;
     a.active = nullptr;
-    a.threshold = (float)cfg->threshold;
-    a.hw = lp.hw;
-    a.hb = lp.hb;
-    a.att = lp.att;
-    a.hold = lp.hold_f;
-    a.rel = lp.rel_f;
-    a.nchunks = (n + geo.chunk - 1) / geo.chunk;
-    std::vector<Affine> agg(4 * a.nchunks);
-    std::vector<double> carry(4 * a.nchunks, 0.0);
-    float edge_sl[14] = {0};
-    double edge_state[2] = {0, 0};
-    a.agg = agg.data();
-    a.carry = carry.data();
-    a.edge_sl = edge_sl;
-    a.edge_state = edge_state;
+    a.nchunks = (n + lp.geo.chunk - 1) / lp.geo.chunk;
+    std::vector<unsigned long long> published(2 * a.nchunks, LIMITER_UNPUBLISHED);
+    a.published = published.data();
+    a.w_hold = lp.w_hold.data();
+    a.w_rel = lp.w_rel.data();
+    int ctrl[2] = {0, 0};
+    a.ticket = &ctrl[0];
+    a.error = &ctrl[1];
     std::vector<float> lds(LB::LDS_BYTES / 4 + 8);
     std::vector<LB::Thread> th(LB::T);
-    std::vector<Affine> m0(LB::T), m1(LB::T);
-    std::vector<Affine> sc(ChunkScan::Scan::SCRATCH);
-
-    auto first_phases = [&](long long chunk) {
-        FOR_THREADS(LB::T) LB::phase_g0(tid, chunk, a, th[tid], lds.data());
-        FOR_THREADS(LB::T) LB::phase_sl(tid, a, th[tid], lds.data());
-        FOR_THREADS(LB::T) LB::phase_sh_runs(tid, a, th[tid], lds.data());
-        FOR_THREADS(LB::T) LB::Scan::scan_groups(LB::scan_area(lds.data()), tid);
-        FOR_THREADS(LB::T) LB::Scan::scan_top(LB::scan_area(lds.data()), tid);
-    };
-    auto second_phases = [&](long long chunk) {
-        FOR_THREADS(LB::T) LB::phase_exact_first(tid, chunk, a, th[tid], lds.data(), m0[tid], m1[tid]);
-        FOR_THREADS(LB::T) LB::phase_put_second(tid, lds.data(), m0[tid], m1[tid]);
-        FOR_THREADS(LB::T) LB::Scan::scan_groups(LB::scan_area(lds.data()), tid);
-        FOR_THREADS(LB::T) LB::Scan::scan_top(LB::scan_area(lds.data()), tid);
-    };
-    // pass 1
-    for (long long c = 0; c < a.nchunks; ++c) {
-        first_phases(c);
-        FOR_THREADS(LB::T) LB::phase_publish(tid, c, a, lds.data(), 0, 1);
+    std::vector<LB::Second> second(LB::T);
+    for (long long chunk = 0; chunk < a.nchunks; ++chunk) {
+        FOR_THREADS(LB::T) LB::phase_load(tid, chunk, a, lds.data());
+        FOR_THREADS(LB::T) LB::phase_planes(tid, chunk, a, th[tid], lds.data());
+        FOR_THREADS(LB::T) LB::phase_windows(tid, a, th[tid], lds.data());
         if (dbg_sl || dbg_sh) {
             FOR_THREADS(LB::T) {
                 if (!th[tid].core) continue;
@@ -244,36 +221,23 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
                 }
             }
         }
+        FOR_THREADS(LB::T) LB::phase_put_first(tid, a, th[tid], lds.data());
+        FOR_THREADS(LB::T) LB::Scan::scan_groups(LB::scan_area(lds.data()), tid);
+        FOR_THREADS(LB::T) LB::Scan::scan_top(LB::scan_area(lds.data()), tid);
+        FOR_THREADS(LB::T) LB::lookback_publish(tid, chunk, 0, a, lds.data());
+        FOR_THREADS(LB::T) LB::lookback_fetch(tid, chunk, 0, a, lds.data());
+        FOR_THREADS(LB::T) LB::lookback_reduce(tid, 0, lds.data());
+        FOR_THREADS(LB::T) second[tid] = LB::phase_exact_first(tid, a, th[tid], lds.data());
+        FOR_THREADS(LB::T) LB::phase_put_second(tid, lds.data(), second[tid]);
+        FOR_THREADS(LB::T) LB::Scan::scan_groups(LB::scan_area(lds.data()), tid);
+        FOR_THREADS(LB::T) LB::Scan::scan_top(LB::scan_area(lds.data()), tid);
+        FOR_THREADS(LB::T) LB::lookback_publish(tid, chunk, 1, a, lds.data());
+        FOR_THREADS(LB::T) LB::lookback_fetch(tid, chunk, 1, a, lds.data());
+        FOR_THREADS(LB::T) LB::lookback_reduce(tid, 1, lds.data());
+        FOR_THREADS(LB::T) LB::phase_gain(tid, a, th[tid], lds.data());
+        FOR_THREADS(LB::T) LB::phase_store(tid, chunk, a, true, lds.data());
     }
-    // scan 1
-    FOR_THREADS(ChunkScan::T) ChunkScan::phase_put(tid, a, 0, 1, true, sc.data());
-    FOR_THREADS(ChunkScan::T) ChunkScan::Scan::scan_groups(sc.data(), tid);
-    FOR_THREADS(ChunkScan::T) ChunkScan::Scan::scan_top(sc.data(), tid);
-    {
-        const double yf0 = ChunkScan::filtfilt_left_state(a);
-        FOR_THREADS(ChunkScan::T) ChunkScan::phase_write(tid, a, 0, 1, true, 0.0, yf0, sc.data());
-    }
-    // pass 2
-    for (long long c = 0; c < a.nchunks; ++c) {
-        first_phases(c);
-        second_phases(c);
-        FOR_THREADS(LB::T) LB::phase_publish(tid, c, a, lds.data(), 2, 3);
-    }
-    // scan 2
-    FOR_THREADS(ChunkScan::T) ChunkScan::phase_put(tid, a, 2, 3, false, sc.data());
-    FOR_THREADS(ChunkScan::T) ChunkScan::Scan::scan_groups(sc.data(), tid);
-    FOR_THREADS(ChunkScan::T) ChunkScan::Scan::scan_top(sc.data(), tid);
-    {
-        const double yb0 = ChunkScan::filtfilt_right_state(a, a.edge_state[0]);
-        FOR_THREADS(ChunkScan::T) ChunkScan::phase_write(tid, a, 2, 3, false, 0.0, yb0, sc.data());
-    }
-    // pass 3
-    for (long long c = 0; c < a.nchunks; ++c) {
-        first_phases(c);
-        second_phases(c);
-        FOR_THREADS(LB::T) LB::phase_output(tid, c, a, th[tid], lds.data());
-    }
-    return 0;
+    return ctrl[1] ? -2 : 0;
 }
 
 // host FIR design (product code, re-exported here so the CPU tests need no HIP runtime)

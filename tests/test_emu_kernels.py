@@ -138,3 +138,45 @@ def test_limiter_phases(emu, name):
     want = mo.limit(y.astype(np.float64), ocfg) * 0.9
     assert rms_error(out, want) <= 1e-6
     assert np.abs(out - want).max() <= 5e-6
+
+
+def test_limiter_lookback_across_many_chunks(emu):
+    """Default 44.1 kHz limiter on 14 s of hot material: ~85 chunks, so the release filter's carry
+    is a truncated look-back over ~70 predecessor chunks and the hold filter's over 3."""
+    import matchering_amd as mg
+    from matchering_amd.synth import synth
+
+    sr = 44100
+    rng = np.random.RandomState(11)
+    x = synth(14.0, sr, 5).astype(np.float64)
+    x *= 1.6 / np.abs(x).max()
+    x[: sr // 2] *= 0.2                     # quiet start: the limiter engages mid-way
+    x += 1e-3 * rng.randn(*x.shape)
+    y = np.ascontiguousarray(x, dtype=np.float32)
+    cfg = mg.Config()
+    native = cfg.to_native()
+    out = np.zeros_like(y)
+    rc = emu.emu_limit(_fp(y), ctypes.c_longlong(y.shape[0]), ctypes.byref(native), ctypes.c_double(1.0),
+                       ctypes.c_double(1.0), _fp(out), None, None)
+    assert rc == 0
+    ocfg = mo.params()
+    want = mo.limit(y.astype(np.float64), ocfg)
+    assert np.abs(want).max() <= ocfg.threshold * (1 + 1e-9)
+    assert rms_error(out, want) <= 1e-6
+    assert np.abs(out - want).max() <= 5e-6
+
+
+@pytest.mark.parametrize("n", [8, 23, 7264, 7265, 2 * 7264 - 1, 30011])
+def test_limiter_lengths_around_chunk_edges(emu, n):
+    import matchering_amd as mg
+
+    rng = np.random.RandomState(n)
+    y = (0.9 * rng.randn(n, 2)).astype(np.float32)
+    cfg = mg.Config()
+    native = cfg.to_native()
+    out = np.zeros_like(y)
+    rc = emu.emu_limit(_fp(y), ctypes.c_longlong(n), ctypes.byref(native), ctypes.c_double(1.0),
+                       ctypes.c_double(1.0), _fp(out), None, None)
+    assert rc == 0
+    want = mo.limit(y.astype(np.float64), mo.params())
+    assert np.abs(out - want).max() <= 5e-6
