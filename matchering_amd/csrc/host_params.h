@@ -30,7 +30,7 @@ struct LimiterParams {
     int attack, hold, hw, hb, ha;
     Iir1 att, hold_f, rel_f;
     Limiter2Block::Geometry geo;
-    std::vector<double> w_hold, w_rel;      // look-back weights (alpha^chunk)^m
+    std::vector<double> w_hold, w_rel, w_att;      // look-back weights (alpha^chunk)^m
 };
 
 inline Iir1f to_f32(const Iir1& f) {
@@ -81,6 +81,7 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
         return "hold/release filter is not a stable low-pass";
     p.w_hold = lookback_weights(p.hold_f.alpha, p.geo.chunk, 1 << 16);
     p.w_rel = lookback_weights(p.rel_f.alpha, p.geo.chunk, 1 << 16);
+    p.w_att = lookback_weights(p.att.alpha, p.geo.chunk, 1 << 16);
     return "";
 }
 
@@ -103,6 +104,7 @@ inline void limiter_fill(const LimiterParams& p, float threshold, Limiter2Args& 
     powers(p.rel_f.alpha, a.pr);
     a.n_hold = (int)p.w_hold.size();
     a.n_rel = (int)p.w_rel.size();
+    a.n_att = (int)p.w_att.size();
 }
 
 inline int ilog2_exact(int v) {

@@ -10,9 +10,9 @@
 //   ro    = lfilter(butter(rel order, rel Hz), max(sh, ho))       hyrax.py:68-73
 //   gain  = 1 - max(g0, gA, max(ho, ro));  out = x * gain         hyrax.py:75,97,99
 //
-// GPU formulation.  The track is cut into chunks of C = CB*16 frames; a chunk is one 512-thread
-// workgroup whose thread t owns "block" t = 16 consecutive frames, GL halo blocks before the
-// chunk's CB core blocks and GR after them.
+// GPU formulation.  The track is cut into chunks of C = CB*16 frames; a chunk is one 256-thread
+// workgroup (four fit a CU) whose thread t owns "block" t = 16 consecutive frames, GL halo blocks
+// before the chunk's CB core blocks and GR after them.
 //
 //  * Frames are loaded coalesced (16 B per lane); only g0 travels through LDS to the owning
 //    thread.  The final gain travels back the same way and the frames are re-read (L2) for the
@@ -25,18 +25,19 @@
 //    across the workgroup by an ordered float64 scan (scan_util.h), and the exact outputs are the
 //    local run plus alpha^j times the carry.  Rounding never accumulates beyond 16 frames.
 //  * The attack smoother's pole rho = exp(coef/attack) forgets quickly: rho^HA <= 1e-8 after
-//    HA ~ 9*attack frames.  The halos are HA (+ window) frames long, so the forward run started
-//    from zero at the left halo and the backward run started from zero at the right halo are
-//    exact (to 1e-8) inside the core: scipy.signal.filtfilt needs no hand-off between chunks.
-//    Its edge handling (odd extension by 6, steady-state initial conditions) is applied by the
-//    chunks that contain frame 0 / frame n-1.
-//  * The hold and release low-passes remember for seconds.  Each chunk publishes the state its
-//    frames produce from a zero carry (one float64 per filter, written once); a chunk's carry is
-//    sum_m (alpha^C)^m * published[chunk-1-m], truncated where (alpha^C)^m <= 1e-10 (3 chunks for
-//    the 7 Hz hold filter, ~70 for the 0.27 Hz release filter).  No chunk ever waits for another
-//    chunk's look-back of the same filter, so the dependency depth is two (release aggregates need
-//    the exact hold output) however long the track is.  Chunk numbers are drawn from an atomic
-//    ticket, so every chunk a workgroup waits for has already started.
+//    HA ~ 9*attack frames.  The right halo is HA (+ window) frames long, so the backward run of
+//    scipy.signal.filtfilt started from zero at the end of the halo is exact (to 1e-8) inside the
+//    core and never needs a later chunk.  filtfilt's edge handling (odd extension by 6,
+//    steady-state initial conditions) is applied by the chunks that contain frame 0 / frame n-1.
+//  * The forward attack smoother, the hold and the release low-passes carry state from chunk to
+//    chunk (the latter two for seconds).  Each chunk publishes the state its core frames produce
+//    from a zero carry (one float64 per filter, written once); a chunk's carry is
+//    sum_m (alpha^C)^m * published[chunk-1-m], truncated where (alpha^C)^m <= 1e-10 (1 chunk for
+//    the attack pole, a handful for the 7 Hz hold filter, ~170 for the 0.27 Hz release filter).
+//    No chunk ever waits for another chunk's look-back of the same filter, so the dependency
+//    depth is two (release aggregates need the exact hold output) however long the track is.
+//    Chunk numbers are drawn from an atomic ticket, so every chunk a workgroup waits for has
+//    already started.
 //
 // Published words are 8-byte granules whose value is the flag: the array is preset to all-ones
 // (not a finite double) before each launch and written with one relaxed agent-scope atomic store
@@ -71,10 +72,11 @@ struct Limiter2Args {
     Iir1f attf, holdf, relf;       // float32 copies for the per-frame arithmetic
     double pa[17], ph[17], pr[17]; // alpha^j in float64, j = 0..16 (aggregate of a partial block)
     long long nchunks;
-    unsigned long long* published; // [2][nchunks]: hold, release chunk aggregates (bit patterns)
+    unsigned long long* published; // [3][nchunks]: hold, release, attack chunk aggregates (bit patterns)
     const double* w_hold;          // (alpha_hold^C)^m, m = 0..n_hold-1
     const double* w_rel;
-    int n_hold, n_rel;
+    const double* w_att;
+    int n_hold, n_rel, n_att;
     int* ticket;                   // chunk dispenser (zeroed before the launch)
     int* error;                    // set to 1 if a bounded wait expired
 };
@@ -89,11 +91,15 @@ __device__ __forceinline__ void publish_word(unsigned long long* p, unsigned lon
 __device__ __forceinline__ unsigned long long poll_word(unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void backoff() { __builtin_amdgcn_s_sleep(8); }
+__device__ __forceinline__ void backoff(int spins) {             // ~0.03 us at first, ~0.5 us when it drags on
+    if (spins < 8) __builtin_amdgcn_s_sleep(1);
+    else if (spins < 64) __builtin_amdgcn_s_sleep(4);
+    else __builtin_amdgcn_s_sleep(16);
+}
 #else
 inline void publish_word(unsigned long long* p, unsigned long long v) { *p = v; }
 inline unsigned long long poll_word(unsigned long long* p) { return *p; }
-inline void backoff() {}
+inline void backoff(int) {}
 #endif
 MGX_HD unsigned long long double_bits(double v) {
     union { double d; unsigned long long u; } c;
@@ -107,7 +113,7 @@ MGX_HD double bits_double(unsigned long long u) {
 }
 
 struct Limiter2Block {
-    static constexpr int T = 512;
+    static constexpr int T = 256;
     static constexpr int E = 16;
     static constexpr int STRIDE = E + 1;               // LDS row stride (floats): conflict-free columns
     static constexpr int G = 16;
@@ -128,7 +134,7 @@ struct Limiter2Block {
     static_assert(GAIN_OFF + PLANE <= 2 * PLANE, "gain plane must fit behind the scan scratch");
     static constexpr int BM_OFF = 2 * PLANE;
     static constexpr int MISC_OFF = BM_OFF + T;
-    static constexpr int MISC_FLOATS = 16 + 2 * 64 + 16;       // edge sl[14] | 64 doubles | 8 doubles
+    static constexpr int MISC_FLOATS = 16 + 2 * 128 + 16;       // edge sl[14] | 64 doubles | 8 doubles
     static constexpr size_t LDS_BYTES = (size_t)(MISC_OFF + MISC_FLOATS) * 4 + 16;
 
     static MGX_HD float* plane(float* lds, int i) { return lds + i * PLANE; }
@@ -137,8 +143,8 @@ struct Limiter2Block {
     static MGX_HD float* gain_plane(float* lds) { return lds + GAIN_OFF; }
     static MGX_HD float* edge_sl(float* lds) { return lds + MISC_OFF; }                 // [14]
     static MGX_HD double* partials(float* lds) { return reinterpret_cast<double*>(lds + MISC_OFF + 16); }   // [64]
-    static MGX_HD double* scalars(float* lds) { return reinterpret_cast<double*>(lds + MISC_OFF + 16 + 128); }
-    //   scalars: [0] hold chunk carry, [1] release chunk carry
+    static MGX_HD double* scalars(float* lds) { return reinterpret_cast<double*>(lds + MISC_OFF + 16 + 256); }
+    //   scalars: [0] hold chunk carry, [1] release chunk carry, [2] attack chunk carry, [4] ticket
     static MGX_HD int gidx(int i) { return (i >> 4) * STRIDE + (i & 15); }
 
     struct Geometry {
@@ -149,9 +155,8 @@ struct Limiter2Block {
         Geometry g;
         g.gw = (hw + E - 1) / E;
         const int hab = (ha + E - 1) / E;
-        const int left_window = (hw + hb + E - 1) / E;
-        g.gl = hab + g.gw > left_window ? hab + g.gw : left_window;
-        g.gr = hab + g.gw;
+        g.gl = (hw + hb + E - 1) / E;          // left: only the sh window (the attack state is carried in)
+        g.gr = hab + g.gw;                      // right: backward warm-up + sl window
         g.core_blocks = T - g.gl - g.gr;
         g.chunk = g.core_blocks * E;
         return g;
@@ -178,13 +183,11 @@ struct Limiter2Block {
         // 1 - 1/(amax/thr) = (amax - thr)/amax, zero at or below the threshold (dsp.py:117-121, hyrax.py:87)
         return amax > thr ? (amax - thr) / amax : 0.f;
     }
-    static MGX_HD float2 scaled(float2 y, double g) {
-        return make_float2((float)((double)y.x * g), (float)((double)y.y * g));
-    }
+    static MGX_HD float2 scaled(float2 y, float g) { return make_float2(y.x * g, y.y * g); }
     static MGX_HD void phase_load(int tid, long long chunk, const Limiter2Args& a, float* lds) {
         const long long r0 = region_start(chunk, a);
         const bool interior = r0 >= 0 && r0 + FRAMES <= a.n;
-        const double g = *a.gain;
+        const float g = (float)*a.gain;
         float* gp = plane(lds, 0);
         MGX_UNROLL
         for (int j = 0; j < E / 2; ++j) {
@@ -208,7 +211,7 @@ struct Limiter2Block {
     static MGX_HD void phase_planes(int tid, long long chunk, const Limiter2Args& a, Thread& th, float* lds) {
         th.base = region_start(chunk, a) + (long long)tid * E;
         th.core = tid >= a.gl && tid < T - a.gr;
-        th.has_sl = tid >= a.gw && tid < T - a.gw;
+        th.has_sl = tid >= a.gl && tid < T - a.gw;
         const long long left = a.n - th.base;
         th.valid = th.base < 0 ? 0 : (left >= E ? E : (left > 0 ? (int)left : 0));
         float* gp = plane(lds, 0) + tid * STRIDE;
@@ -389,16 +392,22 @@ struct Limiter2Block {
 
     // ---- chunk carries: publish this chunk's zero-carry state, gather the predecessors' --------
     // slot 0 = hold, 1 = release.  Thread 0 publishes; threads 0..63 fetch; thread 0 reduces.
+    // slot 0 = hold, 1 = release (scan 1, all core blocks), 2 = forward attack (scan 0, up to the
+    // end of the core: the blocks of the right halo belong to the next chunk's carry)
     static MGX_HD void lookback_publish(int tid, long long chunk, int slot, const Limiter2Args& a, const float* lds) {
         if (tid == 0) {
-            const Affine whole = Scan::whole(scan_area(const_cast<float*>(lds)), 1);
-            publish_word(a.published + (size_t)slot * a.nchunks + chunk, double_bits(whole.b));
+            const Affine* sc = scan_area(const_cast<float*>(lds));
+            const double b = slot == 2 ? Scan::prefix(sc, 0, T - a.gr).b : Scan::whole(sc, 1).b;
+            publish_word(a.published + (size_t)slot * a.nchunks + chunk, double_bits(b));
         }
     }
     static MGX_HD void lookback_fetch(int tid, long long chunk, int slot, const Limiter2Args& a, float* lds) {
         if (tid >= 64) return;
-        const double* w = slot == 0 ? a.w_hold : a.w_rel;
-        const int count = slot == 0 ? a.n_hold : a.n_rel;
+        lookback_fetch_into(tid, chunk, slot, a, partials(lds));
+    }
+    static MGX_HD void lookback_fetch_into(int tid, long long chunk, int slot, const Limiter2Args& a, double* part) {
+        const double* w = slot == 0 ? a.w_hold : (slot == 1 ? a.w_rel : a.w_att);
+        const int count = slot == 0 ? a.n_hold : (slot == 1 ? a.n_rel : a.n_att);
         double acc = 0.0;
         for (int m = tid; m < count; m += 64) {
             const long long c = chunk - 1 - m;
@@ -407,7 +416,7 @@ struct Limiter2Block {
             unsigned long long v = poll_word(p);
             int spins = 0;
             while (v == LIMITER_UNPUBLISHED && spins < MAX_SPINS) {
-                backoff();
+                backoff(spins);
                 v = poll_word(p);
                 ++spins;
             }
@@ -417,12 +426,19 @@ struct Limiter2Block {
             }
             acc = fma(w[m], bits_double(v), acc);
         }
-        partials(lds)[tid] = acc;
+        part[tid] = acc;
     }
-    static MGX_HD void lookback_reduce(int tid, int slot, float* lds) {
-        if (tid != 0) return;
+    // two slots gathered by the two halves of a 128-thread group (hold: threads 0..63, attack: 64..127)
+    static MGX_HD void lookback_fetch_pair(int tid, long long chunk, const Limiter2Args& a, float* lds) {
+        if (tid < 64) lookback_fetch(tid, chunk, 0, a, lds);
+        else if (tid < 128) lookback_fetch_into(tid - 64, chunk, 2, a, partials(lds) + 64);
+    }
+    // `half` selects which 64 partials; fixed summation order
+    static MGX_HD void lookback_reduce(int tid, int slot, int half, float* lds) {
+        if (tid != half * 64) return;
+        const double* p = partials(lds) + half * 64;
         double s = 0.0;
-        for (int i = 0; i < 64; ++i) s += partials(lds)[i];
+        for (int i = 0; i < 64; ++i) s += p[i];
         scalars(lds)[slot] = s;
     }
 
@@ -439,7 +455,7 @@ struct Limiter2Block {
         MGX_UNROLL
         for (int j = 0; j < E; ++j) { th.yf[j] = 0.f; th.x2[j] = 0.f; th.m[j] = th.g0[j]; }
         if (th.has_sl) {
-            double c = affine_apply(Scan::prefix(sc, 0, tid), 0.0);
+            double c = affine_apply(Scan::prefix(sc, 0, tid), scalars(const_cast<float*>(lds))[2]);
             if (th.inject_left) c = th.edge_state;
             out_forward(a.attf, th.sl, th.za, (float)c, th.yf);
             MGX_UNROLL
@@ -505,7 +521,7 @@ struct Limiter2Block {
         const long long r0 = region_start(chunk, a);
         const long long c0 = r0 + (long long)a.gl * E, c1 = r0 + (long long)(T - a.gr) * E;   // core frames
         const bool interior = r0 >= 0 && r0 + FRAMES <= a.n;
-        const double g = *a.gain, post = *a.post_gain;
+        const float g = (float)*a.gain, post = (float)*a.post_gain;
         const float* gn = gain_plane(const_cast<float*>(lds));
         MGX_UNROLL
         for (int j = 0; j < E / 2; ++j) {
@@ -516,20 +532,18 @@ struct Limiter2Block {
             if (interior) {
                 const float4 q = *reinterpret_cast<const float4*>(a.y + f);
                 const float2 v0 = scaled(make_float2(q.x, q.y), g), v1 = scaled(make_float2(q.z, q.w), g);
-                const double s0 = (double)k0 * post, s1 = (double)k1 * post;
-                *reinterpret_cast<float4*>(a.out + f) =
-                    make_float4((float)((double)v0.x * s0), (float)((double)v0.y * s0),
-                                (float)((double)v1.x * s1), (float)((double)v1.y * s1));
+                const float s0 = k0 * post, s1 = k1 * post;
+                *reinterpret_cast<float4*>(a.out + f) = make_float4(v0.x * s0, v0.y * s0, v1.x * s1, v1.y * s1);
             } else {
                 if (f < a.n) {
                     const float2 v = scaled(a.y[f], g);
-                    const double s = (double)k0 * post;
-                    a.out[f] = make_float2((float)((double)v.x * s), (float)((double)v.y * s));
+                    const float s = k0 * post;
+                    a.out[f] = make_float2(v.x * s, v.y * s);
                 }
                 if (f + 1 < a.n) {
                     const float2 v = scaled(a.y[f + 1], g);
-                    const double s = (double)k1 * post;
-                    a.out[f + 1] = make_float2((float)((double)v.x * s), (float)((double)v.y * s));
+                    const float s = k1 * post;
+                    a.out[f + 1] = make_float2(v.x * s, v.y * s);
                 }
             }
         }

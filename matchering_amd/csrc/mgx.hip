@@ -340,9 +340,10 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     a.active = active_dev;
     a.nchunks = (n + lp.geo.chunk - 1) / lp.geo.chunk;
     // look-back weights: uploaded when the parameters change
-    const size_t wbytes = (lp.w_hold.size() + lp.w_rel.size()) * sizeof(double);
     std::vector<double> w(lp.w_hold);
     w.insert(w.end(), lp.w_rel.begin(), lp.w_rel.end());
+    w.insert(w.end(), lp.w_att.begin(), lp.w_att.end());
+    const size_t wbytes = w.size() * sizeof(double);
     if (h->lim_weights_host != w) {
         MGX_TRY(ensure(h, h->lim_weights, wbytes));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -351,8 +352,9 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     }
     a.w_hold = (const double*)h->lim_weights.p;
     a.w_rel = a.w_hold + lp.w_hold.size();
+    a.w_att = a.w_rel + lp.w_rel.size();
     // published words preset to "unpublished", ticket and error zeroed, every launch
-    const size_t pub_bytes = (size_t)2 * a.nchunks * sizeof(unsigned long long);
+    const size_t pub_bytes = (size_t)3 * a.nchunks * sizeof(unsigned long long);
     MGX_TRY(ensure(h, h->lim_published, pub_bytes));
     MGX_TRY(ensure(h, h->lim_ctrl, 64));
     a.published = (unsigned long long*)h->lim_published.p;

@@ -612,9 +612,11 @@ __global__ __launch_bounds__(Limiter2Block::T, 4) void k_limit(Limiter2Args a) {
     LB::Scan::scan_top(LB::scan_area(lds), tid);
     __syncthreads();
     LB::lookback_publish(tid, chunk, 0, a, lds);
-    LB::lookback_fetch(tid, chunk, 0, a, lds);
+    LB::lookback_publish(tid, chunk, 2, a, lds);
+    LB::lookback_fetch_pair(tid, chunk, a, lds);
     __syncthreads();
-    LB::lookback_reduce(tid, 0, lds);
+    LB::lookback_reduce(tid, 0, 0, lds);
+    LB::lookback_reduce(tid, 2, 1, lds);
     __syncthreads();
     const LB::Second second = LB::phase_exact_first(tid, a, th, lds);
     __syncthreads();
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(Limiter2Block::T, 4) void k_limit(Limiter2Args a) {
     LB::lookback_publish(tid, chunk, 1, a, lds);
     LB::lookback_fetch(tid, chunk, 1, a, lds);
     __syncthreads();
-    LB::lookback_reduce(tid, 1, lds);
+    LB::lookback_reduce(tid, 1, 0, lds);
     __syncthreads();
     LB::phase_gain(tid, a, th, lds);
     __syncthreads();

@@ -198,10 +198,11 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
     a.post_gain = &post_gain;
     a.active = nullptr;
     a.nchunks = (n + lp.geo.chunk - 1) / lp.geo.chunk;
-    std::vector<unsigned long long> published(2 * a.nchunks, LIMITER_UNPUBLISHED);
+    std::vector<unsigned long long> published(3 * a.nchunks, LIMITER_UNPUBLISHED);
     a.published = published.data();
     a.w_hold = lp.w_hold.data();
     a.w_rel = lp.w_rel.data();
+    a.w_att = lp.w_att.data();
     int ctrl[2] = {0, 0};
     a.ticket = &ctrl[0];
     a.error = &ctrl[1];
@@ -225,15 +226,17 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
         FOR_THREADS(LB::T) LB::Scan::scan_groups(LB::scan_area(lds.data()), tid);
         FOR_THREADS(LB::T) LB::Scan::scan_top(LB::scan_area(lds.data()), tid);
         FOR_THREADS(LB::T) LB::lookback_publish(tid, chunk, 0, a, lds.data());
-        FOR_THREADS(LB::T) LB::lookback_fetch(tid, chunk, 0, a, lds.data());
-        FOR_THREADS(LB::T) LB::lookback_reduce(tid, 0, lds.data());
+        FOR_THREADS(LB::T) LB::lookback_publish(tid, chunk, 2, a, lds.data());
+        FOR_THREADS(LB::T) LB::lookback_fetch_pair(tid, chunk, a, lds.data());
+        FOR_THREADS(LB::T) LB::lookback_reduce(tid, 0, 0, lds.data());
+        FOR_THREADS(LB::T) LB::lookback_reduce(tid, 2, 1, lds.data());
         FOR_THREADS(LB::T) second[tid] = LB::phase_exact_first(tid, a, th[tid], lds.data());
         FOR_THREADS(LB::T) LB::phase_put_second(tid, lds.data(), second[tid]);
         FOR_THREADS(LB::T) LB::Scan::scan_groups(LB::scan_area(lds.data()), tid);
         FOR_THREADS(LB::T) LB::Scan::scan_top(LB::scan_area(lds.data()), tid);
         FOR_THREADS(LB::T) LB::lookback_publish(tid, chunk, 1, a, lds.data());
         FOR_THREADS(LB::T) LB::lookback_fetch(tid, chunk, 1, a, lds.data());
-        FOR_THREADS(LB::T) LB::lookback_reduce(tid, 1, lds.data());
+        FOR_THREADS(LB::T) LB::lookback_reduce(tid, 1, 0, lds.data());
         FOR_THREADS(LB::T) LB::phase_gain(tid, a, th[tid], lds.data());
         FOR_THREADS(LB::T) LB::phase_store(tid, chunk, a, true, lds.data());
     }

@@ -166,7 +166,7 @@ def test_limiter_lookback_across_many_chunks(emu):
     assert np.abs(out - want).max() <= 5e-6
 
 
-@pytest.mark.parametrize("n", [8, 23, 7264, 7265, 2 * 7264 - 1, 30011])
+@pytest.mark.parametrize("n", [8, 23, 3536, 3537, 2 * 3536 - 1, 7072, 30011])
 def test_limiter_lengths_around_chunk_edges(emu, n):
     import matchering_amd as mg
 
