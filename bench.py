@@ -186,9 +186,16 @@ def main():
                                          hs.ctypes.data_as(dp), f, 1.0, ctypes.c_void_p(out_a.ptr),
                                          ctypes.c_void_p(mid_plane.ptr), 20, ctypes.byref(ms)))
         achieved = CONV_BYTES_PER_FRAME * n / (ms.value * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC passes of tools/gpu_pmc.sh (FETCH_SIZE x2 on gfx950 +
+        # WRITE_SIZE), valid for this workload only; rocprofv3 cannot wrap the process it runs in
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path) and args.seconds == 480.0 and args.sample_rate == 44100:
+            with open(pmc_path) as fh:
+                traffic = json.load(fh)["kernels"].get("k_conv<13>", {}).get("hbm_bytes_per_launch")
         line["roofline"] = {"kernel": "k_conv<13> (overlap-save FIR, B=8192)", "bound": "hbm",
                             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                             "kernel_ms": round(ms.value, 4),
                             "algorithmic_bytes_per_launch": CONV_BYTES_PER_FRAME * n}
         if not args.no_secondary:
