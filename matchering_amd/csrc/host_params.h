@@ -38,13 +38,12 @@ inline Iir1f to_f32(const Iir1& f) {
     r.b0 = (float)f.b0;
     r.alpha = (float)f.alpha;
     r.beta = (float)f.beta;
-    double p = 1.0;
-    for (int j = 0; j <= 16; ++j) { r.pw[j] = (float)p; p *= f.alpha; }
     return r;
 }
-inline void powers(double alpha, double (&t)[17]) {
+inline double power16(double alpha) {
     double p = 1.0;
-    for (int j = 0; j <= 16; ++j) { t[j] = p; p *= alpha; }
+    for (int j = 0; j < 16; ++j) p *= alpha;
+    return p;
 }
 // (alpha^chunk)^m until it drops below 1e-10 (at least one entry, at most `cap`)
 inline std::vector<double> lookback_weights(double alpha, int chunk, int cap) {
@@ -99,9 +98,9 @@ inline void limiter_fill(const LimiterParams& p, float threshold, Limiter2Args& 
     a.attf = to_f32(p.att);
     a.holdf = to_f32(p.hold_f);
     a.relf = to_f32(p.rel_f);
-    powers(p.att.alpha, a.pa);
-    powers(p.hold_f.alpha, a.ph);
-    powers(p.rel_f.alpha, a.pr);
+    a.pa16 = power16(p.att.alpha);
+    a.ph16 = power16(p.hold_f.alpha);
+    a.pr16 = power16(p.rel_f.alpha);
     a.n_hold = (int)p.w_hold.size();
     a.n_rel = (int)p.w_rel.size();
     a.n_att = (int)p.w_att.size();

@@ -54,7 +54,6 @@ struct Iir1 {
 };
 struct Iir1f {
     float b0, alpha, beta;
-    float pw[17];                  // alpha^j, j = 0..16
 };
 
 struct Limiter2Args {
@@ -70,7 +69,7 @@ struct Limiter2Args {
     int gl, gr, gw;                // halo blocks left / right; blocks without a full sl window
     Iir1 att, hold, rel;           // float64 coefficients (edge states, aggregates)
     Iir1f attf, holdf, relf;       // float32 copies for the per-frame arithmetic
-    double pa[17], ph[17], pr[17]; // alpha^j in float64, j = 0..16 (aggregate of a partial block)
+    double pa16, ph16, pr16;       // alpha^16 in float64: the decay of a full block
     long long nchunks;
     unsigned long long* published; // [3][nchunks]: hold, release, attack chunk aggregates (bit patterns)
     const double* w_hold;          // (alpha_hold^C)^m, m = 0..n_hold-1
@@ -116,34 +115,30 @@ struct Limiter2Block {
     static constexpr int T = 256;
     static constexpr int E = 16;
     static constexpr int STRIDE = E + 1;               // LDS row stride (floats): conflict-free columns
-    static constexpr int G = 16;
-    using Scan = WgScan<T, G, 2>;
+    static constexpr int WAVES = T / 64;
     static constexpr int FRAMES = T * E;               // frames a workgroup touches
     static constexpr int PLANE = T * STRIDE;           // floats
     static constexpr int MAX_SPINS = 1 << 20;            // x ~0.2 us of s_sleep: a fifth of a second
 
-    // LDS carve (floats unless noted).  The window planes are dead once sl/sh are in registers,
-    // so the scan scratch and the gain plane live in the same bytes.
-    //   [0, 2*PLANE)              planes: g0 -> prefix maxima | suffix maxima
-    //   [0, SCAN_FLOATS)          scan scratch (Affine = 4 floats), aliasing plane 0
-    //   [GAIN_OFF, +PLANE)        gain plane, aliasing the tail of plane 0 / plane 1
+    // LDS carve (floats).  The window planes are dead once sl/sh are in registers, so the gain
+    // plane reuses plane 0.
+    //   [0, 2*PLANE)              planes: g0 -> prefix maxima | suffix maxima ; later [0, PLANE) = gain
     //   [2*PLANE, +T)             per-block maxima
-    //   [MISC_OFF, ...)           edge samples, look-back partials, broadcast scalars (never aliased)
-    static constexpr int SCAN_FLOATS = Scan::SCRATCH * 4;
-    static constexpr int GAIN_OFF = ((SCAN_FLOATS + 3) / 4) * 4;
-    static_assert(GAIN_OFF + PLANE <= 2 * PLANE, "gain plane must fit behind the scan scratch");
+    //   [MISC_OFF, ...)           edge samples, wave totals of the scans, broadcast scalars (never aliased)
     static constexpr int BM_OFF = 2 * PLANE;
     static constexpr int MISC_OFF = BM_OFF + T;
-    static constexpr int MISC_FLOATS = 16 + 2 * 128 + 16;       // edge sl[14] | 64 doubles | 8 doubles
+    static constexpr int MISC_FLOATS = 16 + 4 * 2 * WAVES * 2 + 16;   // edge sl[14] | totals | scalars
     static constexpr size_t LDS_BYTES = (size_t)(MISC_OFF + MISC_FLOATS) * 4 + 16;
 
     static MGX_HD float* plane(float* lds, int i) { return lds + i * PLANE; }
     static MGX_HD float* block_max(float* lds) { return lds + BM_OFF; }
-    static MGX_HD Affine* scan_area(float* lds) { return reinterpret_cast<Affine*>(lds); }
-    static MGX_HD float* gain_plane(float* lds) { return lds + GAIN_OFF; }
+    static MGX_HD float* gain_plane(float* lds) { return lds; }
     static MGX_HD float* edge_sl(float* lds) { return lds + MISC_OFF; }                 // [14]
-    static MGX_HD double* partials(float* lds) { return reinterpret_cast<double*>(lds + MISC_OFF + 16); }   // [64]
-    static MGX_HD double* scalars(float* lds) { return reinterpret_cast<double*>(lds + MISC_OFF + 16 + 256); }
+    // wave totals of scan k (0/1) of round r (0/1): WAVES Affine each
+    static MGX_HD Affine* wave_totals(float* lds, int round, int k) {
+        return reinterpret_cast<Affine*>(lds + MISC_OFF + 16) + (round * 2 + k) * WAVES;
+    }
+    static MGX_HD double* scalars(float* lds) { return reinterpret_cast<double*>(lds + MISC_OFF + 16 + 4 * 2 * WAVES * 2); }
     //   scalars: [0] hold chunk carry, [1] release chunk carry, [2] attack chunk carry, [4] ticket
     static MGX_HD int gidx(int i) { return (i >> 4) * STRIDE + (i & 15); }
 
@@ -166,9 +161,8 @@ struct Limiter2Block {
         long long base;           // first frame of this thread's block
         int valid;                // frames of the block inside [0, n)
         bool core, has_sl;
-        float g0[E], sl[E], sh[E];
-        float yf[E], x2[E], m[E];         // attack forward output; max(sh,ho); max(g0,ho)
-        float za[E], zb[E];               // zero-carry run states of the two recurrences in flight
+        float sl[E], sh[E];
+        float yf[E], x2[E], m[E];         // attack forward output; max(sh,ho); max(ho,ro)
         bool inject_left, inject_right;   // this block starts at frame 0 / holds frame n-1
         double edge_state;                // filtfilt state to inject (left: entering frame 0; right: entering n-1)
     };
@@ -184,6 +178,12 @@ struct Limiter2Block {
         return amax > thr ? (amax - thr) / amax : 0.f;
     }
     static MGX_HD float2 scaled(float2 y, float g) { return make_float2(y.x * g, y.y * g); }
+    // gain = 1 - max(g0, envelopes) = min(1 - g0, k) with k = 1 - max(envelopes) from the gain plane:
+    // the frame's own hard-clip gain g0 is re-derived from the re-read frame instead of being held
+    // in registers through the whole kernel
+    static MGX_HD float own_gain(float2 v, float k, bool with_gain, float thr) {
+        return with_gain ? fminf(k, 1.0f - gain_of(v, thr)) : 1.f;
+    }
     static MGX_HD void phase_load(int tid, long long chunk, const Limiter2Args& a, float* lds) {
         const long long r0 = region_start(chunk, a);
         const bool interior = r0 >= 0 && r0 + FRAMES <= a.n;
@@ -216,15 +216,16 @@ struct Limiter2Block {
         th.valid = th.base < 0 ? 0 : (left >= E ? E : (left > 0 ? (int)left : 0));
         float* gp = plane(lds, 0) + tid * STRIDE;
         float* gs = plane(lds, 1) + tid * STRIDE;
+        float g0[E];
         MGX_UNROLL
-        for (int j = 0; j < E; ++j) th.g0[j] = gp[j];
+        for (int j = 0; j < E; ++j) g0[j] = gp[j];
         float run = 0.f;
         MGX_UNROLL
-        for (int j = 0; j < E; ++j) { run = fmaxf(run, th.g0[j]); gp[j] = run; }
+        for (int j = 0; j < E; ++j) { run = fmaxf(run, g0[j]); gp[j] = run; }
         block_max(lds)[tid] = run;
         run = 0.f;
         MGX_UNROLL
-        for (int j = E - 1; j >= 0; --j) { run = fmaxf(run, th.g0[j]); gs[j] = run; }
+        for (int j = E - 1; j >= 0; --j) { run = fmaxf(run, g0[j]); gs[j] = run; }
     }
 
     // max of g0 over [c - lw, c + rw] for the 16 frames c of block tid (van Herk: suffix maximum of
@@ -241,13 +242,17 @@ struct Limiter2Block {
         for (int k = tid - la + 1; k <= tid + ra - 1; ++k) core = fmaxf(core, bm[k]);
         const float ml = bm[tid - la], mr = bm[tid + ra];
         const bool apart = la + ra > 0;                   // tid-la and tid+ra are different blocks
+        // Rows are STRIDE = 17 floats apart, so stepping from a block into its neighbour skips exactly
+        // one pad slot: the window's first frame c - lw sits at  bl + j - (j < lb),  its last frame
+        // c + rw at  br + j + (j + rb >= 16).  lb, rb are uniform: two base registers per side and an
+        // immediate offset per frame.
+        const float* pl = gs + (tid - la) * STRIDE - lb;
+        const float* pr = gp + (tid + ra) * STRIDE + rb;
         MGX_UNROLL
         for (int j = 0; j < E; ++j) {
-            // first frame c - lw: block tid-la at offset j-lb, or (j < lb) one block further left
-            // last frame c + rw: block tid+ra at offset j+rb, or (j+rb >= 16) one block further right
             const bool far_l = j < lb, far_r = j + rb >= E;
-            const float lft = far_l ? gs[(tid - la - 1) * STRIDE + (E + j - lb)] : gs[(tid - la) * STRIDE + (j - lb)];
-            const float rgt = far_r ? gp[(tid + ra + 1) * STRIDE + (j + rb - E)] : gp[(tid + ra) * STRIDE + (j + rb)];
+            const float lft = far_l ? pl[j - 1] : pl[j];
+            const float rgt = far_r ? pr[j + 1] : pr[j];
             float m = fmaxf(core, fmaxf(lft, rgt));
             // block tid-la is whole inside the window when the window starts left of it and ends
             // right of it; likewise block tid+ra
@@ -257,52 +262,53 @@ struct Limiter2Block {
         }
     }
 
-    // first-order recurrence over a thread's frames from a zero state, float32:
-    // z[j] = state after frame j (frames >= count do not advance the state)
-    static MGX_HD float run_forward(const Iir1f& f, const float (&x)[E], int count, float (&z)[E]) {
-        float s = 0.f;
+    // ---- first-order recurrences over a thread's 16 frames, float32 ---------------------------------
+    // state after `count` frames starting from `z0` (frames >= count do not advance the state)
+    static MGX_HD float run_forward(const Iir1f& f, const float (&x)[E], int count, float z0) {
+        float s = z0;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j)
+            if (j < count) s = fmaf(f.alpha, s, f.beta * x[j]);
+        return s;
+    }
+    static MGX_HD float run_backward(const Iir1f& f, const float (&x)[E], int count, float z0) {
+        float s = z0;
+        MGX_UNROLL
+        for (int j = E - 1; j >= 0; --j)
+            if (j < count) s = fmaf(f.alpha, s, f.beta * x[j]);
+        return s;
+    }
+    // outputs y[j] = b0 x[j] + z[j-1] with the true state z0 entering the block; returns the state
+    // after the block.  Rounding accumulates over at most 16 frames (the carry is exact float64
+    // rounded once).
+    static MGX_HD float out_forward(const Iir1f& f, const float (&x)[E], int count, float z0, float (&y)[E]) {
+        float s = z0;
         MGX_UNROLL
         for (int j = 0; j < E; ++j) {
-            if (j < count) s = fmaf(f.alpha, s, f.beta * x[j]);
-            z[j] = s;
+            if (j < count) {
+                y[j] = fmaf(f.b0, x[j], s);
+                s = fmaf(f.alpha, s, f.beta * x[j]);
+            } else {
+                y[j] = 0.f;
+            }
         }
         return s;
     }
-    static MGX_HD float run_backward(const Iir1f& f, const float (&x)[E], int count, float (&z)[E]) {
-        float s = 0.f;
-        MGX_UNROLL
-        for (int j = E - 1; j >= 0; --j) {
-            if (j < count) s = fmaf(f.alpha, s, f.beta * x[j]);
-            z[j] = s;
-        }
-        return s;
-    }
-    // outputs given the state entering the run
-    static MGX_HD void out_forward(const Iir1f& f, const float (&x)[E], const float (&z)[E], float carry,
-                                   float (&y)[E]) {
-        MGX_UNROLL
-        for (int j = 0; j < E; ++j) {
-            const float zprev = (j == 0 ? 0.f : z[j - 1]) + f.pw[j] * carry;
-            y[j] = fmaf(f.b0, x[j], zprev);
-        }
-    }
-    static MGX_HD void out_backward(const Iir1f& f, const float (&x)[E], const float (&z)[E], int count,
-                                    float carry, float (&y)[E]) {
-        float pw = 1.f;                       // alpha^(frames already processed): count-1-j at frame j
+    static MGX_HD void out_backward(const Iir1f& f, const float (&x)[E], int count, float z0, float (&y)[E]) {
+        float s = z0;
         MGX_UNROLL
         for (int j = E - 1; j >= 0; --j) {
             if (j < count) {
-                const float znext = (j + 1 < count ? z[j + 1] : 0.f) + pw * carry;
-                y[j] = fmaf(f.b0, x[j], znext);
-                pw *= f.alpha;
+                y[j] = fmaf(f.b0, x[j], s);
+                s = fmaf(f.alpha, s, f.beta * x[j]);
             } else {
                 y[j] = 0.f;
             }
         }
     }
     // alpha^count for the aggregate of a block with `count` valid frames: table[E] for a full block
-    static MGX_HD double block_decay(const double (&table)[17], double alpha, int count) {
-        if (count == E) return table[E];
+    static MGX_HD double block_decay(double full, double alpha, int count) {
+        if (count == E) return full;
         double r = 1.0;
         for (int i = 0; i < count; ++i) r *= alpha;
         return r;
@@ -337,22 +343,33 @@ struct Limiter2Block {
         return zb;
     }
 
-    // ---- P3: sl, sh, zero-carry runs of the forward attack smoother and the hold filter -------
-    static MGX_HD void phase_windows(int tid, const Limiter2Args& a, Thread& th, float* lds) {
+    // What a thread hands to the two workgroup scans that follow a phase, and what it gets back:
+    // scan 0 = forward attack smoother (round 1) / backward attack smoother, right to left (round 2);
+    // scan 1 = hold filter (round 1) / release filter (round 2).  `p0`, `p1` = composition of the
+    // maps of all blocks before this one in the scan's direction (the device composes them with
+    // wave shuffles, mgx_kernels.h; the CPU emulation with a plain loop).
+    struct ScanIn {
+        Affine m0, m1;
+    };
+    struct ScanOut {
+        Affine p0, p1;
+    };
+
+    // ---- P3: sl, sh, block maps of the forward attack smoother and the hold filter -----------------
+    static MGX_HD ScanIn phase_windows(int tid, const Limiter2Args& a, Thread& th, float* lds) {
+        ScanIn r;
+        r.m0 = affine_identity();
+        r.m1 = affine_identity();
         th.inject_left = false;
         th.inject_right = false;
         th.edge_state = 0.0;
         MGX_UNROLL
-        for (int j = 0; j < E; ++j) { th.sl[j] = 0.f; th.sh[j] = 0.f; th.za[j] = 0.f; th.zb[j] = 0.f; }
+        for (int j = 0; j < E; ++j) { th.sl[j] = 0.f; th.sh[j] = 0.f; }
         if (th.has_sl) {
             window_max(tid, a.hw, a.hw, lds, th.sl);
             MGX_UNROLL
             for (int j = 0; j < E; ++j)
                 if (j >= th.valid) th.sl[j] = 0.f;            // windows are truncated at the array ends
-            if (th.base < 0) {
-                MGX_UNROLL
-                for (int j = 0; j < E; ++j) th.sl[j] = 0.f;
-            }
             // filtfilt edge samples sl[n-7 .. n-1] for whoever holds frame n-1
             MGX_UNROLL
             for (int j = 0; j < E; ++j) {
@@ -361,55 +378,40 @@ struct Limiter2Block {
             }
             th.inject_left = th.base == 0;
             th.inject_right = th.valid > 0 && th.base + th.valid == a.n;
-            run_forward(a.attf, th.sl, th.valid, th.za);
+            if (th.valid > 0) {
+                const double decay = block_decay(a.pa16, a.att.alpha, th.valid);
+                const double zend = (double)run_forward(a.attf, th.sl, th.valid, 0.f);
+                r.m0 = Affine{decay, zend};
+                if (th.inject_left) {
+                    // the state entering frame 0 is filtfilt's steady-state start, whatever precedes it
+                    th.edge_state = filtfilt_left_state(a.att, th.sl);
+                    r.m0 = Affine{0.0, fma(decay, th.edge_state, zend)};
+                }
+            }
         }
         if (th.core) {
             window_max(tid, a.hw + a.hb, a.hw, lds, th.sh);
             MGX_UNROLL
             for (int j = 0; j < E; ++j)
                 if (j >= th.valid) th.sh[j] = 0.f;
-            run_forward(a.holdf, th.sh, th.valid, th.zb);
+            if (th.valid > 0)
+                r.m1 = Affine{block_decay(a.ph16, a.hold.alpha, th.valid), (double)run_forward(a.holdf, th.sh, th.valid, 0.f)};
         }
+        return r;
     }
 
-    // ---- P4: block aggregates of both runs -> scan scratch (aliases the planes: barrier first) --
-    static MGX_HD void phase_put_first(int tid, const Limiter2Args& a, Thread& th, float* lds) {
-        Affine m_att = affine_identity(), m_hold = affine_identity();
-        if (th.has_sl && th.valid > 0) {
-            const double decay = block_decay(a.pa, a.att.alpha, th.valid);
-            m_att = Affine{decay, (double)th.za[E - 1]};
-            if (th.inject_left) {
-                // state entering frame 0 is the filtfilt steady-state start, whatever precedes it
-                th.edge_state = filtfilt_left_state(a.att, th.sl);
-                m_att = Affine{0.0, fma(decay, th.edge_state, (double)th.za[E - 1])};
-            }
-        }
-        if (th.core && th.valid > 0) m_hold = Affine{block_decay(a.ph, a.hold.alpha, th.valid), (double)th.zb[E - 1]};
-        Affine* sc = scan_area(lds);
-        Scan::put(sc, 0, tid, m_att);
-        Scan::put(sc, 1, tid, m_hold);
+    // ---- chunk carries ----------------------------------------------------------------------------
+    // slot 0 = hold, 1 = release, 2 = forward attack.  A chunk publishes the state its core frames
+    // produce from a zero carry; lane `lane` of the fetching wave returns its share of
+    // sum_m w[m] * published[chunk-1-m] (the caller adds the 64 shares).
+    static MGX_HD void lookback_publish(long long chunk, int slot, const Limiter2Args& a, double b) {
+        publish_word(a.published + (size_t)slot * a.nchunks + chunk, double_bits(b));
     }
-
-    // ---- chunk carries: publish this chunk's zero-carry state, gather the predecessors' --------
-    // slot 0 = hold, 1 = release.  Thread 0 publishes; threads 0..63 fetch; thread 0 reduces.
-    // slot 0 = hold, 1 = release (scan 1, all core blocks), 2 = forward attack (scan 0, up to the
-    // end of the core: the blocks of the right halo belong to the next chunk's carry)
-    static MGX_HD void lookback_publish(int tid, long long chunk, int slot, const Limiter2Args& a, const float* lds) {
-        if (tid == 0) {
-            const Affine* sc = scan_area(const_cast<float*>(lds));
-            const double b = slot == 2 ? Scan::prefix(sc, 0, T - a.gr).b : Scan::whole(sc, 1).b;
-            publish_word(a.published + (size_t)slot * a.nchunks + chunk, double_bits(b));
-        }
-    }
-    static MGX_HD void lookback_fetch(int tid, long long chunk, int slot, const Limiter2Args& a, float* lds) {
-        if (tid >= 64) return;
-        lookback_fetch_into(tid, chunk, slot, a, partials(lds));
-    }
-    static MGX_HD void lookback_fetch_into(int tid, long long chunk, int slot, const Limiter2Args& a, double* part) {
+    static MGX_HD double lookback_share(int lane, long long chunk, int slot, const Limiter2Args& a) {
         const double* w = slot == 0 ? a.w_hold : (slot == 1 ? a.w_rel : a.w_att);
         const int count = slot == 0 ? a.n_hold : (slot == 1 ? a.n_rel : a.n_att);
         double acc = 0.0;
-        for (int m = tid; m < count; m += 64) {
+        for (int m = lane; m < count; m += 64) {
             const long long c = chunk - 1 - m;
             if (c < 0) break;
             unsigned long long* p = a.published + (size_t)slot * a.nchunks + c;
@@ -426,93 +428,63 @@ struct Limiter2Block {
             }
             acc = fma(w[m], bits_double(v), acc);
         }
-        part[tid] = acc;
-    }
-    // two slots gathered by the two halves of a 128-thread group (hold: threads 0..63, attack: 64..127)
-    static MGX_HD void lookback_fetch_pair(int tid, long long chunk, const Limiter2Args& a, float* lds) {
-        if (tid < 64) lookback_fetch(tid, chunk, 0, a, lds);
-        else if (tid < 128) lookback_fetch_into(tid - 64, chunk, 2, a, partials(lds) + 64);
-    }
-    // `half` selects which 64 partials; fixed summation order
-    static MGX_HD void lookback_reduce(int tid, int slot, int half, float* lds) {
-        if (tid != half * 64) return;
-        const double* p = partials(lds) + half * 64;
-        double s = 0.0;
-        for (int i = 0; i < 64; ++i) s += p[i];
-        scalars(lds)[slot] = s;
+        return acc;
     }
 
-    // ---- P5: exact forward attack output and hold output; zero-carry runs of the backward attack
-    //          smoother (input yf) and the release filter (input max(sh, ho)) ----------------------
-    struct Second {
-        Affine m_bwd, m_rel;
-    };
-    static MGX_HD Second phase_exact_first(int tid, const Limiter2Args& a, Thread& th, const float* lds) {
-        Second r;
-        r.m_bwd = affine_identity();
-        r.m_rel = affine_identity();
-        const Affine* sc = scan_area(const_cast<float*>(lds));
+    // ---- P5: exact forward attack output and hold output; block maps of the backward attack
+    //          smoother (input yf) and of the release filter (input max(sh, ho)) --------------------
+    static MGX_HD ScanIn phase_exact_first(int tid, const Limiter2Args& a, Thread& th, const ScanOut& pre,
+                                           double att_carry, double hold_carry, const float* lds) {
+        ScanIn r;
+        r.m0 = affine_identity();
+        r.m1 = affine_identity();
         MGX_UNROLL
-        for (int j = 0; j < E; ++j) { th.yf[j] = 0.f; th.x2[j] = 0.f; th.m[j] = th.g0[j]; }
+        for (int j = 0; j < E; ++j) { th.yf[j] = 0.f; th.x2[j] = 0.f; th.m[j] = 0.f; }
         if (th.has_sl) {
-            double c = affine_apply(Scan::prefix(sc, 0, tid), scalars(const_cast<float*>(lds))[2]);
+            double c = affine_apply(pre.p0, att_carry);
             if (th.inject_left) c = th.edge_state;
-            out_forward(a.attf, th.sl, th.za, (float)c, th.yf);
-            MGX_UNROLL
-            for (int j = 0; j < E; ++j)
-                if (j >= th.valid) th.yf[j] = 0.f;
-            double z_end = 0.0;                        // forward state after frame n-1 (right filtfilt edge)
-            if (th.inject_right) {
-                float zl = 0.f;
-                MGX_UNROLL
-                for (int j = 0; j < E; ++j)
-                    if (j == th.valid - 1) zl = th.za[j];
-                z_end = fma(block_decay(a.pa, a.att.alpha, th.valid), c, (double)zl);
-            }
-            run_backward(a.attf, th.yf, th.valid, th.za);
+            const float zend = out_forward(a.attf, th.sl, th.valid, (float)c, th.yf);
             if (th.valid > 0) {
-                const double decay = block_decay(a.pa, a.att.alpha, th.valid);
-                r.m_bwd = Affine{decay, (double)th.za[0]};
+                const double decay = block_decay(a.pa16, a.att.alpha, th.valid);
+                const double zb = (double)run_backward(a.attf, th.yf, th.valid, 0.f);
+                r.m0 = Affine{decay, zb};
                 if (th.inject_right) {
-                    th.edge_state = filtfilt_right_state(a.att, edge_sl(const_cast<float*>(lds)) + 7, z_end);
-                    r.m_bwd = Affine{0.0, fma(decay, th.edge_state, (double)th.za[0])};
+                    // forward state after frame n-1 -> filtfilt's backward start
+                    th.edge_state = filtfilt_right_state(a.att, edge_sl(const_cast<float*>(lds)) + 7, (double)zend);
+                    r.m0 = Affine{0.0, fma(decay, th.edge_state, zb)};
                 }
             }
         }
         if (th.core) {
-            const double c = affine_apply(Scan::prefix(sc, 1, tid), scalars(const_cast<float*>(lds))[0]);
+            const double c = affine_apply(pre.p1, hold_carry);
             float ho[E];
-            out_forward(a.holdf, th.sh, th.zb, (float)c, ho);
+            out_forward(a.holdf, th.sh, th.valid, (float)c, ho);
             MGX_UNROLL
             for (int j = 0; j < E; ++j) {
                 th.x2[j] = fmaxf(th.sh[j], ho[j]);                 // hyrax.py:73
-                th.m[j] = fmaxf(th.g0[j], ho[j]);
+                th.m[j] = ho[j];
             }
-            run_forward(a.relf, th.x2, th.valid, th.zb);
-            if (th.valid > 0) r.m_rel = Affine{block_decay(a.pr, a.rel.alpha, th.valid), (double)th.zb[E - 1]};
+            if (th.valid > 0)
+                r.m1 = Affine{block_decay(a.pr16, a.rel.alpha, th.valid), (double)run_forward(a.relf, th.x2, th.valid, 0.f)};
         }
         return r;
     }
-    static MGX_HD void phase_put_second(int tid, float* lds, const Second& s) {
-        Affine* sc = scan_area(lds);
-        Scan::put(sc, 0, T - 1 - tid, s.m_bwd);          // right-to-left scan order
-        Scan::put(sc, 1, tid, s.m_rel);
-    }
 
-    // ---- P7: exact backward attack output and release output -> gain -> LDS gain plane ---------
-    static MGX_HD void phase_gain(int tid, const Limiter2Args& a, Thread& th, float* lds) {
+    // ---- P7: exact backward attack output and release output -> gain -> LDS gain plane -------------
+    static MGX_HD void phase_gain(int tid, const Limiter2Args& a, Thread& th, const ScanOut& pre, double rel_carry,
+                                  float* lds) {
         if (!th.core) return;
-        const Affine* sc = scan_area(lds);
-        double cb = affine_apply(Scan::prefix(sc, 0, T - 1 - tid), 0.0);
+        double cb = affine_apply(pre.p0, 0.0);
         if (th.inject_right) cb = th.edge_state;
-        const double cr = affine_apply(Scan::prefix(sc, 1, tid), scalars(lds)[1]);
-        float yb[E], ro[E];
-        out_backward(a.attf, th.yf, th.za, th.valid, (float)cb, yb);
-        out_forward(a.relf, th.x2, th.zb, (float)cr, ro);
+        const double cr = affine_apply(pre.p1, rel_carry);
+        float ro[E], yb[E];
+        out_forward(a.relf, th.x2, th.valid, (float)cr, ro);
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) th.m[j] = fmaxf(th.m[j], ro[j]);           // max(ho, ro), hyrax.py:75
+        out_backward(a.attf, th.yf, th.valid, (float)cb, yb);
         float* gn = gain_plane(lds) + tid * STRIDE;
         MGX_UNROLL
-        for (int j = 0; j < E; ++j)
-            gn[j] = 1.0f - fmaxf(th.m[j], fmaxf(yb[j], ro[j]));   // hyrax.py:75,97
+        for (int j = 0; j < E; ++j) gn[j] = 1.0f - fmaxf(th.m[j], yb[j]);      // hyrax.py:97 without g0 (phase_store)
     }
 
     // ---- P8: coalesced reload, apply gain, store ------------------------------------------------
@@ -532,17 +504,18 @@ struct Limiter2Block {
             if (interior) {
                 const float4 q = *reinterpret_cast<const float4*>(a.y + f);
                 const float2 v0 = scaled(make_float2(q.x, q.y), g), v1 = scaled(make_float2(q.z, q.w), g);
-                const float s0 = k0 * post, s1 = k1 * post;
+                const float s0 = own_gain(v0, k0, with_gain, a.threshold) * post;
+                const float s1 = own_gain(v1, k1, with_gain, a.threshold) * post;
                 *reinterpret_cast<float4*>(a.out + f) = make_float4(v0.x * s0, v0.y * s0, v1.x * s1, v1.y * s1);
             } else {
                 if (f < a.n) {
                     const float2 v = scaled(a.y[f], g);
-                    const float s = k0 * post;
+                    const float s = own_gain(v, k0, with_gain, a.threshold) * post;
                     a.out[f] = make_float2(v.x * s, v.y * s);
                 }
                 if (f + 1 < a.n) {
                     const float2 v = scaled(a.y[f + 1], g);
-                    const float s = k1 * post;
+                    const float s = own_gain(v, k1, with_gain, a.threshold) * post;
                     a.out[f + 1] = make_float2(v.x * s, v.y * s);
                 }
             }

@@ -584,12 +584,64 @@ __global__ __launch_bounds__(256) void k_frame_peaks(const float2* x, long long 
 // ---------------------------------------------------------------------------
 // limiter (limiter2_kernel.h): one launch, grid = chunks
 // ---------------------------------------------------------------------------
+// Ordered composition of affine maps across a workgroup: inclusive scan over the 64 lanes of each
+// wave by shuffles (scan order = lane order, or reversed), wave totals through LDS, then every
+// thread composes the totals of the waves before it.  Returns the composition of all maps BEFORE
+// this thread in scan order; `*whole` (if wanted) the composition of everything.
+template <bool REVERSE>
+__device__ __forceinline__ Affine wave_inclusive(Affine m) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        Affine o;
+        o.a = REVERSE ? __shfl_down(m.a, d, 64) : __shfl_up(m.a, d, 64);
+        o.b = REVERSE ? __shfl_down(m.b, d, 64) : __shfl_up(m.b, d, 64);
+        const bool has = REVERSE ? (lane + d < 64) : (lane >= d);
+        if (has) m = affine_then(o, m);
+    }
+    return m;
+}
+template <bool REVERSE>
+__device__ __forceinline__ Affine wave_exclusive(Affine inclusive) {
+    const int lane = threadIdx.x & 63;
+    Affine o;
+    o.a = REVERSE ? __shfl_down(inclusive.a, 1, 64) : __shfl_up(inclusive.a, 1, 64);
+    o.b = REVERSE ? __shfl_down(inclusive.b, 1, 64) : __shfl_up(inclusive.b, 1, 64);
+    const bool first = REVERSE ? lane == 63 : lane == 0;
+    return first ? affine_identity() : o;
+}
+// totals[w] = inclusive total of wave w (written by the caller before the barrier)
+template <bool REVERSE, int WAVES>
+__device__ __forceinline__ Affine compose_waves(const Affine* totals, Affine exclusive_in_wave, Affine* whole) {
+    const int w = threadIdx.x >> 6;
+    Affine before = affine_identity(), all = affine_identity();
+#pragma unroll
+    for (int i = 0; i < WAVES; ++i) {
+        const int k = REVERSE ? WAVES - 1 - i : i;           // waves in scan order
+        const Affine t = totals[k];
+        const bool earlier = REVERSE ? k > w : k < w;
+        if (earlier) before = affine_then(before, t);
+        all = affine_then(all, t);
+    }
+    if (whole) *whole = all;
+    return affine_then(before, exclusive_in_wave);
+}
+
+// The phases of a kernel share index arithmetic (LDS addresses derived from the thread id).  Left
+// alone, the compiler computes it once and keeps dozens of addresses alive across the whole
+// kernel -- in scratch memory once the registers run out.  An empty asm makes the id opaque so
+// that each phase re-derives its few addresses instead.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 __global__ __launch_bounds__(Limiter2Block::T, 4) void k_limit(Limiter2Args a) {
     using LB = Limiter2Block;
     MGX_LDS;
     float* lds = reinterpret_cast<float*>(mgx_smem);
     int& ticket = *reinterpret_cast<int*>(LB::scalars(lds) + 4);      // dynamic LDS only (16-byte aligned base)
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool active = a.active ? (*a.active != 0) : true;
     if (!active) {                       // hyrax.py:83-85: the array passes through, then stages.py:203
         LB::phase_store(tid, blockIdx.x, a, false, lds);
@@ -599,41 +651,50 @@ __global__ __launch_bounds__(Limiter2Block::T, 4) void k_limit(Limiter2Args a) {
     __syncthreads();
     const long long chunk = ticket;
     LB::Thread th;
-    LB::phase_load(tid, chunk, a, lds);
+    LB::phase_load(opaque(tid), chunk, a, lds);
     __syncthreads();
-    LB::phase_planes(tid, chunk, a, th, lds);
+    LB::phase_planes(opaque(tid), chunk, a, th, lds);
     __syncthreads();
-    LB::phase_windows(tid, a, th, lds);
+
+    // round 1: forward attack smoother (scan 0) and hold filter (scan 1)
+    const LB::ScanIn in1 = LB::phase_windows(opaque(tid), a, th, lds);
+    Affine i0 = wave_inclusive<false>(in1.m0), i1 = wave_inclusive<false>(in1.m1);
+    if (lane == 63) { LB::wave_totals(lds, 0, 0)[wave] = i0; LB::wave_totals(lds, 0, 1)[wave] = i1; }
+    Affine e0 = wave_exclusive<false>(i0), e1 = wave_exclusive<false>(i1);
     __syncthreads();
-    LB::phase_put_first(tid, a, th, lds);
+    LB::ScanOut pre;
+    Affine whole;
+    pre.p0 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 0, 0), e0, nullptr);
+    pre.p1 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 0, 1), e1, &whole);
+    if (tid == LB::T - a.gr) LB::lookback_publish(chunk, 2, a, pre.p0.b);      // attack state at the end of the core
+    if (tid == 0) LB::lookback_publish(chunk, 0, a, whole.b);
+    if (wave < 2) {                      // wave 0 gathers the hold carry, wave 1 the attack carry
+        const int slot = wave == 0 ? 0 : 2;
+        const double s = wave_sum(LB::lookback_share(lane, chunk, slot, a));
+        if (lane == 0) LB::scalars(lds)[slot] = s;
+    }
     __syncthreads();
-    LB::Scan::scan_groups(LB::scan_area(lds), tid);
+
+    // round 2: backward attack smoother, right to left (scan 0), and release filter (scan 1)
+    const LB::ScanIn in2 = LB::phase_exact_first(opaque(tid), a, th, pre, LB::scalars(lds)[2], LB::scalars(lds)[0], lds);
+    i0 = wave_inclusive<true>(in2.m0);
+    i1 = wave_inclusive<false>(in2.m1);
+    if (lane == 0) LB::wave_totals(lds, 1, 0)[wave] = i0;
+    if (lane == 63) LB::wave_totals(lds, 1, 1)[wave] = i1;
+    e0 = wave_exclusive<true>(i0);
+    e1 = wave_exclusive<false>(i1);
     __syncthreads();
-    LB::Scan::scan_top(LB::scan_area(lds), tid);
+    pre.p0 = compose_waves<true, LB::WAVES>(LB::wave_totals(lds, 1, 0), e0, nullptr);
+    pre.p1 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 1, 1), e1, &whole);
+    if (tid == 0) LB::lookback_publish(chunk, 1, a, whole.b);
+    if (wave == 0) {
+        const double s = wave_sum(LB::lookback_share(lane, chunk, 1, a));
+        if (lane == 0) LB::scalars(lds)[1] = s;
+    }
     __syncthreads();
-    LB::lookback_publish(tid, chunk, 0, a, lds);
-    LB::lookback_publish(tid, chunk, 2, a, lds);
-    LB::lookback_fetch_pair(tid, chunk, a, lds);
+    LB::phase_gain(opaque(tid), a, th, pre, LB::scalars(lds)[1], lds);
     __syncthreads();
-    LB::lookback_reduce(tid, 0, 0, lds);
-    LB::lookback_reduce(tid, 2, 1, lds);
-    __syncthreads();
-    const LB::Second second = LB::phase_exact_first(tid, a, th, lds);
-    __syncthreads();
-    LB::phase_put_second(tid, lds, second);
-    __syncthreads();
-    LB::Scan::scan_groups(LB::scan_area(lds), tid);
-    __syncthreads();
-    LB::Scan::scan_top(LB::scan_area(lds), tid);
-    __syncthreads();
-    LB::lookback_publish(tid, chunk, 1, a, lds);
-    LB::lookback_fetch(tid, chunk, 1, a, lds);
-    __syncthreads();
-    LB::lookback_reduce(tid, 1, 0, lds);
-    __syncthreads();
-    LB::phase_gain(tid, a, th, lds);
-    __syncthreads();
-    LB::phase_store(tid, chunk, a, true, lds);
+    LB::phase_store(opaque(tid), chunk, a, true, lds);
 }
 
 }  // namespace mgx

@@ -208,11 +208,30 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
     a.error = &ctrl[1];
     std::vector<float> lds(LB::LDS_BYTES / 4 + 8);
     std::vector<LB::Thread> th(LB::T);
-    std::vector<LB::Second> second(LB::T);
+    std::vector<LB::ScanIn> in(LB::T);
+    std::vector<LB::ScanOut> pre(LB::T);
+    // the workgroup scans of the device kernel (wave shuffles there), as plain ordered loops:
+    // scan 1 always left to right, scan 0 left to right or (reverse0) right to left
+    auto scan = [&](bool reverse0, Affine& whole1) {
+        Affine run = affine_identity();
+        for (int t = 0; t < LB::T; ++t) { pre[t].p1 = run; run = affine_then(run, in[t].m1); }
+        whole1 = run;
+        run = affine_identity();
+        for (int i = 0; i < LB::T; ++i) {
+            const int t = reverse0 ? LB::T - 1 - i : i;
+            pre[t].p0 = run;
+            run = affine_then(run, in[t].m0);
+        }
+    };
+    auto carry = [&](long long chunk, int slot) {
+        double s = 0.0;
+        for (int lane = 0; lane < 64; ++lane) s += LB::lookback_share(lane, chunk, slot, a);
+        return s;
+    };
     for (long long chunk = 0; chunk < a.nchunks; ++chunk) {
         FOR_THREADS(LB::T) LB::phase_load(tid, chunk, a, lds.data());
         FOR_THREADS(LB::T) LB::phase_planes(tid, chunk, a, th[tid], lds.data());
-        FOR_THREADS(LB::T) LB::phase_windows(tid, a, th[tid], lds.data());
+        FOR_THREADS(LB::T) in[tid] = LB::phase_windows(tid, a, th[tid], lds.data());
         if (dbg_sl || dbg_sh) {
             FOR_THREADS(LB::T) {
                 if (!th[tid].core) continue;
@@ -222,22 +241,16 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
                 }
             }
         }
-        FOR_THREADS(LB::T) LB::phase_put_first(tid, a, th[tid], lds.data());
-        FOR_THREADS(LB::T) LB::Scan::scan_groups(LB::scan_area(lds.data()), tid);
-        FOR_THREADS(LB::T) LB::Scan::scan_top(LB::scan_area(lds.data()), tid);
-        FOR_THREADS(LB::T) LB::lookback_publish(tid, chunk, 0, a, lds.data());
-        FOR_THREADS(LB::T) LB::lookback_publish(tid, chunk, 2, a, lds.data());
-        FOR_THREADS(LB::T) LB::lookback_fetch_pair(tid, chunk, a, lds.data());
-        FOR_THREADS(LB::T) LB::lookback_reduce(tid, 0, 0, lds.data());
-        FOR_THREADS(LB::T) LB::lookback_reduce(tid, 2, 1, lds.data());
-        FOR_THREADS(LB::T) second[tid] = LB::phase_exact_first(tid, a, th[tid], lds.data());
-        FOR_THREADS(LB::T) LB::phase_put_second(tid, lds.data(), second[tid]);
-        FOR_THREADS(LB::T) LB::Scan::scan_groups(LB::scan_area(lds.data()), tid);
-        FOR_THREADS(LB::T) LB::Scan::scan_top(LB::scan_area(lds.data()), tid);
-        FOR_THREADS(LB::T) LB::lookback_publish(tid, chunk, 1, a, lds.data());
-        FOR_THREADS(LB::T) LB::lookback_fetch(tid, chunk, 1, a, lds.data());
-        FOR_THREADS(LB::T) LB::lookback_reduce(tid, 1, 0, lds.data());
-        FOR_THREADS(LB::T) LB::phase_gain(tid, a, th[tid], lds.data());
+        Affine whole;
+        scan(false, whole);
+        LB::lookback_publish(chunk, 2, a, pre[LB::T - a.gr].p0.b);
+        LB::lookback_publish(chunk, 0, a, whole.b);
+        const double hold_carry = carry(chunk, 0), att_carry = carry(chunk, 2);
+        FOR_THREADS(LB::T) in[tid] = LB::phase_exact_first(tid, a, th[tid], pre[tid], att_carry, hold_carry, lds.data());
+        scan(true, whole);
+        LB::lookback_publish(chunk, 1, a, whole.b);
+        const double rel_carry = carry(chunk, 1);
+        FOR_THREADS(LB::T) LB::phase_gain(tid, a, th[tid], pre[tid], rel_carry, lds.data());
         FOR_THREADS(LB::T) LB::phase_store(tid, chunk, a, true, lds.data());
     }
     return ctrl[1] ? -2 : 0;
