@@ -224,7 +224,9 @@ struct Conv2Block {
             MGX_UNROLL
             for (int j = 0; j < R0; ++j) {
                 const int i = u + j * S0;                         // h'[i] = h[i-1], i in [1, F]
-                v[j] = make_float2((i >= 1 && i <= TAPS) ? taps[i - 1] : 0.f, 0.f);
+                const bool ok = i >= 1 && i <= TAPS;
+                const float t = taps[ok ? i - 1 : 0];             // unconditional load, then select
+                v[j] = make_float2(ok ? t : 0.f, 0.f);
             }
             F::fwd0_store(v, tid, c, ps.tw0, lds);
         }

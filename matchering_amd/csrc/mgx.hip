@@ -57,8 +57,13 @@ struct DevBuf {
 struct TrackWork {              // per-track analysis workspace + results (device)
     DevBuf wg_sumsq, wg_peak, wg_spec, stats, rms, loud, avg;   // avg: [2][F/2+1] double
     DevBuf part;                                                 // [SPEC_SLICES][2][F/2+1] partial spectrum sums
-    int divisions = 0, segs_per_piece = 0, segs_per_wg = 0, chunks = 0;
+    int divisions = 0, segs_per_piece = 0, segs_per_wg = 0, chunks = 0, nwg = 0, is_reference = 0;
     long long piece = 0;
+};
+
+struct PlanDev {
+    void* blob = nullptr;       // FirPlanHost tables
+    double* M = nullptr;        // [bins][bins] raw -> smooth operator
 };
 
 struct mgx_handle {
@@ -71,7 +76,7 @@ struct mgx_handle {
     DevBuf lim_published, lim_ctrl, lim_weights;
     std::vector<double> lim_weights_host;
     DevBuf fir_scratch;
-    std::map<const FirPlanHost*, void*> plan_dev;                 // uploaded plan blobs
+    std::map<const FirPlanHost*, PlanDev> plan_dev;               // uploaded plan blobs + dense operators
     std::vector<std::shared_ptr<FirPlanHost>> plans;              // keeps the host plans alive
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -200,39 +205,95 @@ static int run_analysis(mgx_handle* h, const float* x, long long n, const mgx_co
 #undef CASE
         default: return fail(MGX_ERR_UNSUPPORTED, "fft_size not supported by the analysis kernel");
     }
-    const size_t lds = (size_t)(64 + w.divisions) * sizeof(double);
+    w.nwg = nwg;
+    w.is_reference = is_reference;
+    return 0;
+}
+
+static LevelsArgs levels_args(const TrackWork& w) {
+    LevelsArgs a;
+    a.wg_sumsq = (const double*)w.wg_sumsq.p;
+    a.wg_peak = (const float*)w.wg_peak.p;
+    a.chunks_per_piece = w.chunks;
+    a.divisions = w.divisions;
+    a.piece = w.piece;
+    a.is_reference = w.is_reference;
+    a.st = (TrackStats*)w.stats.p;
+    a.rms = (double*)w.rms.p;
+    a.loud = (int*)w.loud.p;
+    return a;
+}
+static SpectraArgs spectra_args(const TrackWork& w) {
+    SpectraArgs a;
+    a.wg_spec = (const float*)w.wg_spec.p;
+    a.loud = (const int*)w.loud.p;
+    a.chunks_per_piece = w.chunks;
+    a.nwg = w.nwg;
+    a.part = (double*)w.part.p;
+    return a;
+}
+// piece statistics -> decisions, then the loud pieces' spectrum sums; one launch each for 1 or 2 tracks
+static int run_levels(mgx_handle* h, const mgx_config* cfg, TrackWork* first, TrackWork* second) {
+    const int tracks = second ? 2 : 1, half = cfg->fft_size / 2;
+    const int max_div = std::max(first->divisions, second ? second->divisions : 0);
+    const size_t lds = (size_t)(64 + max_div) * sizeof(double);
     if (lds > 150 * 1024) return fail(MGX_ERR_UNSUPPORTED, "too many analysis pieces");
     MGX_TRY(allow_lds(k_levels, lds));
-    hipLaunchKernelGGL(k_levels, dim3(1), dim3(1024), lds, h->stream, (const double*)w.wg_sumsq.p,
-                       (const float*)w.wg_peak.p, w.chunks, w.divisions, w.piece, is_reference, cfg->threshold,
-                       cfg->min_value, (TrackStats*)w.stats.p, (double*)w.rms.p, (int*)w.loud.p);
-    HIP_TRY(hipGetLastError());
-    MGX_TRY(ensure(h, w.part, (size_t)SPEC_SLICES * 2 * (half + 1) * sizeof(double)));
-    hipLaunchKernelGGL(k_average_spectra, dim3((half + 1 + 63) / 64, 2, SPEC_SLICES), dim3(1024), 0, h->stream,
-                       (const float*)w.wg_spec.p, (const int*)w.loud.p, w.chunks, nwg, half + 1, (double*)w.part.p);
+    for (TrackWork* w : {first, second})
+        if (w) MGX_TRY(ensure(h, w->part, (size_t)SPEC_SLICES * 2 * (half + 1) * sizeof(double)));
+    const LevelsArgs l0 = levels_args(*first), l1 = second ? levels_args(*second) : l0;
+    hipLaunchKernelGGL(k_levels, dim3(tracks), dim3(1024), lds, h->stream, l0, l1, cfg->threshold, cfg->min_value);
+    const SpectraArgs s0 = spectra_args(*first), s1 = second ? spectra_args(*second) : s0;
+    hipLaunchKernelGGL(k_average_spectra, dim3((half + 1 + 63) / 64, 2, SPEC_SLICES * tracks), dim3(1024), 0, h->stream,
+                       s0, s1, half + 1);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // device-side FIR design (fir_plan.h): spectra partial sums of both tracks -> h->taps ([2][F] float),
-// level gain c0 -> h->scalars[0].  No host synchronisation.
+// level gain c0 -> h->scalars[0].  No host synchronisation.  The chain raw -> smooth is one dense
+// operator per plan (mgx_kernels.h), built on first use.
+static int build_fir_operator(mgx_handle* h, const FirPlanView& pl, double** out) {
+    const size_t per = (size_t)3 * pl.bins + (size_t)3 * pl.nlog + pl.lw.anchors;
+    const int batch = std::min(pl.bins, 256);
+    double* scratch = nullptr;
+    double* M = nullptr;
+    HIP_TRY(hipMalloc((void**)&scratch, (size_t)batch * per * sizeof(double)));
+    HIP_TRY(hipMalloc((void**)&M, (size_t)pl.bins * pl.bins * sizeof(double)));
+    const size_t lds_scan = (size_t)FirDesign::Scan::SCRATCH * sizeof(Affine);
+    for (int col0 = 0; col0 < pl.bins; col0 += batch) {
+        const int nb = std::min(batch, pl.bins - col0);
+        hipLaunchKernelGGL(k_fir_unit_a, dim3(nb), dim3(1024), lds_scan, h->stream, pl, scratch, col0);
+        hipLaunchKernelGGL(k_fir_lowess, dim3((pl.lw.anchors + 15) / 16, nb), dim3(1024), 0, h->stream, pl, scratch);
+        hipLaunchKernelGGL(k_fir_b, dim3(nb), dim3(1024), lds_scan, h->stream, pl, scratch);
+        hipLaunchKernelGGL(k_fir_gather, dim3((nb + 255) / 256, pl.bins), dim3(256), 0, h->stream, pl, scratch, col0,
+                           nb, M);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(scratch));
+    *out = M;
+    return 0;
+}
+
 static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork& tw, const TrackWork& rw) {
     FirDesignParams p{cfg->fft_size, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac,
                       cfg->lowess_it, cfg->lowess_delta, cfg->min_value};
     std::shared_ptr<FirPlanHost> plan = FirPlanHost::get(p);
-    void* dev_blob = nullptr;
+    PlanDev pd;
     auto it = h->plan_dev.find(plan.get());
     if (it == h->plan_dev.end()) {
-        HIP_TRY(hipMalloc(&dev_blob, plan->blob_bytes()));
-        HIP_TRY(hipMemcpy(dev_blob, plan->blob(), plan->blob_bytes(), hipMemcpyHostToDevice));
-        h->plan_dev[plan.get()] = dev_blob;
+        HIP_TRY(hipMalloc(&pd.blob, plan->blob_bytes()));
+        HIP_TRY(hipMemcpy(pd.blob, plan->blob(), plan->blob_bytes(), hipMemcpyHostToDevice));
+        MGX_TRY(build_fir_operator(h, plan->view(pd.blob), &pd.M));
+        h->plan_dev[plan.get()] = pd;
         h->plans.push_back(plan);
     } else {
-        dev_blob = it->second;
+        pd = it->second;
     }
-    const FirPlanView pl = plan->view(dev_blob);
+    const FirPlanView pl = plan->view(pd.blob);
     const size_t per = (size_t)3 * pl.bins + (size_t)3 * pl.nlog + pl.lw.anchors;
-    MGX_TRY(ensure(h, h->fir_scratch, 2 * per * sizeof(double)));
+    MGX_TRY(ensure(h, h->fir_scratch, (2 * per + 2 * (size_t)pl.bins) * sizeof(double)));
     MGX_TRY(ensure(h, h->scalars, 64));
     MGX_TRY(ensure(h, h->taps, (size_t)2 * cfg->fft_size * sizeof(float)));
     FirInputs in;
@@ -244,10 +305,11 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     in.segs_r = rw.segs_per_piece;
     in.eps = cfg->min_value;
     double* scratch = (double*)h->fir_scratch.p;
-    const size_t lds_scan = (size_t)FirDesign::Scan::SCRATCH * sizeof(Affine);
-    hipLaunchKernelGGL(k_fir_a, dim3(2), dim3(1024), lds_scan, h->stream, pl, in, scratch, (double*)h->scalars.p);
-    hipLaunchKernelGGL(k_fir_lowess, dim3((pl.lw.anchors + 15) / 16, 2), dim3(1024), 0, h->stream, pl, scratch);
-    hipLaunchKernelGGL(k_fir_b, dim3(2), dim3(1024), lds_scan, h->stream, pl, scratch);
+    double* raw = scratch + 2 * per;
+    hipLaunchKernelGGL(k_fir_raw, dim3((pl.bins + 255) / 256, 2), dim3(256), 0, h->stream, pl, in, raw,
+                       (double*)h->scalars.p);
+    hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
+                       (const double*)raw, scratch);
     const size_t lds_taps = ((size_t)pl.fft + pl.bins + 1024) * sizeof(double);
     MGX_TRY(allow_lds(k_fir_taps, lds_taps));
     hipLaunchKernelGGL(k_fir_taps, dim3(pl.fft / 64, 2), dim3(1024), lds_taps, h->stream, pl, (const double*)scratch,
@@ -456,6 +518,10 @@ int mgx_destroy(mgx_handle* h) {
             if (b->p) hipFree(b->p);
     }
     for (auto& kv : h->twiddles) hipFree(kv.second);
+    for (auto& kv : h->plan_dev) {
+        if (kv.second.blob) hipFree(kv.second.blob);
+        if (kv.second.M) hipFree(kv.second.M);
+    }
     if (h->pinned) hipHostFree(h->pinned);
     hipEventDestroy(h->ev0);
     hipEventDestroy(h->ev1);
@@ -516,6 +582,7 @@ int mgx_analyze(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* 
     HIP_TRY(hipSetDevice(h->device));
     TrackWork& w = h->track[is_reference ? 1 : 0];
     MGX_TRY(run_analysis(h, x_dev, n, cfg, is_reference, w));
+    MGX_TRY(run_levels(h, cfg, &w, nullptr));
     {
         const int total = 2 * (cfg->fft_size / 2 + 1);
         hipLaunchKernelGGL(k_finish_spectra, dim3((total + 255) / 256), dim3(256), 0, h->stream,
@@ -675,6 +742,7 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     TrackWork& rw = h->track[1];
     MGX_TRY(run_analysis(h, target_dev, n_target, cfg, 0, tw));
     MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
+    MGX_TRY(run_levels(h, cfg, &tw, &rw));
     // stage 2 (stages.py:107-135): FIR design on the device, then the overlap-save convolution with
     // the level gain of stages.py:80-88 (a device scalar) folded into the filter spectra
     MGX_TRY(run_fir_design(h, cfg, tw, rw));

@@ -259,37 +259,48 @@ __device__ __forceinline__ void decide_loud(const double* sums, int divisions, l
     match = sqrt(red[17] / red[40]);
 }
 
-__global__ __launch_bounds__(1024) void k_levels(const double* wg_sumsq, const float* wg_peak,
-                                                 int chunks_per_piece, int divisions, long long piece,
-                                                 int is_reference, double threshold, double eps,
-                                                 TrackStats* st, double* rms, int* loud) {
+struct LevelsArgs {
+    const double* wg_sumsq;
+    const float* wg_peak;
+    int chunks_per_piece, divisions;
+    long long piece;
+    int is_reference;
+    TrackStats* st;
+    double* rms;
+    int* loud;
+};
+__device__ __forceinline__ void levels_body(const LevelsArgs& t, double threshold, double eps) {
     MGX_LDS;
     double* red = reinterpret_cast<double*>(mgx_smem);          // 64 doubles of reduction scratch
     double* sums = red + 64;                                     // [divisions]
     float* fred = reinterpret_cast<float*>(red + 52);
     float m = 0.f;
-    for (int w = threadIdx.x; w < divisions * chunks_per_piece; w += blockDim.x) m = fmaxf(m, wg_peak[w]);
+    for (int w = threadIdx.x; w < t.divisions * t.chunks_per_piece; w += blockDim.x) m = fmaxf(m, t.wg_peak[w]);
     const float pk = block_max<1024>(m, fred);
     if (threadIdx.x == 0) red[41] = (double)pk;
     __syncthreads();
     const double peak = red[41];
     double c = 1.0;
-    if (is_reference && peak < threshold) c = fmax(eps, peak / threshold);     // dsp.py:98-99
-    piece_sums_to_lds(wg_sumsq, chunks_per_piece, divisions, sums);
+    if (t.is_reference && peak < threshold) c = fmax(eps, peak / threshold);     // dsp.py:98-99
+    piece_sums_to_lds(t.wg_sumsq, t.chunks_per_piece, t.divisions, sums);
     double avg, match;
     int count;
-    decide_loud(sums, divisions, piece, 1.0 / c, red, rms, loud, avg, match, count);
+    decide_loud(sums, t.divisions, t.piece, 1.0 / c, red, t.rms, t.loud, avg, match, count);
     if (threadIdx.x == 0) {
         TrackStats s;
         s.peak = peak;
         s.amplitude_c = c;
         s.average_rms = avg;
         s.match_rms = match;
-        s.divisions = divisions;
+        s.divisions = t.divisions;
         s.loud_count = count;
-        s.piece = piece;
-        *st = s;
+        s.piece = t.piece;
+        *t.st = s;
     }
+}
+// one workgroup per track: grid = 1 (a single track) or 2 (target, reference)
+__global__ __launch_bounds__(1024) void k_levels(LevelsArgs t0, LevelsArgs t1, double threshold, double eps) {
+    levels_body(blockIdx.x == 0 ? t0 : t1, threshold, eps);
 }
 
 // mean over loud pieces and segments of |rfft|/F (match_frequencies.py:42), float64
@@ -298,25 +309,32 @@ __global__ __launch_bounds__(1024) void k_levels(const double* wg_sumsq, const f
 // part[z][plane][bins] (unscaled sums over the LOUD pieces' workgroups); the consumer adds
 // the SPEC_SLICES slices and applies spectrum_scale().
 constexpr int SPEC_SLICES = 8;
-__global__ __launch_bounds__(1024) void k_average_spectra(const float* wg_spec, const int* loud,
-                                                          int chunks_per_piece, int nwg, int bins, double* part) {
+struct SpectraArgs {
+    const float* wg_spec;
+    const int* loud;
+    int chunks_per_piece, nwg;
+    double* part;
+};
+// grid (bin tiles of 64, 2 planes, SPEC_SLICES * tracks)
+__global__ __launch_bounds__(1024) void k_average_spectra(SpectraArgs t0, SpectraArgs t1, int bins) {
     __shared__ double red[1024];
+    const SpectraArgs& t = blockIdx.z < SPEC_SLICES ? t0 : t1;
     const int bin = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
-    const int plane = blockIdx.y, z = blockIdx.z;
-    const int per = (nwg + SPEC_SLICES - 1) / SPEC_SLICES;
-    const int w0 = z * per, w1 = min(nwg, w0 + per);
+    const int plane = blockIdx.y, z = blockIdx.z % SPEC_SLICES;
+    const int per = (t.nwg + SPEC_SLICES - 1) / SPEC_SLICES;
+    const int w0 = z * per, w1 = min(t.nwg, w0 + per);
     double s = 0.0;
     if (bin < bins) {
         for (int w = w0 + lane; w < w1; w += 16)
-            if (loud[w / chunks_per_piece]) s += (double)wg_spec[((size_t)w * 2 + plane) * bins + bin];
+            if (t.loud[w / t.chunks_per_piece]) s += (double)t.wg_spec[((size_t)w * 2 + plane) * bins + bin];
     }
     red[threadIdx.x] = s;
     __syncthreads();
     if (lane == 0 && bin < bins) {
-        double t = 0.0;
+        double acc = 0.0;
 #pragma unroll
-        for (int l = 0; l < 16; ++l) t += red[l * 64 + (threadIdx.x & 63)];
-        part[((size_t)z * 2 + plane) * bins + bin] = t;
+        for (int l = 0; l < 16; ++l) acc += red[l * 64 + (threadIdx.x & 63)];
+        t.part[((size_t)z * 2 + plane) * bins + bin] = acc;
     }
 }
 __device__ __forceinline__ double spectrum_scale(const TrackStats* st, int segs_per_piece, int fft) {
@@ -383,25 +401,79 @@ __device__ __forceinline__ void fir_solve(const SplineTables& sp, const double* 
     FD::phase_closure(tid, sp, m);
     __syncthreads();
 }
-// raw curve -> spline onto the log grid.  grid = 2 (mid, side)
-__global__ __launch_bounds__(1024) void k_fir_a(FirPlanView pl, FirInputs in, double* scratch, double* c0_out) {
+// ---- the chain raw -> smooth as ONE dense operator ---------------------------------------------
+// For a given Config, smooth = M * raw with a fixed (bins x bins) float64 matrix: splines and
+// LOWESS (it = 0) are linear in their input and the pinned bins are rows of M.  M is built once
+// per plan ON THE DEVICE by pushing unit vectors through the very kernels above/below
+// (k_fir_unit_a, k_fir_lowess, k_fir_b, k_fir_gather); per pair the design is then k_fir_raw +
+// one 34 MB matrix-vector product for both channels (k_fir_matvec) instead of ~90 us of serial
+// single-workgroup scans.
+__global__ __launch_bounds__(1024) void k_fir_unit_a(FirPlanView pl, double* scratch, int col0) {
     MGX_LDS;
     Affine* sc = reinterpret_cast<Affine*>(mgx_smem);
     const int tid = threadIdx.x, plane = blockIdx.x;
     FirScratch s = fir_scratch(scratch, pl, plane);
-    const double c0 = in.st_r->match_rms / fmax(in.eps, in.st_t->match_rms);      // match_levels.py:106-111
-    if (plane == 0 && tid == 0) *c0_out = c0;
-    const double sc_t = spectrum_scale(in.st_t, in.segs_t, pl.fft) * c0;          // stages.py:90-91
-    const double sc_r = spectrum_scale(in.st_r, in.segs_r, pl.fft);
-    for (int k = tid; k < pl.bins; k += 1024) {
-        const double at = spectrum_at(in.part_t, plane, pl.bins, k) * sc_t;
-        const double ar = spectrum_at(in.part_r, plane, pl.bins, k) * sc_r;
-        s.raw[k] = ar / fmax(pl.min_value, at);                                   // match_frequencies.py:93-94
-    }
+    for (int k = tid; k < pl.bins; k += 1024) s.raw[k] = k == col0 + plane ? 1.0 : 0.0;
     __syncthreads();
     fir_solve(pl.s1, s.raw, s.m1, sc);
     FirDesign::phase_eval(tid, pl.s1, s.raw, s.m1, s.on_log);
 }
+// M[i][col0 + c] = smooth of unit vector col0 + c, bin i
+__global__ __launch_bounds__(256) void k_fir_gather(FirPlanView pl, double* scratch, int col0, int ncols, double* M) {
+    const int c = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (c >= ncols) return;
+    const FirScratch s = fir_scratch(scratch, pl, c);
+    M[(size_t)i * pl.bins + col0 + c] = s.smooth[i];
+}
+// raw matching curves of both channels (match_frequencies.py:93-94) + the level gain c0
+__global__ __launch_bounds__(256) void k_fir_raw(FirPlanView pl, FirInputs in, double* raw /* [2][bins] */,
+                                                 double* c0_out) {
+    const int k = blockIdx.x * 256 + threadIdx.x, plane = blockIdx.y;
+    const double c0 = in.st_r->match_rms / fmax(in.eps, in.st_t->match_rms);      // match_levels.py:106-111
+    if (plane == 0 && k == 0) *c0_out = c0;
+    if (k >= pl.bins) return;
+    const double sc_t = spectrum_scale(in.st_t, in.segs_t, pl.fft) * c0;          // stages.py:90-91
+    const double sc_r = spectrum_scale(in.st_r, in.segs_r, pl.fft);
+    const double at = spectrum_at(in.part_t, plane, pl.bins, k) * sc_t;
+    const double ar = spectrum_at(in.part_r, plane, pl.bins, k) * sc_r;
+    raw[(size_t)plane * pl.bins + k] = ar / fmax(pl.min_value, at);
+}
+// smooth[plane][i] = sum_j M[i][j] raw[plane][j]: one 256-thread workgroup per row, both channels per
+// pass over the row, every load of the row in flight at once (bins <= 256 * MATVEC_PER_THREAD)
+__global__ __launch_bounds__(256) void k_fir_matvec(FirPlanView pl, const double* M, const double* raw,
+                                                    double* scratch) {
+    __shared__ double red[2][4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const double* m = M + (size_t)row * pl.bins;
+    const double* r0 = raw;
+    const double* r1 = raw + pl.bins;
+    double a0 = 0.0, a1 = 0.0;
+    for (int j0 = tid; j0 < pl.bins; j0 += 256 * 10) {
+        double v[10];
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const int j = j0 + 256 * u;
+            v[u] = j < pl.bins ? m[j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 10; ++u) {
+            const int j = j0 + 256 * u;
+            if (j < pl.bins) {
+                a0 = fma(v[u], r0[j], a0);
+                a1 = fma(v[u], r1[j], a1);
+            }
+        }
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = a0; red[1][tid >> 6] = a1; }
+    __syncthreads();
+    if (tid == 0) {
+        fir_scratch(scratch, pl, 0).smooth[row] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        fir_scratch(scratch, pl, 1).smooth[row] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+
 // LOWESS regressions: one wave per anchor.  grid = (ceil(anchors/16), 2)
 __global__ __launch_bounds__(1024) void k_fir_lowess(FirPlanView pl, double* scratch) {
     const int plane = blockIdx.y;
