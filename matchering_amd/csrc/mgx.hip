@@ -73,7 +73,7 @@ struct mgx_handle {
     std::map<int, float2*> twiddles;
     TrackWork track[2];
     DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars;
-    DevBuf lim_published, lim_ctrl, lim_weights;
+    DevBuf lim_published, lim_ctrl, lim_weights, round_ctr;
     std::vector<double> lim_weights_host;
     DevBuf fir_scratch;
     std::map<const FirPlanHost*, PlanDev> plan_dev;               // uploaded plan blobs + dense operators
@@ -111,6 +111,10 @@ static int ensure_pinned(mgx_handle* h, size_t bytes) {
     return 0;
 }
 
+// control words shared by the kernels that count arrivals: [0] limiter ticket, [1] limiter error flag,
+// [4] correction-round arrivals.  Zeroed when allocated; every user leaves its word at zero.
+static int ensure_ctrl(mgx_handle* h);
+
 static int get_twiddles(mgx_handle* h, int log2n, const float2** out) {
     auto it = h->twiddles.find(log2n);
     if (it != h->twiddles.end()) {
@@ -135,6 +139,13 @@ static int allow_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+static int ensure_ctrl(mgx_handle* h) {
+    if (h->lim_ctrl.p) return 0;
+    MGX_TRY(ensure(h, h->lim_ctrl, 64));
+    HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 64, h->stream));
     return 0;
 }
 
@@ -306,8 +317,9 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     in.eps = cfg->min_value;
     double* scratch = (double*)h->fir_scratch.p;
     double* raw = scratch + 2 * per;
+    MGX_TRY(ensure(h, h->cstate, sizeof(CorrectionState)));
     hipLaunchKernelGGL(k_fir_raw, dim3((pl.bins + 255) / 256, 2), dim3(256), 0, h->stream, pl, in, raw,
-                       (double*)h->scalars.p);
+                       (double*)h->scalars.p, (CorrectionState*)h->cstate.p);
     hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
                        (const double*)raw, scratch);
     const size_t lds_taps = ((size_t)pl.fft + pl.bins + 1024) * sizeof(double);
@@ -418,12 +430,12 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     // published words preset to "unpublished", ticket and error zeroed, every launch
     const size_t pub_bytes = (size_t)3 * a.nchunks * sizeof(unsigned long long);
     MGX_TRY(ensure(h, h->lim_published, pub_bytes));
-    MGX_TRY(ensure(h, h->lim_ctrl, 64));
+    MGX_TRY(ensure_ctrl(h));
     a.published = (unsigned long long*)h->lim_published.p;
     a.ticket = (int*)h->lim_ctrl.p;
     a.error = a.ticket + 1;
     HIP_TRY(hipMemsetAsync(h->lim_published.p, 0xff, pub_bytes, h->stream));
-    HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 8, h->stream));       // ticket only: a raised error sticks
+    HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 4, h->stream));       // ticket only: a raised error sticks
     const size_t lds = Limiter2Block::LDS_BYTES;
     MGX_TRY(allow_lds(k_limit, lds));
     hipLaunchKernelGGL(k_limit, dim3((unsigned)a.nchunks), dim3(Limiter2Block::T), lds, h->stream, a);
@@ -509,7 +521,7 @@ int mgx_destroy(mgx_handle* h) {
     hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
-                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch};
+                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch, &h->round_ctr};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (TrackWork& w : h->track) {
@@ -751,21 +763,39 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     long long nblocks = 0;
     MGX_TRY(run_conv(h, target_dev, n_target, f, (const float*)h->taps.p, 1.0, (float*)h->y.p, (float*)h->mid.p,
                      &nblocks, 1, (const double*)h->scalars.p));
-    // stage 3 (stages.py:138-170): scalar feedback stays on the device
-    MGX_TRY(ensure(h, h->cstate, sizeof(CorrectionState)));
+    // stage 3 (stages.py:138-170): scalar feedback stays on the device; one launch per round, the last
+    // round also derives the peak / early-out / normalisation scalars (the state was reset by k_fir_raw)
     CorrectionState* cs = (CorrectionState*)h->cstate.p;
-    hipLaunchKernelGGL(k_correction_init, dim3(1), dim3(1), 0, h->stream, cs, 1.0);
-    const double* ref_match = &((const TrackStats*)rw.stats.p)->match_rms;
-    const size_t lds_step = (size_t)(64 + tw.divisions) * sizeof(double);
-    for (int step = 0; step < cfg->rms_correction_steps; ++step) {
-        int chunks = 0;
-        MGX_TRY(run_clipped_sumsq(h, (const float*)h->mid.p, tw.piece, tw.divisions, &cs->gain, 1.0, &chunks));
-        hipLaunchKernelGGL(k_correction_step, dim3(1), dim3(1024), lds_step, h->stream, (const double*)h->partial.p,
-                           chunks, tw.divisions, tw.piece, ref_match, cfg->min_value, cs);
+    {
+        RoundArgs ra;
+        ra.mid = (const float*)h->mid.p;
+        ra.piece = tw.piece;
+        ra.divisions = tw.divisions;
+        ra.chunks = std::max(1, 1024 / tw.divisions);        // ~1000 workgroups: each pays one publish + ticket
+        MGX_TRY(ensure(h, h->partial, (size_t)ra.divisions * ra.chunks * sizeof(double)));
+        ra.partial = (double*)h->partial.p;
+        const size_t ctr_bytes = (size_t)(1 + ra.divisions) * sizeof(unsigned);
+        if (h->round_ctr.bytes < ctr_bytes) {                 // zeroed when (re)allocated, reset by each launch
+            MGX_TRY(ensure(h, h->round_ctr, std::max(ctr_bytes, (size_t)4096)));
+            HIP_TRY(hipMemsetAsync(h->round_ctr.p, 0, h->round_ctr.bytes, h->stream));
+        }
+        ra.arrivals = (unsigned*)h->round_ctr.p;
+        ra.reference_match_rms = &((const TrackStats*)rw.stats.p)->match_rms;
+        ra.eps = cfg->min_value;
+        ra.threshold = cfg->threshold;
+        ra.cs = cs;
+        ra.npeaks = nblocks;
+        const size_t lds_step = (size_t)(64 + tw.divisions + (size_t)ra.divisions * ra.chunks) * sizeof(double);
+        const int rounds = cfg->rms_correction_steps;
+        for (int step = 0; step < rounds; ++step) {
+            ra.final_peaks = step == rounds - 1 ? (const float*)h->block_peak.p : nullptr;
+            hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, ra);
+        }
+        if (rounds == 0)
+            hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, h->stream, (const float*)h->block_peak.p,
+                               nblocks, cfg->threshold, cfg->min_value, cs);
+        HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, h->stream, (const float*)h->block_peak.p, nblocks,
-                       cfg->threshold, cfg->min_value, cs);
-    HIP_TRY(hipGetLastError());
     // stage 4 (stages.py:173-207)
     if (result_no_limiter_dev || result_no_limiter_normalized_dev) {
         const unsigned grid = (unsigned)std::min<long long>((n_target + 255) / 256, 8192);

@@ -228,6 +228,7 @@ __device__ __forceinline__ void piece_sums_to_lds(const double* partial, int chu
     __syncthreads();
 }
 // returns (on every thread) average rms, match rms and the loud count; optionally stores rms/loud
+template <int THREADS>
 __device__ __forceinline__ void decide_loud(const double* sums, int divisions, long long piece, double inv_c,
                                             double* red, double* rms_out, int* loud_out, double& avg,
                                             double& match, int& count) {
@@ -236,7 +237,7 @@ __device__ __forceinline__ void decide_loud(const double* sums, int divisions, l
         const double r = sqrt(sums[d] / (double)piece) * inv_c;
         acc += r * r;
     }
-    double tot = block_sum<1024>(acc, red);
+    double tot = block_sum<THREADS>(acc, red);
     if (threadIdx.x == 0) red[16] = sqrt(tot / divisions);
     __syncthreads();
     avg = red[16];
@@ -249,10 +250,10 @@ __device__ __forceinline__ void decide_loud(const double* sums, int divisions, l
         if (loud_out) loud_out[d] = l ? 1 : 0;
     }
     __syncthreads();
-    tot = block_sum<1024>(lacc, red);
+    tot = block_sum<THREADS>(lacc, red);
     if (threadIdx.x == 0) red[17] = tot;
     __syncthreads();
-    const double cnt = block_sum<1024>(lcnt, red + 18);
+    const double cnt = block_sum<THREADS>(lcnt, red + 18);
     if (threadIdx.x == 0) red[40] = cnt;
     __syncthreads();
     count = (int)red[40];
@@ -285,7 +286,7 @@ __device__ __forceinline__ void levels_body(const LevelsArgs& t, double threshol
     piece_sums_to_lds(t.wg_sumsq, t.chunks_per_piece, t.divisions, sums);
     double avg, match;
     int count;
-    decide_loud(sums, t.divisions, t.piece, 1.0 / c, red, t.rms, t.loud, avg, match, count);
+    decide_loud<1024>(sums, t.divisions, t.piece, 1.0 / c, red, t.rms, t.loud, avg, match, count);
     if (threadIdx.x == 0) {
         TrackStats s;
         s.peak = peak;
@@ -426,11 +427,16 @@ __global__ __launch_bounds__(256) void k_fir_gather(FirPlanView pl, double* scra
     M[(size_t)i * pl.bins + col0 + c] = s.smooth[i];
 }
 // raw matching curves of both channels (match_frequencies.py:93-94) + the level gain c0
+struct CorrectionState;
+__device__ void correction_reset(CorrectionState* cs, double gain);
 __global__ __launch_bounds__(256) void k_fir_raw(FirPlanView pl, FirInputs in, double* raw /* [2][bins] */,
-                                                 double* c0_out) {
+                                                 double* c0_out, CorrectionState* cs_init) {
     const int k = blockIdx.x * 256 + threadIdx.x, plane = blockIdx.y;
     const double c0 = in.st_r->match_rms / fmax(in.eps, in.st_t->match_rms);      // match_levels.py:106-111
-    if (plane == 0 && k == 0) *c0_out = c0;
+    if (plane == 0 && k == 0) {
+        *c0_out = c0;
+        if (cs_init) correction_reset(cs_init, 1.0);       // stages.py:138-170 starts from gain 1
+    }
     if (k >= pl.bins) return;
     const double sc_t = spectrum_scale(in.st_t, in.segs_t, pl.fft) * c0;          // stages.py:90-91
     const double sc_r = spectrum_scale(in.st_r, in.segs_r, pl.fft);
@@ -586,7 +592,7 @@ __global__ __launch_bounds__(1024) void k_correction_step(const double* partial,
     piece_sums_to_lds(partial, chunks, divisions, sums);
     double avg, match;
     int count;
-    decide_loud(sums, divisions, piece, 1.0, red, nullptr, nullptr, avg, match, count);
+    decide_loud<1024>(sums, divisions, piece, 1.0, red, nullptr, nullptr, avg, match, count);
     if (threadIdx.x == 0) {
         const double c = *reference_match_rms / fmax(eps, match);      // match_levels.py:106-111
         cs->coeffs[cs->steps_done] = c;
@@ -595,15 +601,130 @@ __global__ __launch_bounds__(1024) void k_correction_step(const double* partial,
     }
 }
 
-__global__ void k_correction_init(CorrectionState* cs, double gain) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        cs->gain = gain;
-        cs->steps_done = 0;
-        cs->result_peak = 0.0;
-        cs->normalize_c = 1.0;
-        cs->limiter_active = 1;
-        for (int i = 0; i < 16; ++i) cs->coeffs[i] = 0.0;
+// One round of stages.py:149-168 in ONE launch: every workgroup sums its chunk of
+// clip(gain*mid)^2, and the workgroup that arrives last at the ticket counter takes the decision
+// (loud pieces, coefficient, accumulated gain) -- split-K style "last arriver combines"
+// (MI355X_MICROARCH.md, fanin / splitk-seam): partials are published write-through (sc1) and drained
+// before the ticket, the last arriver acquires before reading them.  With `final_peaks` the same
+// workgroup also derives the peak / limiter early-out / normalisation scalars (k_finalize_scalars).
+struct RoundArgs {
+    const float* mid;
+    long long piece;
+    int chunks, divisions;
+    double* partial;            // [divisions][chunks]
+    unsigned* arrivals;         // [1 + divisions] counters, zero between launches: [0] pieces done, [1+d] chunks of piece d
+    const double* reference_match_rms;
+    double eps, threshold;
+    CorrectionState* cs;
+    const float* final_peaks;   // per-pair peaks of the convolution, or null
+    long long npeaks;
+};
+__global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
+    MGX_LDS;
+    double* red = reinterpret_cast<double*>(mgx_smem);          // 64 doubles of scratch
+    double* sums = red + 64;                                     // [divisions]
+    __shared__ int is_last;
+    const int d = blockIdx.x / a.chunks, ch = blockIdx.x % a.chunks;
+    const long long len = (a.piece + a.chunks - 1) / a.chunks;
+    const long long b = (long long)d * a.piece + ch * len;
+    const long long e = min((long long)(d + 1) * a.piece, b + len);
+    const double g = a.cs->gain;
+    double acc = 0.0;
+    // float64 product then clip: the reference clips the float64 mid (dsp.py:109-110)
+    auto add = [&](float v) {
+        const double c = fmin(fmax((double)v * g, -1.0), 1.0);
+        acc = fma(c, c, acc);
+    };
+    // scalar head up to a 16-byte boundary, float4 body (64 B per thread in flight), scalar tail
+    const long long head = min(e, (b + 3) & ~3ll);
+    if (b + threadIdx.x < head) add(a.mid[b + threadIdx.x]);
+    const long long body_end = head + ((e - head) & ~3ll);
+    long long i = head + 4ll * threadIdx.x;
+    for (; i + 3 * 1024 < body_end; i += 4 * 1024) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(a.mid + i + u * 1024);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { add(v[u].x); add(v[u].y); add(v[u].z); add(v[u].w); }
     }
+    for (; i < body_end; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(a.mid + i);
+        add(v.x); add(v.y); add(v.z); add(v.w);
+    }
+    if (body_end + threadIdx.x < e) add(a.mid[body_end + threadIdx.x]);
+    const double s = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) {
+        // write-through 8-byte store + drained vmcnt instead of a release fence (a fence per workgroup
+        // would write back the XCD's whole L2 two thousand times)
+        __hip_atomic_store(a.partial + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // two-level arrival count (one word takes ~88 atomics per microsecond; 2048 workgroups on a
+        // single word would cost more than the sums themselves)
+        is_last = 0;
+        if (atomicAdd(a.arrivals + 1 + d, 1u) == (unsigned)a.chunks - 1) {
+            a.arrivals[1 + d] = 0;                                         // ready for the next launch
+            is_last = atomicAdd(a.arrivals, 1u) == (unsigned)a.divisions - 1;
+        }
+        if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // The last arriver is alone and every load below is a cold miss: issue them in batches of
+    // eight per thread, stage the partials in LDS, then sum each piece's chunks from there.
+    double* stage = sums + a.divisions;                          // [divisions * chunks]
+    const int total = a.divisions * a.chunks;
+    for (int k0 = threadIdx.x; k0 < total; k0 += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = k0 + 256 * u < total ? a.partial[k0 + 256 * u] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 256 * u < total) stage[k0 + 256 * u] = v[u];
+    }
+    __shared__ float fscratch[4];
+    float m = 0.f;
+    if (a.final_peaks) {
+        for (long long k0 = threadIdx.x; k0 < a.npeaks; k0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = k0 + 256 * u < a.npeaks ? a.final_peaks[k0 + 256 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+        }
+    }
+    __syncthreads();
+    piece_sums_to_lds(stage, a.chunks, a.divisions, sums);
+    double avg, match;
+    int count;
+    decide_loud<256>(sums, a.divisions, a.piece, 1.0, red, nullptr, nullptr, avg, match, count);
+    const float pk = block_max<256>(m, fscratch);
+    if (threadIdx.x == 0) {
+        const double c = *a.reference_match_rms / fmax(a.eps, match);      // match_levels.py:106-111
+        CorrectionState* cs = a.cs;
+        cs->coeffs[cs->steps_done] = c;
+        cs->steps_done += 1;
+        cs->gain *= c;
+        if (a.final_peaks) {
+            const double peak = (double)(float)((double)pk * cs->gain);      // max |float32(y*gain)|
+            cs->result_peak = peak;
+            const double rect = fmax(peak, a.threshold) / a.threshold;
+            cs->limiter_active = fabs(rect - 1.0) > (1e-8 + 1e-5) ? 1 : 0;   // numpy.isclose defaults, hyrax.py:83
+            cs->normalize_c = fmax(a.eps, peak / a.threshold);               // dsp.py:93-100
+        }
+        *a.arrivals = 0;                                                     // ready for the next launch
+    }
+}
+
+__device__ void correction_reset(CorrectionState* cs, double gain) {
+    cs->gain = gain;
+    cs->steps_done = 0;
+    cs->result_peak = 0.0;
+    cs->normalize_c = 1.0;
+    cs->limiter_active = 1;
+    for (int i = 0; i < 16; ++i) cs->coeffs[i] = 0.0;
+}
+__global__ void k_correction_init(CorrectionState* cs, double gain) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) correction_reset(cs, gain);
 }
 
 // peak of the corrected result, limiter early-out decision (hyrax.py:83-85 with numpy.isclose
