@@ -124,19 +124,26 @@ struct Conv2Block {
     }
 
     // ---- phase FPI: last forward pass, times H, first inverse pass, on the thread's row -------
-    static MGX_HD void phase_filter(int tid, const float2* h, float2* lds) {
+    // The filter spectrum of the row is fetched one phase early (before the middle pass and its
+    // barrier) so that its L2 latency is covered by that pass.
+    struct RowFilter {
+        float2 h[RL];
+    };
+    static MGX_HD void fetch_filter(int tid, const float2* h, RowFilter& f) {
         if (!F::has_row(tid)) return;
-        float2 hq[RL];
         const MemView hv = mem_view(h, (long long)N * 8);
         MGX_UNROLL
-        for (int q = 0; q < RL; ++q) hq[q] = ld_f2(hv, (unsigned)tid * 8u, (unsigned)(q * F::L * 8));
+        for (int q = 0; q < RL; ++q) f.h[q] = ld_f2(hv, (unsigned)tid * 8u, (unsigned)(q * F::L * 8));
+    }
+    static MGX_HD void phase_filter(int tid, const RowFilter& f, float2* lds) {
+        if (!F::has_row(tid)) return;
         float2 v[RL];
         F::load_row(v, tid, lds);
         dft_regs<RL, false>(v);
         MGX_UNROLL
         for (int q = 0; q < RL; ++q) {
             const int i = bitrev(q, F::lr(F::LAST));
-            v[i] = cmul(v[i], hq[q]);
+            v[i] = cmul(v[i], f.h[q]);
         }
         dft_regs<RL, true>(v);
         F::store_row(v, tid, lds);

@@ -168,6 +168,20 @@ static int check_config(const mgx_config* c) {
 // ---------------------------------------------------------------------------
 // stage runners (asynchronous on h->stream)
 // ---------------------------------------------------------------------------
+// workgroups of k_analyze<log2f> one CU holds (LDS and wave slots)
+static int analysis_workgroups_per_cu(int log2f) {
+    size_t lds = 0;
+    int threads = 64;
+    switch (log2f) {
+#define CASE(L) case L: lds = analysis_lds_bytes<L>(); threads = Fft2<L>::T; break;
+        CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
+#undef CASE
+        default: return 1;
+    }
+    const int by_lds = (int)((size_t)160 * 1024 / lds), by_waves = 2048 / threads;
+    return std::max(1, std::min(8, std::min(by_lds, by_waves)));
+}
+
 template <int LOG2N>
 static int launch_analysis(mgx_handle* h, const AnalysisArgs& a, int nwg) {
     const size_t lds = analysis_lds_bytes<LOG2N>();
@@ -185,7 +199,12 @@ static int run_analysis(mgx_handle* h, const float* x, long long n, const mgx_co
     w.segs_per_piece = (int)(w.piece / f);
     if (w.segs_per_piece < 1)
         return fail(MGX_ERR_UNSUPPORTED, "analysis pieces shorter than fft_size are not implemented");
-    const int want_chunks = std::min(w.segs_per_piece, std::max(1, (1536 + w.divisions - 1) / w.divisions));
+    // One workgroup per resident slot at most: a second dispatch wave of a few stragglers would double
+    // the kernel's duration (every workgroup runs segs_per_wg segments back to back).
+    int dev_cus = 256;
+    HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    const int slots = dev_cus * analysis_workgroups_per_cu(ilog2_exact(f));
+    const int want_chunks = std::min(w.segs_per_piece, std::max(1, slots / w.divisions));
     w.segs_per_wg = (w.segs_per_piece + want_chunks - 1) / want_chunks;
     w.chunks = (w.segs_per_piece + w.segs_per_wg - 1) / w.segs_per_wg;
     const int nwg = w.divisions * w.chunks;

@@ -68,13 +68,15 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2A
     using F = Fft2<LOG2N>;
     const bool edge = !CB::interior(pair, a.n);
     typename CB::Kept kept;
+    typename CB::RowFilter rf;
     CB::template phase_load<false>(tid, pair, edge, a, ps, lds);
+    CB::fetch_filter(tid, a.h_mid, rf);
     __syncthreads();
     if (F::P == 3) {
         CB::phase_fwd_mid(tid, lds, mid_table);
         __syncthreads();
     }
-    CB::phase_filter(tid, a.h_mid, lds);
+    CB::phase_filter(tid, rf, lds);
     __syncthreads();
     if (F::P == 3) {
         CB::phase_inv_mid(tid, lds, mid_table);
@@ -83,12 +85,13 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2A
     CB::phase_keep_mid(tid, ps, lds, kept);
     __syncthreads();
     CB::template phase_load<true>(tid, pair, edge, a, ps, lds);
+    CB::fetch_filter(tid, a.h_side, rf);
     __syncthreads();
     if (F::P == 3) {
         CB::phase_fwd_mid(tid, lds, mid_table);
         __syncthreads();
     }
-    CB::phase_filter(tid, a.h_side, lds);
+    CB::phase_filter(tid, rf, lds);
     __syncthreads();
     if (F::P == 3) {
         CB::phase_inv_mid(tid, lds, mid_table);

@@ -61,12 +61,12 @@ static int conv_impl(const float* x, long long n, const double* fir_mid, const d
         const bool edge = !CB::interior(pair, n);
         FOR_THREADS(F::T) CB::template phase_load<false>(tid, pair, edge, a, ps[tid], lds.data());
         FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
-        FOR_THREADS(F::T) CB::phase_filter(tid, a.h_mid, lds.data());
+        FOR_THREADS(F::T) { typename CB::RowFilter rf; CB::fetch_filter(tid, a.h_mid, rf); CB::phase_filter(tid, rf, lds.data()); }
         FOR_THREADS(F::T) CB::phase_inv_mid(tid, lds.data(), mid_table.data());
         FOR_THREADS(F::T) CB::phase_keep_mid(tid, ps[tid], lds.data(), kept[tid]);
         FOR_THREADS(F::T) CB::template phase_load<true>(tid, pair, edge, a, ps[tid], lds.data());
         FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
-        FOR_THREADS(F::T) CB::phase_filter(tid, a.h_side, lds.data());
+        FOR_THREADS(F::T) { typename CB::RowFilter rf; CB::fetch_filter(tid, a.h_side, rf); CB::phase_filter(tid, rf, lds.data()); }
         FOR_THREADS(F::T) CB::phase_inv_mid(tid, lds.data(), mid_table.data());
         FOR_THREADS(F::T) pk = std::fmax(pk, CB::phase_store(tid, pair, edge, a, ps[tid], lds.data(), kept[tid]));
     }
