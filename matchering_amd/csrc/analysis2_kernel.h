@@ -64,7 +64,6 @@ struct Analysis2Block {
         float peak;
         float acc_mid[RL / 2 + 1];     // magnitudes of bins (row, q < RL/2); [RL/2]: bin F/2 on thread 0
         float acc_side[RL / 2 + 1];
-        float2 z[RL / 2 + 1];          // those bins of the current segment
     };
 
     static MGX_HD bool active0(int tid) { return !F::partial(0) || tid < F::NB(0); }
@@ -84,18 +83,32 @@ struct Analysis2Block {
         s = m - lr.y;                  // dsp.py:62
     }
 
-    // segment starting at frame `start` (always fully inside the track)
-    static MGX_HD void phase_load(int tid, long long start, const AnalysisArgs& a, const Persist& ps,
-                                  Thread& t, float2* lds) {
+    // frames of one segment as a thread needs them for pass 0 (segments always lie inside the track)
+    struct Raw {
+        float2 f[CNT0][R0];
+    };
+    static MGX_HD void fetch(int tid, long long start, const AnalysisArgs& a, Raw& r) {
         if (!active0(tid)) return;
+        const MemView src = mem_view(a.x, a.n * 8);
         MGX_UNROLL
         for (int c = 0; c < CNT0; ++c) {
-            const int u = tid + c * T;
+            const unsigned lane = ((unsigned)start + (unsigned)(tid + c * T)) * 8u;
+            MGX_UNROLL
+            for (int j = 0; j < R0; ++j) r.f[c][j] = ld_f2(src, lane, (unsigned)(j * S0 * 8));
+        }
+    }
+    // mid/side, level statistics, pass 0 -> LDS
+    static MGX_HD void phase_load(int tid, const Raw& r, const Persist& ps, Thread& t, float2* lds) {
+        if (!active0(tid)) return;
+        typename F::Tw0Full tw;
+        F::expand_tw0(ps.tw0, tw);
+        MGX_UNROLL
+        for (int c = 0; c < CNT0; ++c) {
             float2 v[R0];
             float ss = 0.f;
             MGX_UNROLL
             for (int j = 0; j < R0; ++j) {
-                const float2 lr = a.x[start + u + (long long)j * S0];
+                const float2 lr = r.f[c][j];
                 float m, s;
                 to_ms(lr, m, s);
                 v[j] = make_float2(m, s);
@@ -103,16 +116,13 @@ struct Analysis2Block {
                 t.peak = fmaxf(t.peak, fmaxf(fabsf(lr.x), fabsf(lr.y)));
             }
             t.sumsq += (double)ss;
-            F::fwd0_store(v, tid, c, ps.tw0, lds);
+            F::fwd0_store(v, tid, c, tw, lds);
         }
     }
     static MGX_HD void phase_fwd_mid(int tid, float2* lds, const float2* mid_table) {
         if (F::P == 3) F::fwd_mid(tid, lds, mid_table);
     }
-    // last forward pass on the thread's row; bins go back to LDS in position order.  Row 0 holds
-    // its own mirror bins, (0,q) <-> (0,(RL-q)%RL); thread 0 therefore stores its row rotated by
-    // one so that the uniform rule "mirror of (row,q) sits at (mirror_row, RL-1-q)" also covers
-    // it (nobody else reads row 0).
+    // last forward pass on the thread's row; bins go back to LDS in position order
     static MGX_HD void phase_row(int tid, Thread& t, float2* lds) {
         if (!F::has_row(tid)) return;
         float2 v[RL], w[RL];
@@ -120,33 +130,31 @@ struct Analysis2Block {
         dft_regs<RL, false>(v);
         MGX_UNROLL
         for (int q = 0; q < RL; ++q) w[q] = v[bitrev(q, F::lr(F::LAST))];
-        MGX_UNROLL
-        for (int q = 0; q <= RL / 2; ++q) t.z[q] = w[q];
-        const bool r0 = tid == 0;
-        MGX_UNROLL
-        for (int e = 0; e < RL; ++e) {
-            const float2 a = w[e], b = w[(e + 1) % RL];
-            v[e] = make_float2(r0 ? b.x : a.x, r0 ? b.y : a.y);
-        }
-        F::store_row(v, tid, lds);
+        F::store_row(w, tid, lds);
     }
-    // mirror bins -> magnitudes
+    // own lower half + mirror row's upper half -> magnitudes.  Bin (row, q) mirrors to
+    // (mirror_row, RL-1-q); row 0 mirrors into itself, (0, q) <-> (0, (RL-q) % RL), i.e. one
+    // element further up, with bins 0 and F/2 their own mirrors.
     static MGX_HD void phase_magnitudes(int tid, Thread& t, const float2* lds) {
         if (!F::has_row(tid)) return;
-        float2 m[RL / 2];                                   // mirror row, elements RL/2 .. RL-1
-        F::template load_row_part<RL / 2, RL / 2>(m, F::mirror_row(tid), lds);
+        float2 z[RL / 2 + 2], m[RL / 2];
+        F::template load_row_part<0, RL / 2 + 2>(z, tid, lds);                  // own bins 0 .. RL/2 (+1 unused)
+        F::template load_row_part<RL / 2, RL / 2>(m, F::mirror_row(tid), lds);  // mirror row, elements RL/2 .. RL-1
+        const bool r0 = tid == 0;
         MGX_UNROLL
         for (int q = 0; q < RL / 2; ++q) {
-            const float2 z = t.z[q], zm = m[RL / 2 - 1 - q];      // = mirror element RL-1-q
+            const float2 a = m[RL / 2 - 1 - q];                                  // element RL-1-q
+            const float2 b = q == 0 ? z[0] : m[RL / 2 - q];                      // element (RL-q) % RL of row 0
+            const float2 zm = make_float2(r0 ? b.x : a.x, r0 ? b.y : a.y);
             // M = (Z + conj Zm)/2, S = (Z - conj Zm)/(2j): |.| only
-            const float mx = z.x + zm.x, my = z.y - zm.y;
-            const float sx = z.x - zm.x, sy = z.y + zm.y;
+            const float mx = z[q].x + zm.x, my = z[q].y - zm.y;
+            const float sx = z[q].x - zm.x, sy = z[q].y + zm.y;
             t.acc_mid[q] += 0.5f * fast_sqrt(fmaf(mx, mx, my * my));
             t.acc_side[q] += 0.5f * fast_sqrt(fmaf(sx, sx, sy * sy));
         }
         // bin F/2 mirrors into itself: M = Re Z, S = Im Z (meaningful on thread 0 only)
-        t.acc_mid[RL / 2] += fabsf(t.z[RL / 2].x);
-        t.acc_side[RL / 2] += fabsf(t.z[RL / 2].y);
+        t.acc_mid[RL / 2] += fabsf(z[RL / 2].x);
+        t.acc_side[RL / 2] += fabsf(z[RL / 2].y);
     }
 
     // frames outside whole segments: RMS (optional) and peak only

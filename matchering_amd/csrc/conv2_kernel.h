@@ -83,6 +83,8 @@ struct Conv2Block {
                                   float2* lds) {
         if (!active0(tid)) return;
         const long long i0 = first_input(pair);
+        typename F::Tw0Full tw;
+        F::expand_tw0(ps.tw0, tw);
         MGX_UNROLL
         for (int c = 0; c < CNT0; ++c) {
             const int u = tid + c * T;
@@ -111,7 +113,7 @@ struct Conv2Block {
             float2 v[R0];
             MGX_UNROLL
             for (int j = 0; j < R0; ++j) v[j] = make_float2(ch[j], ch[j + HALF]);
-            F::fwd0_store(v, tid, c, ps.tw0, lds);
+            F::fwd0_store(v, tid, c, tw, lds);
         }
     }
 
@@ -152,10 +154,12 @@ struct Conv2Block {
     // ---- phase I0 (mid channel): inverse pass 0, keep the valid half in registers --------------
     static MGX_HD void phase_keep_mid(int tid, const Persist& ps, const float2* lds, Kept& k) {
         if (!active0(tid)) return;
+        typename F::Tw0Full tw;
+        F::expand_tw0(ps.tw0, tw);
         MGX_UNROLL
         for (int c = 0; c < CNT0; ++c) {
             float2 v[R0];
-            F::inv0_load(v, tid, c, ps.tw0, lds);
+            F::inv0_load(v, tid, c, tw, lds);
             MGX_UNROLL
             for (int j = 0; j < HALF; ++j) k.v[c][j] = v[HALF + j];
         }
@@ -168,11 +172,13 @@ struct Conv2Block {
         float peak = 0.f;
         if (!active0(tid)) return peak;
         const long long o0 = first_output(pair);
+        typename F::Tw0Full tw;
+        F::expand_tw0(ps.tw0, tw);
         MGX_UNROLL
         for (int c = 0; c < CNT0; ++c) {
             const int u = tid + c * T;
             float2 v[R0];
-            F::inv0_load(v, tid, c, ps.tw0, lds);
+            F::inv0_load(v, tid, c, tw, lds);
             float2 ya[HALF], yb[HALF];
             MGX_UNROLL
             for (int j = 0; j < HALF; ++j) {
@@ -224,6 +230,8 @@ struct Conv2Block {
     // taps[0..F) -> zero-extended, delayed by one sample -> pass 0 -> LDS
     static MGX_HD void phase_load_taps(int tid, const float* taps, const Persist& ps, float2* lds) {
         if (!active0(tid)) return;
+        typename F::Tw0Full tw;
+        F::expand_tw0(ps.tw0, tw);
         MGX_UNROLL
         for (int c = 0; c < CNT0; ++c) {
             const int u = tid + c * T;
@@ -235,7 +243,7 @@ struct Conv2Block {
                 const float t = taps[ok ? i - 1 : 0];             // unconditional load, then select
                 v[j] = make_float2(ok ? t : 0.f, 0.f);
             }
-            F::fwd0_store(v, tid, c, ps.tw0, lds);
+            F::fwd0_store(v, tid, c, tw, lds);
         }
     }
     // last pass of the filter transform -> table in the layout phase_filter reads

@@ -190,13 +190,28 @@ struct Fft2 {
     }
 
     // ---- twiddles ----------------------------------------------------------------------
-    // pass 0: w_N^(q*t), q = 1..R0-1, in registers (tw = table of exp(-2 pi i k / N))
+    // pass 0: w_N^(q*t), q = 1..R0-1.  Only the log2(R0) "base" powers w^(t*2^i) live in registers
+    // for the life of a workgroup (exact table values); a phase that needs the full set rebuilds the
+    // other R0-1-log2(R0) by products of depth <= log2(R0)-1 (11 complex multiplies for radix 16
+    // against a ~230-instruction butterfly), which keeps ~22 VGPRs free.
+    static constexpr int LB0 = Plan::LR[0];
     struct Tw0 {
+        float2 b[LB0];
+    };
+    struct Tw0Full {
         float2 w[R0 - 1];
     };
     static MGX_HD void load_tw0(int tid, const float2* tw, Tw0& t) {
         MGX_UNROLL
-        for (int q = 1; q < R0; ++q) t.w[q - 1] = tw[tw_index<0>(tid % S(0), q) & (N - 1)];
+        for (int i = 0; i < LB0; ++i) t.b[i] = tw[tw_index<0>(tid % S(0), 1 << i) & (N - 1)];
+    }
+    static MGX_HD void expand_tw0(const Tw0& t, Tw0Full& f) {
+        MGX_UNROLL
+        for (int q = 1; q < R0; ++q) {
+            int hb = 1;
+            while (hb * 2 <= q) hb *= 2;                       // highest set bit of q
+            f.w[q - 1] = q == hb ? t.b[ilog2(hb)] : cmul(t.b[ilog2(hb)], f.w[q - hb - 1]);
+        }
     }
     // middle pass (P == 3): (R1-1)*S1 entries in LDS, [q-1][n]
     static constexpr int MID = 1;
@@ -212,7 +227,7 @@ struct Fft2 {
 
     // ---- pass 0, forward: registers (natural order v[j] = x[u + j*S0]) -> LDS ----------------
     // c = which of the thread's CNT(0) butterflies (u = tid + c*T)
-    static MGX_HD void fwd0_store(float2 (&v)[R0], int tid, int c, const Tw0& t, float2* lds) {
+    static MGX_HD void fwd0_store(float2 (&v)[R0], int tid, int c, const Tw0Full& t, float2* lds) {
         constexpr int bits = lr(0);
         float2* p = lds + base<0>(tid + c * T);
         dft_regs<R0, false>(v);
@@ -228,7 +243,7 @@ struct Fft2 {
         }
     }
     // ---- pass 0, inverse: LDS -> registers (natural order v[j] = y[u + j*S0]) ----------------
-    static MGX_HD void inv0_load(float2 (&v)[R0], int tid, int c, const Tw0& t, const float2* lds) {
+    static MGX_HD void inv0_load(float2 (&v)[R0], int tid, int c, const Tw0Full& t, const float2* lds) {
         constexpr int bits = lr(0);
         const float2* p = lds + base<0>(tid + c * T);
         MGX_UNROLL

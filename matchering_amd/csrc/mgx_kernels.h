@@ -15,6 +15,10 @@ namespace mgx {
 
 #define MGX_LDS extern __shared__ __attribute__((aligned(16))) char mgx_smem[]
 
+// Workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight
+// (__syncthreads() would drain vmcnt as well and serialise a software prefetch).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, 2) void k_conv(Conv2Args a) {
         // from the thread id) should: hoisted out of this loop it would sit in VGPRs it does
         // not have.  An empty asm makes the values opaque per iteration.
 #pragma unroll
-        for (int q = 0; q < F::R0 - 1; ++q) asm volatile("" : "+v"(ps.tw0.w[q].x), "+v"(ps.tw0.w[q].y));
+        for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
         const float pk = conv_pair<LOG2N>(tid, pair, a, ps, lds, mid_table);
         const float bp = block_max<F::T>(pk, scratch);
         if (tid == 0 && a.pair_peak) a.pair_peak[pair] = bp;
@@ -189,17 +193,20 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
     const int s0 = ch * a.segs_per_wg;
     const int s1 = min(a.segs_per_piece, s0 + a.segs_per_wg);
     for (int s = s0; s < s1; ++s) {
-        const long long start = (long long)d * a.piece + (long long)s * F::N;
-        AB::phase_load(tid, start, a, ps, th, lds);
-        __syncthreads();
+        // (a software prefetch of the next segment was tried: at 128 VGPRs the 32 registers it pins
+        // spill, which stalls on the very loads it was meant to hide)
+        typename AB::Raw raw;
+        AB::fetch(tid, (long long)d * a.piece + (long long)s * F::N, a, raw);
+        AB::phase_load(tid, raw, ps, th, lds);
+        lds_barrier();
         if (F::P == 3) {
             AB::phase_fwd_mid(tid, lds, mid_table);
-            __syncthreads();
+            lds_barrier();
         }
         AB::phase_row(tid, th, lds);
-        __syncthreads();
+        lds_barrier();
         AB::phase_magnitudes(tid, th, lds);
-        __syncthreads();
+        lds_barrier();
     }
     if (ch == a.chunks_per_piece - 1) {
         AB::phase_loose_frames(tid, (long long)d * a.piece + (long long)a.segs_per_piece * F::N,

@@ -124,7 +124,7 @@ static int analyze_impl(const float* x, long long n, const mgx_config* cfg, int 
         const int s0 = ch * a.segs_per_wg, s1 = std::min(a.segs_per_piece, s0 + a.segs_per_wg);
         for (int s = s0; s < s1; ++s) {
             const long long start = d * piece + (long long)s * F::N;
-            FOR_THREADS(F::T) AB::phase_load(tid, start, a, ps[tid], th[tid], lds.data());
+            FOR_THREADS(F::T) { typename AB::Raw raw; AB::fetch(tid, start, a, raw); AB::phase_load(tid, raw, ps[tid], th[tid], lds.data()); }
             FOR_THREADS(F::T) AB::phase_fwd_mid(tid, lds.data(), mid_table.data());
             FOR_THREADS(F::T) AB::phase_row(tid, th[tid], lds.data());
             FOR_THREADS(F::T) AB::phase_magnitudes(tid, th[tid], lds.data());
