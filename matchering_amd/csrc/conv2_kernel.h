@@ -33,10 +33,11 @@ struct Conv2Args {
     long long n;           // frames
     float2* y;             // (n,2) interleaved L/R output frames
     float* ymid;           // (n,) mid of the output, or nullptr
-    const float2* h_mid;   // filter spectra, [RL][N/RL] (bin at position row*RL+q stored at q*L+row),
+    const float2* h_mid;   // filter spectra, [parts][RL][N/RL] (bin at position row*RL+q stored at q*L+row),
     const float2* h_side;  //   already scaled by gain/N
     const float2* tw;      // exp(-2 pi i k / N), k = 0..N-1
-    long long npairs;      // ceil(n / (2F))
+    int parts;             // filter partitions K: taps = K * N/2 (1 = plain overlap-save)
+    long long npairs;      // ceil(n / N)
     float* pair_peak;      // [npairs] max(|yL|,|yR|) per pair, or nullptr
 };
 
@@ -67,12 +68,19 @@ struct Conv2Block {
         F::fill_mid_table(tid, tw, mid_table);
     }
 
-    // frames of the pair: block A outputs [pair*2F, pair*2F + F), block B the next F
+    // Frames of the pair: block A outputs [pair*N, pair*N + P), block B the next P (P = N/2).
+    // With K filter partitions of P taps each (uniformly partitioned overlap-save: taps = K*P,
+    // y = sum_k h_k * x delayed by k*P), partition k reads the N + P frames starting at
+    //     pair*N + K*P/2 - (k+1)*P
+    // (scipy's "same" centring puts half of the filter into the future); K = 1 is the plain case.
     static MGX_HD long long first_output(long long pair) { return pair * (long long)N; }
-    static MGX_HD long long first_input(long long pair) { return pair * (long long)N - TAPS / 2; }
+    static MGX_HD long long first_input(long long pair, int parts = 1, int k = 0) {
+        return pair * (long long)N + (long long)parts * TAPS / 2 - (long long)(k + 1) * TAPS;
+    }
     // every frame the pair touches lies inside the track: no bounds checks needed
-    static MGX_HD bool interior(long long pair, long long n) {
-        return first_input(pair) >= 0 && first_input(pair) + N + TAPS <= n;
+    static MGX_HD bool interior(long long pair, long long n, int parts = 1) {
+        return first_input(pair, parts, parts - 1) >= 0 && first_input(pair, parts, 0) + N + TAPS <= n &&
+               first_output(pair) + N <= n;
     }
 
     // ---- phase F0: global -> registers -> pass 0 -> LDS, channel SIDE ? side : mid --------
@@ -80,9 +88,9 @@ struct Conv2Block {
     // bounds checks.
     template <bool SIDE>
     static MGX_HD void phase_load(int tid, long long pair, bool edge, const Conv2Args& a, const Persist& ps,
-                                  float2* lds) {
+                                  float2* lds, int part = 0) {
         if (!active0(tid)) return;
-        const long long i0 = first_input(pair);
+        const long long i0 = first_input(pair, a.parts, part);
         typename F::Tw0Full tw;
         F::expand_tw0(ps.tw0, tw);
         MGX_UNROLL
@@ -149,6 +157,32 @@ struct Conv2Block {
         }
         dft_regs<RL, true>(v);
         F::store_row(v, tid, lds);
+    }
+
+    // K > 1: the row's product is accumulated over the partitions (phase_accumulate once per
+    // partition, then phase_finish_row)
+    struct RowAcc {
+        float2 w[RL];
+    };
+    static MGX_HD void clear_acc(RowAcc& acc) {
+        MGX_UNROLL
+        for (int q = 0; q < RL; ++q) acc.w[q] = make_float2(0.f, 0.f);
+    }
+    static MGX_HD void phase_accumulate(int tid, const RowFilter& f, const float2* lds, RowAcc& acc) {
+        if (!F::has_row(tid)) return;
+        float2 v[RL];
+        F::load_row(v, tid, lds);
+        dft_regs<RL, false>(v);
+        MGX_UNROLL
+        for (int q = 0; q < RL; ++q) {
+            const int i = bitrev(q, F::lr(F::LAST));
+            acc.w[i] = cadd(acc.w[i], cmul(v[i], f.h[q]));
+        }
+    }
+    static MGX_HD void phase_finish_row(int tid, RowAcc& acc, float2* lds) {
+        if (!F::has_row(tid)) return;
+        dft_regs<RL, true>(acc.w);
+        F::store_row(acc.w, tid, lds);
     }
 
     // ---- phase I0 (mid channel): inverse pass 0, keep the valid half in registers --------------

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -153,9 +154,9 @@ static int check_config(const mgx_config* c) {
     if (!c) return fail(MGX_ERR_ARGUMENT, "config is null");
     if (c->internal_sample_rate <= 0) return fail(MGX_ERR_ARGUMENT, "internal_sample_rate must be positive");
     if (ilog2_exact(c->fft_size) < 0) return fail(MGX_ERR_ARGUMENT, "fft_size must be a power of two");
-    if (c->fft_size < 64 || c->fft_size > 8192)
-        return fail(MGX_ERR_UNSUPPORTED, "fft_size outside [64, 8192] is not implemented "
-                                         "(the overlap-save block 2*fft_size must fit one CU's LDS)");
+    if (c->fft_size < 64 || c->fft_size > 16384)
+        return fail(MGX_ERR_UNSUPPORTED, "fft_size outside [64, 16384] is not implemented "
+                                         "(one analysis segment must fit one CU's LDS)");
     if (c->rms_correction_steps < 0 || c->rms_correction_steps > 16)
         return fail(MGX_ERR_UNSUPPORTED, "rms_correction_steps outside [0, 16]");
     if (c->lowess_it != 0) return fail(MGX_ERR_UNSUPPORTED, "lowess_it != 0 is not implemented");
@@ -174,7 +175,7 @@ static int analysis_workgroups_per_cu(int log2f) {
     int threads = 64;
     switch (log2f) {
 #define CASE(L) case L: lds = analysis_lds_bytes<L>(); threads = Fft2<L>::T; break;
-        CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
+        CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return 1;
     }
@@ -231,7 +232,7 @@ static int run_analysis(mgx_handle* h, const float* x, long long n, const mgx_co
     MGX_TRY(get_twiddles(h, l, &a.tw));
     switch (l) {
 #define CASE(L) case L: MGX_TRY(launch_analysis<L>(h, a, nwg)); break;
-        CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
+        CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return fail(MGX_ERR_UNSUPPORTED, "fft_size not supported by the analysis kernel");
     }
@@ -341,24 +342,26 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
                        (double*)h->scalars.p, (CorrectionState*)h->cstate.p);
     hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
                        (const double*)raw, scratch);
-    const size_t lds_taps = ((size_t)pl.fft + pl.bins + 1024) * sizeof(double);
+    // the cosine table rides in LDS when it fits (F <= 8192), otherwise it is read through L2
+    const bool cos_in_lds = ((size_t)pl.fft + pl.bins + 1024) * sizeof(double) <= (size_t)150 * 1024;
+    const size_t lds_taps = ((cos_in_lds ? (size_t)pl.fft : 0) + pl.bins + 1024) * sizeof(double);
     MGX_TRY(allow_lds(k_fir_taps, lds_taps));
     hipLaunchKernelGGL(k_fir_taps, dim3(pl.fft / 64, 2), dim3(1024), lds_taps, h->stream, pl, (const double*)scratch,
-                       (float*)h->taps.p);
+                       (float*)h->taps.p, cos_in_lds ? 1 : 0);
     HIP_TRY(hipGetLastError());
     h->last_taps = cfg->fft_size;
     return 0;
 }
 
-template <int LOG2N>
+template <int LOG2N, bool MULTI>
 static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr,
                        int repeat) {
     using F = Fft2<LOG2N>;
     const size_t lds = conv_lds_bytes<LOG2N>();
     MGX_TRY(allow_lds(k_conv_prep<LOG2N>, lds));
-    MGX_TRY(allow_lds(k_conv<LOG2N>, lds));
-    hipLaunchKernelGGL(k_conv_prep<LOG2N>, dim3(2), dim3(F::T), lds, h->stream, taps_dev, a.tw, (float2*)h->filt.p,
-                       gain_ptr, gain);
+    MGX_TRY((allow_lds(k_conv<LOG2N, MULTI>, lds)));
+    hipLaunchKernelGGL(k_conv_prep<LOG2N>, dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev, a.tw,
+                       (float2*)h->filt.p, a.parts, gain_ptr, gain);
     HIP_TRY(hipGetLastError());
     MGX_TRY(ensure(h, h->block_peak, (size_t)a.npairs * sizeof(float)));
     a.pair_peak = (float*)h->block_peak.p;
@@ -370,34 +373,49 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
     const unsigned grid = (unsigned)(((std::min<long long>(a.npairs, cap) + 7) / 8) * 8);
     if (repeat > 1) HIP_TRY(hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < repeat; ++r)
-        hipLaunchKernelGGL(k_conv<LOG2N>, dim3(grid), dim3(F::T), lds, h->stream, a);
+        hipLaunchKernelGGL((k_conv<LOG2N, MULTI>), dim3(grid), dim3(F::T), lds, h->stream, a);
     if (repeat > 1) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-// taps_dev: [2][F] float (mid then side) already on the device
+// taps_dev: [2][F] float (mid then side) already on the device.  F <= 8192: one overlap-save block of
+// N = 2F per filter; longer filters (config #5: 16 k taps at 96 kHz) are cut into K = F/4096
+// partitions on N = 8192 blocks (uniformly partitioned overlap-save), because N = 2F no longer fits
+// a CU's LDS.  MGX_CONV_BLOCK_LOG2=<l> forces N = 2^l with K = 2F/N partitions (tests).
 static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const float* taps_dev, double gain,
                     float* y, float* ymid, long long* npairs_out, int repeat = 1,
                     const double* gain_ptr = nullptr) {
     const int l = ilog2_exact(taps);
     if (l < 0) return fail(MGX_ERR_ARGUMENT, "FIR length must be a power of two");
-    const int log2b = l + 1;
+    int log2b = l + 1;
+    if (log2b > 14) log2b = 13;
+    if (const char* forced = std::getenv("MGX_CONV_BLOCK_LOG2")) {
+        const int f = std::atoi(forced);
+        if ((f == 10 || f == 13) && f <= l + 1) log2b = f;      // the partitioned kernel exists for these two
+    }
     const size_t nb = (size_t)1 << log2b;
-    MGX_TRY(ensure(h, h->filt, 2 * nb * sizeof(float2)));
+    const int parts = (int)((size_t)2 * taps / nb);
+    MGX_TRY(ensure(h, h->filt, 2 * (size_t)parts * nb * sizeof(float2)));
     Conv2Args a;
     a.x = reinterpret_cast<const float2*>(x);
     a.n = n;
     a.y = reinterpret_cast<float2*>(y);
     a.ymid = ymid;
     a.h_mid = (const float2*)h->filt.p;
-    a.h_side = (const float2*)h->filt.p + nb;
+    a.h_side = (const float2*)h->filt.p + (size_t)parts * nb;
+    a.parts = parts;
     a.npairs = (n + (long long)nb - 1) / (long long)nb;
     a.pair_peak = nullptr;
     MGX_TRY(get_twiddles(h, log2b, &a.tw));
     if (npairs_out) *npairs_out = a.npairs;
+    if (parts > 1) {
+        if (log2b == 13) return launch_conv<13, true>(h, a, taps_dev, gain, gain_ptr, repeat);
+        if (log2b == 10) return launch_conv<10, true>(h, a, taps_dev, gain, gain_ptr, repeat);
+        return fail(MGX_ERR_UNSUPPORTED, "partitioned convolution is built for 1024- and 8192-frame blocks only");
+    }
     switch (log2b) {
-#define CASE(L) case L: return launch_conv<L>(h, a, taps_dev, gain, gain_ptr, repeat);
+#define CASE(L) case L: return launch_conv<L, false>(h, a, taps_dev, gain, gain_ptr, repeat);
         CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return fail(MGX_ERR_UNSUPPORTED, "FIR length not supported by the convolution kernel");

@@ -64,43 +64,58 @@ constexpr size_t conv_lds_bytes() {
 }
 
 // one pair of output blocks: mid channel, then side channel + epilogue (conv2_kernel.h)
-template <int LOG2N>
+template <int LOG2N, bool SIDE, bool MULTI>
+__device__ __forceinline__ void conv_channel(int tid, long long pair, bool edge, const Conv2Args& a,
+                                             const typename Conv2Block<LOG2N>::Persist& ps, float2* lds,
+                                             const float2* mid_table) {
+    using CB = Conv2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
+    const float2* h = SIDE ? a.h_side : a.h_mid;
+    typename CB::RowFilter rf;
+    if (!MULTI) {
+        CB::template phase_load<SIDE>(tid, pair, edge, a, ps, lds);
+        CB::fetch_filter(tid, h, rf);
+        __syncthreads();
+        if (F::P == 3) {
+            CB::phase_fwd_mid(tid, lds, mid_table);
+            __syncthreads();
+        }
+        CB::phase_filter(tid, rf, lds);
+    } else {
+        // uniformly partitioned overlap-save: one forward transform per filter partition, products
+        // accumulated on the thread's row, one inverse transform
+        typename CB::RowAcc acc;
+        CB::clear_acc(acc);
+        for (int k = 0; k < a.parts; ++k) {
+            CB::template phase_load<SIDE>(tid, pair, edge, a, ps, lds, k);
+            CB::fetch_filter(tid, h + (size_t)k * F::N, rf);
+            __syncthreads();
+            if (F::P == 3) {
+                CB::phase_fwd_mid(tid, lds, mid_table);
+                __syncthreads();
+            }
+            CB::phase_accumulate(tid, rf, lds, acc);
+            __syncthreads();
+        }
+        CB::phase_finish_row(tid, acc, lds);
+    }
+    __syncthreads();
+    if (F::P == 3) {
+        CB::phase_inv_mid(tid, lds, mid_table);
+        __syncthreads();
+    }
+}
+template <int LOG2N, bool MULTI>
 __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2Args& a,
                                            const typename Conv2Block<LOG2N>::Persist& ps, float2* lds,
                                            const float2* mid_table) {
     using CB = Conv2Block<LOG2N>;
-    using F = Fft2<LOG2N>;
-    const bool edge = !CB::interior(pair, a.n);
+    const bool edge = !CB::interior(pair, a.n, a.parts);
     typename CB::Kept kept;
-    typename CB::RowFilter rf;
-    CB::template phase_load<false>(tid, pair, edge, a, ps, lds);
-    CB::fetch_filter(tid, a.h_mid, rf);
-    __syncthreads();
-    if (F::P == 3) {
-        CB::phase_fwd_mid(tid, lds, mid_table);
-        __syncthreads();
-    }
-    CB::phase_filter(tid, rf, lds);
-    __syncthreads();
-    if (F::P == 3) {
-        CB::phase_inv_mid(tid, lds, mid_table);
-        __syncthreads();
-    }
+    conv_channel<LOG2N, false, MULTI>(tid, pair, edge, a, ps, lds, mid_table);
     CB::phase_keep_mid(tid, ps, lds, kept);
     __syncthreads();
-    CB::template phase_load<true>(tid, pair, edge, a, ps, lds);
-    CB::fetch_filter(tid, a.h_side, rf);
-    __syncthreads();
-    if (F::P == 3) {
-        CB::phase_fwd_mid(tid, lds, mid_table);
-        __syncthreads();
-    }
-    CB::phase_filter(tid, rf, lds);
-    __syncthreads();
-    if (F::P == 3) {
-        CB::phase_inv_mid(tid, lds, mid_table);
-        __syncthreads();
-    }
+    conv_channel<LOG2N, true, MULTI>(tid, pair, edge, a, ps, lds, mid_table);
     return CB::phase_store(tid, pair, edge, a, ps, lds, kept);
 }
 
@@ -108,7 +123,9 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2A
 // XCD w % 8, so XCD x walks its own contiguous eighth of the track and the workgroups resident on
 // it work on neighbouring pairs: the overlap between neighbours is re-read from that XCD's L2,
 // not from HBM.  Placement only affects speed, never results.
-template <int LOG2N>
+// MULTI = more than one filter partition (its own instantiation: the accumulator row costs registers
+// the plain kernel should not pay for)
+template <int LOG2N, bool MULTI>
 __global__ __launch_bounds__(Fft2<LOG2N>::T, 2) void k_conv(Conv2Args a) {
     using CB = Conv2Block<LOG2N>;
     using F = Fft2<LOG2N>;
@@ -129,33 +146,34 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, 2) void k_conv(Conv2Args a) {
         // not have.  An empty asm makes the values opaque per iteration.
 #pragma unroll
         for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
-        const float pk = conv_pair<LOG2N>(tid, pair, a, ps, lds, mid_table);
+        const float pk = conv_pair<LOG2N, MULTI>(tid, pair, a, ps, lds, mid_table);
         const float bp = block_max<F::T>(pk, scratch);
         if (tid == 0 && a.pair_peak) a.pair_peak[pair] = bp;
         __syncthreads();
     }
 }
 
-// filter spectra: grid = 2 (mid, side); taps = [2][F] float, tables = [2][N] float2
+// filter spectra: grid = 2 * parts; taps = [2][parts * N/2] float (mid then side), tables =
+// [2][parts][N] float2.  Workgroup (ch, k) transforms partition k of channel ch.
 template <int LOG2N>
 __global__ __launch_bounds__(Fft2<LOG2N>::T) void k_conv_prep(const float* taps, const float2* tw, float2* tables,
-                                                              const double* gain_ptr, double gain) {
+                                                              int parts, const double* gain_ptr, double gain) {
     using CB = Conv2Block<LOG2N>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
     float2* mid_table = lds + F::LDS_ELEMS;
-    const int tid = threadIdx.x, ch = blockIdx.x;
+    const int tid = threadIdx.x, ch = blockIdx.x / parts, k = blockIdx.x % parts;
     typename CB::Persist ps;
     CB::load_persist(tid, tw, mid_table, ps);
-    CB::phase_load_taps(tid, taps + (size_t)ch * CB::TAPS, ps, lds);
+    CB::phase_load_taps(tid, taps + ((size_t)ch * parts + k) * CB::TAPS, ps, lds);
     __syncthreads();
     if (F::P == 3) {
         CB::phase_fwd_mid(tid, lds, mid_table);
         __syncthreads();
     }
     const double g = gain_ptr ? *gain_ptr * gain : gain;
-    CB::phase_write_filter(tid, lds, (float)(g / (double)F::N), tables + (size_t)ch * F::N);
+    CB::phase_write_filter(tid, lds, (float)(g / (double)F::N), tables + ((size_t)ch * parts + k) * F::N);
 }
 
 // ---------------------------------------------------------------------------
@@ -518,16 +536,19 @@ __global__ __launch_bounds__(1024) void k_fir_b(FirPlanView pl, double* scratch)
 }
 // irfft + ifftshift + Hann (match_frequencies.py:98-99).  grid = (F/64, 2); a workgroup
 // computes 64 taps, 16 lanes each summing a slice of the bins.
-__global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double* scratch, float* taps /* [2][F] */) {
+__global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double* scratch, float* taps /* [2][F] */,
+                                                   int cos_in_lds) {
     MGX_LDS;
-    double* cosv = reinterpret_cast<double*>(mgx_smem);     // [F]
-    double* sm = cosv + pl.fft;                             // [bins]
+    double* sm = reinterpret_cast<double*>(mgx_smem);       // [bins]
     double* red = sm + pl.bins;                             // [1024]
+    double* cos_lds = red + 1024;                           // [F] when it fits
     const int plane = blockIdx.y, f = pl.fft, half = f / 2;
     const FirScratch s = fir_scratch(const_cast<double*>(scratch), pl, plane);
-    for (int i = threadIdx.x; i < f; i += 1024) cosv[i] = pl.cos_table[i];
+    if (cos_in_lds)
+        for (int i = threadIdx.x; i < f; i += 1024) cos_lds[i] = pl.cos_table[i];
     for (int i = threadIdx.x; i < pl.bins; i += 1024) sm[i] = s.smooth[i];
     __syncthreads();
+    const double* cosv = cos_in_lds ? cos_lds : pl.cos_table;
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
     const int mm = (i + half) & (f - 1);
     const int per = (half - 1 + 15) / 16;                   // bins 1 .. half-1 split over 16 lanes

@@ -34,56 +34,86 @@ static int conv_impl(const float* x, long long n, const double* fir_mid, const d
                      double gain, float* y, float* ymid, double* peak) {
     using CB = Conv2Block<LOG2N>;
     using F = typename CB::F;
+    const int parts = 2 * taps / F::N;
     const std::vector<float2> tw = twiddles(F::N);
-    std::vector<float2> lds(F::LDS_ELEMS), mid_table(F::MID_TABLE + 1), tables(2 * F::N);
+    std::vector<float2> lds(F::LDS_ELEMS), mid_table(F::MID_TABLE + 1), tables((size_t)2 * parts * F::N);
     std::vector<float> h(2 * taps);
     for (int i = 0; i < taps; ++i) { h[i] = (float)fir_mid[i]; h[taps + i] = (float)fir_side[i]; }
     std::vector<typename CB::Persist> ps(F::T);
     FOR_THREADS(F::T) CB::load_persist(tid, tw.data(), mid_table.data(), ps[tid]);
-    for (int ch = 0; ch < 2; ++ch) {
-        FOR_THREADS(F::T) CB::phase_load_taps(tid, h.data() + ch * taps, ps[tid], lds.data());
-        FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
-        FOR_THREADS(F::T) CB::phase_write_filter(tid, lds.data(), (float)(gain / F::N), tables.data() + ch * F::N);
-    }
+    for (int ch = 0; ch < 2; ++ch)
+        for (int k = 0; k < parts; ++k) {
+            FOR_THREADS(F::T) CB::phase_load_taps(tid, h.data() + ((size_t)ch * parts + k) * CB::TAPS, ps[tid], lds.data());
+            FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
+            FOR_THREADS(F::T) CB::phase_write_filter(tid, lds.data(), (float)(gain / F::N),
+                                                     tables.data() + ((size_t)ch * parts + k) * F::N);
+        }
     Conv2Args a;
     a.x = reinterpret_cast<const float2*>(x);
     a.n = n;
     a.y = reinterpret_cast<float2*>(y);
     a.ymid = ymid;
     a.h_mid = tables.data();
-    a.h_side = tables.data() + F::N;
+    a.h_side = tables.data() + (size_t)parts * F::N;
     a.tw = tw.data();
+    a.parts = parts;
     a.npairs = (n + F::N - 1) / F::N;
     a.pair_peak = nullptr;
     float pk = 0.f;
     std::vector<typename CB::Kept> kept(F::T);
+    std::vector<typename CB::RowAcc> acc(F::T);
+    // one channel of one pair, exactly the phase sequence of conv_channel() in mgx_kernels.h
+    auto channel = [&](long long pair, bool edge, bool side) {
+        const float2* hh = side ? a.h_side : a.h_mid;
+        if (parts == 1) {
+            if (side) { FOR_THREADS(F::T) CB::template phase_load<true>(tid, pair, edge, a, ps[tid], lds.data()); }
+            else { FOR_THREADS(F::T) CB::template phase_load<false>(tid, pair, edge, a, ps[tid], lds.data()); }
+            FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
+            FOR_THREADS(F::T) { typename CB::RowFilter rf; CB::fetch_filter(tid, hh, rf); CB::phase_filter(tid, rf, lds.data()); }
+        } else {
+            FOR_THREADS(F::T) CB::clear_acc(acc[tid]);
+            for (int k = 0; k < parts; ++k) {
+                if (side) { FOR_THREADS(F::T) CB::template phase_load<true>(tid, pair, edge, a, ps[tid], lds.data(), k); }
+                else { FOR_THREADS(F::T) CB::template phase_load<false>(tid, pair, edge, a, ps[tid], lds.data(), k); }
+                FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
+                FOR_THREADS(F::T) {
+                    typename CB::RowFilter rf;
+                    CB::fetch_filter(tid, hh + (size_t)k * F::N, rf);
+                    CB::phase_accumulate(tid, rf, lds.data(), acc[tid]);
+                }
+            }
+            FOR_THREADS(F::T) CB::phase_finish_row(tid, acc[tid], lds.data());
+        }
+        FOR_THREADS(F::T) CB::phase_inv_mid(tid, lds.data(), mid_table.data());
+    };
     for (long long pair = 0; pair < a.npairs; ++pair) {
-        const bool edge = !CB::interior(pair, n);
-        FOR_THREADS(F::T) CB::template phase_load<false>(tid, pair, edge, a, ps[tid], lds.data());
-        FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
-        FOR_THREADS(F::T) { typename CB::RowFilter rf; CB::fetch_filter(tid, a.h_mid, rf); CB::phase_filter(tid, rf, lds.data()); }
-        FOR_THREADS(F::T) CB::phase_inv_mid(tid, lds.data(), mid_table.data());
+        const bool edge = !CB::interior(pair, n, parts);
+        channel(pair, edge, false);
         FOR_THREADS(F::T) CB::phase_keep_mid(tid, ps[tid], lds.data(), kept[tid]);
-        FOR_THREADS(F::T) CB::template phase_load<true>(tid, pair, edge, a, ps[tid], lds.data());
-        FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
-        FOR_THREADS(F::T) { typename CB::RowFilter rf; CB::fetch_filter(tid, a.h_side, rf); CB::phase_filter(tid, rf, lds.data()); }
-        FOR_THREADS(F::T) CB::phase_inv_mid(tid, lds.data(), mid_table.data());
+        channel(pair, edge, true);
         FOR_THREADS(F::T) pk = std::fmax(pk, CB::phase_store(tid, pair, edge, a, ps[tid], lds.data(), kept[tid]));
     }
     if (peak) *peak = pk;
     return 0;
 }
 
-extern "C" int emu_convolve(const float* x, long long n, const double* fir_mid, const double* fir_side,
-                            int taps, double gain, float* y, float* ymid, double* peak) {
+// block_log2 = 0: N = 2*taps (one partition); otherwise N = 2^block_log2 and 2*taps/N partitions
+extern "C" int emu_convolve_blocked(const float* x, long long n, const double* fir_mid, const double* fir_side,
+                                    int taps, double gain, float* y, float* ymid, double* peak, int block_log2) {
     const int l = ilog2_exact(taps);
     if (l < 0) return -1;
-    switch (l + 1) {
+    const int log2b = block_log2 ? block_log2 : l + 1;
+    if ((2 * taps) % (1 << log2b) != 0) return -1;
+    switch (log2b) {
 #define CASE(L) case L: return conv_impl<L>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
         CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return -4;
     }
+}
+extern "C" int emu_convolve(const float* x, long long n, const double* fir_mid, const double* fir_side,
+                            int taps, double gain, float* y, float* ymid, double* peak) {
+    return emu_convolve_blocked(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak, 0);
 }
 
 // ---------------------------------------------------------------------------

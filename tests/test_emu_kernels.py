@@ -64,6 +64,29 @@ def test_convolution_phases(emu, taps, n):
     assert abs(peak - np.abs(y).max()) <= 1e-6
 
 
+@pytest.mark.parametrize("taps,block_log2,n", [(256, 8, 1500), (1024, 9, 4000), (2048, 10, 7001),
+                                               (512, 7, 1), (4096, 11, 9000)])
+def test_partitioned_convolution_phases(emu, taps, block_log2, n):
+    """Filters longer than half a block: uniformly partitioned overlap-save (K = 2*taps/N partitions),
+    the path a 16 k-tap FIR takes on N = 8192 blocks; checked here at small N against the same
+    direct convolution."""
+    rng = np.random.RandomState(taps + n)
+    x = np.ascontiguousarray((0.3 * rng.randn(n, 2)).astype(np.float32))
+    hm, hs = rng.randn(taps) / np.sqrt(taps), rng.randn(taps) / np.sqrt(taps)
+    y = np.zeros((n, 2), dtype=np.float32)
+    ymid = np.zeros(n, dtype=np.float32)
+    peak = ctypes.c_double()
+    rc = emu.emu_convolve_blocked(_fp(x), ctypes.c_longlong(n), _dp(hm), _dp(hs), ctypes.c_int(taps),
+                                  ctypes.c_double(0.8), _fp(y), _fp(ymid), ctypes.byref(peak),
+                                  ctypes.c_int(block_log2))
+    assert rc == 0
+    mid, side = mo.mid_side(x.astype(np.float64))
+    want, want_mid = mo.convolve_same(mid * 0.8, hm, side * 0.8, hs)
+    assert rms_error(y, want) <= 1e-6
+    assert rms_error(ymid, want_mid) <= 1e-6
+    assert abs(peak.value - np.abs(y).max()) <= 1e-6
+
+
 def test_convolution_identity(emu):
     # scipy "same" centring (match_frequencies.py:112): delta at (F-1)//2 is the identity
     rng = np.random.RandomState(5)

@@ -108,6 +108,45 @@ def test_convolution_stage(taps):
     assert abs(peak - np.abs(y).max()) <= 1e-6
 
 
+@pytest.mark.parametrize("taps,forced_block", [(2048, "10"), (8192, "13"), (16384, None), (32768, None)])
+def test_partitioned_convolution_stage(taps, forced_block, monkeypatch):
+    """Uniformly partitioned overlap-save: FIRs longer than half an LDS block (a 16 k-tap filter on
+    8192-frame blocks = 4 partitions; BASELINE config #5).  The smaller cases force the partitioned
+    kernel onto sizes the plain kernel also handles."""
+    from matchering_amd import kernels
+
+    if forced_block:
+        monkeypatch.setenv("MGX_CONV_BLOCK_LOG2", forced_block)
+    rng = np.random.RandomState(taps)
+    n = 2 * taps + 40961
+    x = (0.3 * rng.randn(n, 2)).astype(np.float32)
+    hm, hs = rng.randn(taps) / np.sqrt(taps), rng.randn(taps) / np.sqrt(taps)
+    y, ymid, peak = kernels.convolve(x, hm, hs, gain=0.9)
+    mid, side = mo.mid_side(x.astype(np.float64))
+    want, want_mid = mo.convolve_same(mid * 0.9, hm, side * 0.9, hs)
+    assert rms_error(y, want) <= 1e-6
+    assert rms_error(ymid, want_mid) <= 1e-6
+    assert abs(peak - np.abs(y).max()) <= 1e-6
+
+
+def test_master_long_fir_96k():
+    """BASELINE config #5 in miniature: 96 kHz, fft_size 16384 (16 k-tap matching FIR), full pipeline
+    against the oracle."""
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd.synth import make_pair
+
+    sr = 96000
+    t, r = make_pair(3.0, sr, pair=7, reference_seconds=2.6)
+    kw = dict(internal_sample_rate=sr, fft_size=16384, max_piece_size=1.1)
+    res, res_nl, res_nln = stages.main(t, r, mg.Config(**kw), need_default=True, need_no_limiter=True,
+                                       need_no_limiter_normalized=True)
+    want = mo.master(t, r, mo.params(**kw), True, True, True)
+    for mine, ref in zip((res, res_nl, res_nln), want):
+        assert rms_error(mine, ref) <= RMS_TOL
+        assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
 def test_convolution_identity_and_linearity():
     from matchering_amd import kernels
 
@@ -162,5 +201,5 @@ def test_fails_loudly_on_unsupported():
 
     t, r = build_inputs(CASES["hot_lowrate"])
     with pytest.raises(MgxError):
-        stages.main(t, r, mg.Config(internal_sample_rate=8000, fft_size=16384, max_piece_size=5.0,
+        stages.main(t, r, mg.Config(internal_sample_rate=8000, fft_size=32768, max_piece_size=5.0,
                                     max_length=600))
