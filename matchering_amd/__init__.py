@@ -9,4 +9,8 @@ __version__ = "0.1.0"
 __reference_version__ = "2.0.6"
 
 from .log import set_handlers as log  # noqa: F401
+from .results import Result, pcm16, pcm24  # noqa: F401
 from .config import Config, LimiterConfig  # noqa: F401
+from .core import process  # noqa: F401
+from .audio_io import load  # noqa: F401
+from .checker import check  # noqa: F401

@@ -1,0 +1,57 @@
+"""A/B previews (matchering/preview_creator.py:30-94): the loudest ``preview_size`` window of the
+RESULT (RMS over both channels, windows every ``preview_analysis_step``), cut from target and
+result alike, faded in and out, saved.  Host numpy, off the timed path."""
+
+import numpy as np
+
+from .audio_io import save
+from .config import Config
+from .log import Code, debug, debug_line, info
+from .results import Result
+from .utils import time_str
+
+
+def _window_starts(length, size, step):
+    if size > length:
+        return np.array([0]), length                      # dsp.py:131-132: the whole array is the only window
+    return np.arange((length - size) // step + 1) * step, size
+
+
+def _loudest_window(result, size, step):
+    """argmax over windows of the mean square of all samples in the window (dsp.py:128-143)."""
+    starts, size = _window_starts(result.shape[0], size, step)
+    csum = np.concatenate(([0.0], np.cumsum(np.einsum("ij,ij->i", result, result))))
+    energy = csum[starts + size] - csum[starts]
+    return int(np.argmax(energy)), starts, size
+
+
+def _fade(array, fade_size):
+    """dsp.py:146-152: linear fade-in and fade-out of ``fade_size`` frames."""
+    array = np.array(array, dtype=np.float64, copy=True)
+    ramp = np.linspace(0, 1, fade_size)
+    array[:fade_size] *= ramp[:, None]
+    array[array.shape[0] - fade_size:] *= ramp[::-1, None]
+    return array
+
+
+def create_preview(target: np.ndarray, result: np.ndarray, config: Config, preview_target: Result,
+                   preview_result: Result) -> None:
+    debug_line()
+    info(Code.INFO_MAKING_PREVIEWS)
+    target = np.clip(target, -config.threshold, config.threshold)            # dsp.py:109-110
+    size, step = int(config.preview_size), int(config.preview_analysis_step)
+    debug(f"The maximum duration of the preview is {size / config.internal_sample_rate} seconds, "
+          f"with the analysis step of {step / config.internal_sample_rate} seconds")
+    index, starts, size = _loudest_window(np.asarray(result, dtype=np.float64), size, step)
+    begin = int(starts[index])
+    target_piece = np.array(target[begin:begin + size], dtype=np.float64)
+    result_piece = np.array(result[begin:begin + size], dtype=np.float64)
+    debug(f"The best part to preview: {time_str(begin, config.internal_sample_rate)} "
+          f"- {time_str(begin + result_piece.shape[0], config.internal_sample_rate)}")
+    if result.shape[0] != result_piece.shape[0]:
+        fade_size = int(min(config.preview_fade_size, result_piece.shape[0] // config.preview_fade_coefficient))
+        target_piece, result_piece = _fade(target_piece, fade_size), _fade(result_piece, fade_size)
+    if preview_target:
+        save(preview_target.file, target_piece, config.internal_sample_rate, preview_target.subtype, "target preview")
+    if preview_result:
+        save(preview_result.file, result_piece, config.internal_sample_rate, preview_result.subtype, "result preview")

@@ -203,3 +203,43 @@ def test_fails_loudly_on_unsupported():
     with pytest.raises(MgxError):
         stages.main(t, r, mg.Config(internal_sample_rate=8000, fft_size=32768, max_piece_size=5.0,
                                     max_length=600))
+
+
+def test_process_files_end_to_end(tmp_path):
+    """``mg.process`` (core.py:32-121): WAV files in, WAV files + previews out, against the oracle run
+    on the decoded inputs.  BASELINE config #1 (examples/basic.py) with the DSP on the GPU."""
+    import matchering_amd as mg
+    from matchering_amd import audio_io
+    from matchering_amd.synth import make_pair
+
+    sr = 44100
+    t, r = make_pair(9.0, sr, pair=9, reference_seconds=5.3)
+    tp, rp = str(tmp_path / "target.wav"), str(tmp_path / "reference.wav")
+    audio_io.write_wav(tp, t, sr, "PCM_24")
+    audio_io.write_wav(rp, r[:, :1], sr, "FLOAT")                 # mono reference: 2201 + duplication
+    outs = {k: str(tmp_path / f"{k}.wav") for k in ("lim24", "lim16", "nolim", "norm", "pt", "pr")}
+    cfg = mg.Config(max_piece_size=1.0, preview_size=6, preview_analysis_step=1.5, preview_fade_size=0.5)
+    codes = []
+    mg.log(lambda m: codes.append(m.split(":")[0]), show_codes=True)
+    try:
+        mg.process(tp, rp,
+                   [mg.pcm24(outs["lim24"]), mg.pcm16(outs["lim16"]),
+                    mg.Result(outs["nolim"], "FLOAT", use_limiter=False, normalize=False),
+                    mg.Result(outs["norm"], "FLOAT", use_limiter=False, normalize=True)],
+                   config=cfg, preview_target=mg.pcm16(outs["pt"]), preview_result=mg.pcm16(outs["pr"]))
+    finally:
+        mg.log()
+    for code in ("2003", "2201", "2004", "2005", "2006", "2007", "2008", "2009", "2010"):
+        assert code in codes, code
+    t_in, _ = audio_io.read_wav(tp)
+    r_in, _ = audio_io.read_wav(rp)
+    r_in = np.repeat(r_in, 2, axis=1)
+    want = mo.master(t_in, r_in, mo.params(max_piece_size=1.0), True, True, True)
+    got24, rate = audio_io.read_wav(outs["lim24"])
+    assert rate == sr and rms_error(got24, want[0]) <= RMS_TOL
+    got16, _ = audio_io.read_wav(outs["lim16"])
+    assert rms_error(got16, want[0]) <= 3e-5                      # 16-bit quantisation
+    assert rms_error(audio_io.read_wav(outs["nolim"])[0], want[1]) <= RMS_TOL
+    assert rms_error(audio_io.read_wav(outs["norm"])[0], want[2]) <= RMS_TOL
+    assert audio_io.read_wav(outs["pr"])[0].shape == (6 * sr, 2)
+    assert audio_io.read_wav(outs["pt"])[0].shape == (6 * sr, 2)

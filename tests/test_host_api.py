@@ -1,0 +1,171 @@
+"""Host side of ``process``: WAV codec, ``Result``, ``check``,
+``create_preview`` -- numpy only, no GPU.  Cross-checked against the standard library's ``wave``
+module and against brute-force restatements of the reference's definitions
+(matchering/results.py, loader.py, saver.py, checker.py, preview_creator.py, dsp.py:128-152)."""
+
+import wave
+
+import numpy as np
+import pytest
+
+import matchering_amd as mg
+from matchering_amd import audio_io, checker, preview
+from matchering_amd.log import Code, ModuleError
+
+
+def _signal(n=5000, channels=2, seed=0):
+    rng = np.random.RandomState(seed)
+    return np.clip(0.4 * rng.randn(n, channels), -0.999, 0.999)
+
+
+# integers are written as rint(x * (2^(b-1) - 1)) and read as v / 2^(b-1) (libsndfile's scaling):
+# half a step of rounding plus |x| / 2^(b-1) of scale mismatch
+@pytest.mark.parametrize("subtype,tol", [("PCM_16", 1.5 / 2 ** 15), ("PCM_24", 1.5 / 2 ** 23),
+                                         ("PCM_32", 1.5 / 2 ** 31), ("FLOAT", 1e-7), ("DOUBLE", 0.0),
+                                         ("PCM_U8", 1.5 / 2 ** 7)])
+def test_wav_round_trip(tmp_path, subtype, tol):
+    x = _signal()
+    path = str(tmp_path / "a.wav")
+    audio_io.write_wav(path, x, 48000, subtype)
+    y, rate = audio_io.read_wav(path)
+    assert rate == 48000 and y.shape == x.shape
+    assert np.abs(y - x).max() <= tol
+
+
+@pytest.mark.parametrize("width", [2, 3])
+def test_wav_agrees_with_stdlib_wave(tmp_path, width):
+    x = _signal(3000)
+    path = str(tmp_path / "ours.wav")
+    audio_io.write_wav(path, x, 44100, "PCM_16" if width == 2 else "PCM_24")
+    with wave.open(path, "rb") as w:                     # our writer, stdlib reader
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (2, width, 44100, 3000)
+        raw = np.frombuffer(w.readframes(3000), dtype=np.uint8).reshape(-1, width).astype(np.int64)
+    v = sum(raw[:, i] << (8 * i) for i in range(width))
+    v = np.where(v >= 1 << (8 * width - 1), v - (1 << (8 * width)), v).reshape(-1, 2)
+    top = (1 << (8 * width - 1)) - 1
+    assert np.array_equal(v, np.rint(x * top).astype(np.int64))
+    theirs = str(tmp_path / "theirs.wav")                # stdlib writer, our reader
+    with wave.open(theirs, "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(22050)
+        w.writeframes(np.rint(x * 32767).astype("<i2").tobytes())
+    y, rate = audio_io.read_wav(theirs)
+    assert rate == 22050 and np.abs(y - np.rint(x * 32767) / 32768).max() <= 1e-12
+
+
+def test_load_errors_follow_the_reference_codes(tmp_path):
+    bad = tmp_path / "noise.bin"
+    bad.write_bytes(b"this is not audio")
+    for kind, code in (("target", Code.ERROR_TARGET_LOADING), ("reference", Code.ERROR_REFERENCE_LOADING)):
+        with pytest.raises(ModuleError) as e:
+            mg.load(str(bad), kind, str(tmp_path))
+        assert e.value.code == code
+    with pytest.raises(ModuleError):
+        mg.load(str(tmp_path / "missing.wav"), "target", str(tmp_path))
+
+
+def test_result_validation():
+    r = mg.pcm16("out.wav")
+    assert (r.subtype, r.use_limiter, r.normalize) == ("PCM_16", True, True)
+    assert mg.pcm24("x/y.wav").subtype == "PCM_24"
+    assert mg.Result("a.wav", "FLOAT", use_limiter=False, normalize=False).use_limiter is False
+    with pytest.raises(TypeError, match="XYZ format is not supported"):
+        mg.Result("a.xyz", "PCM_16")
+    with pytest.raises(TypeError, match="WAV format does not have VORBIS subtype"):
+        mg.Result("a.wav", "VORBIS")
+
+
+def test_check_channels_length_and_rate():
+    cfg = mg.Config()
+    events = []
+    mg.log(warning_handler=lambda m: events.append(("w", m)), info_handler=lambda m: events.append(("i", m)),
+           show_codes=True)
+    try:
+        mono = _signal(50000, channels=1)
+        out, rate = mg.check(mono, 44100, cfg, "reference")
+        assert out.shape == (50000, 2) and np.array_equal(out[:, 0], out[:, 1]) and rate == 44100
+        assert any(m.startswith("2201") for _, m in events)
+        with pytest.raises(ModuleError) as e:
+            mg.check(_signal(100), 44100, cfg, "target")
+        assert e.value.code == Code.ERROR_TARGET_LENGTH_IS_TOO_SMALL
+        with pytest.raises(ModuleError) as e:
+            mg.check(np.zeros((44100 * 15 * 60 + 1, 2), dtype=np.float32), 44100, cfg, "reference")
+        assert e.value.code == Code.ERROR_REFERENCE_LENGTH_LENGTH_IS_EXCEEDED
+        with pytest.raises(ModuleError) as e:
+            mg.check(_signal(50000, channels=3), 44100, cfg, "target")
+        assert e.value.code == Code.ERROR_TARGET_NUM_OF_CHANNELS_IS_EXCEEDED
+        events.clear()
+        t = np.arange(48000 * 2) / 48000.0
+        tone = np.stack([np.sin(2 * np.pi * 440 * t), np.sin(2 * np.pi * 440 * t)], axis=1) * 0.5
+        out, rate = mg.check(tone, 48000, cfg, "target")
+        assert rate == 44100 and abs(out.shape[0] - 2 * 44100) <= 1
+        assert any(m.startswith("3003") for _, m in events)
+        k = np.arange(out.shape[0]) / 44100.0          # the resampled tone is still the 440 Hz tone
+        mid = slice(2000, -2000)
+        assert np.abs(out[mid, 0] - 0.5 * np.sin(2 * np.pi * 440 * k[mid])).max() <= 2e-3
+    finally:
+        mg.log()
+
+
+def test_check_flags_clipping_and_limiting():
+    cfg = mg.Config()
+    seen = []
+    mg.log(warning_handler=seen.append, show_codes=True)
+    try:
+        x = 0.1 * np.random.RandomState(5).randn(60000, 2)
+        x[100:140, 0] = 1.0                                     # 40 samples sitting at full scale
+        mg.check(x, 44100, cfg, "target")
+        assert any(m.startswith("3001") for m in seen)
+        seen.clear()
+        y = np.clip(_signal(60000, seed=3) * 3, -0.9, 0.9)      # flat-topped well below full scale
+        mg.check(y, 44100, cfg, "target")
+        assert any(m.startswith("3002") for m in seen)
+        seen.clear()
+        mg.check(0.1 * np.random.RandomState(4).randn(60000, 2), 44100, cfg, "target")
+        assert not seen
+    finally:
+        mg.log()
+    with pytest.raises(ModuleError) as e:
+        checker.check_equality(x, x.copy())
+    assert e.value.code == Code.ERROR_TARGET_EQUALS_REFERENCE
+    checker.check_equality(x, y)
+
+
+def test_preview_picks_the_loudest_window(tmp_path):
+    sr = 8000
+    cfg = mg.Config(internal_sample_rate=sr, fft_size=512, max_piece_size=2.0, preview_size=6,
+                    preview_analysis_step=2, preview_fade_size=1)
+    rng = np.random.RandomState(2)
+    n = sr * 21 + 123
+    result = 0.1 * rng.randn(n, 2)
+    result[sr * 9: sr * 14] *= 4.0                              # loud between 9 s and 14 s
+    target = 0.5 * rng.randn(n, 2)
+    size, step = sr * 6, sr * 2
+    rms = [np.sqrt(np.mean(result[s:s + size] ** 2)) for s in range(0, n - size + 1, step)]
+    begin = int(np.argmax(rms)) * step
+    pt, pr = str(tmp_path / "t.wav"), str(tmp_path / "r.wav")
+    preview.create_preview(target, result, cfg, mg.Result(pt, "DOUBLE"), mg.Result(pr, "DOUBLE"))
+    got_r, _ = audio_io.read_wav(pr)
+    got_t, _ = audio_io.read_wav(pt)
+    assert got_r.shape == (size, 2) and got_t.shape == (size, 2)
+    fade = min(int(cfg.preview_fade_size), size // cfg.preview_fade_coefficient)
+    ramp = np.linspace(0, 1, fade)
+    want = result[begin:begin + size].copy()
+    want[:fade] *= ramp[:, None]
+    want[size - fade:] *= ramp[::-1, None]
+    assert np.abs(got_r - want).max() <= 1e-12
+    want_t = np.clip(target, -cfg.threshold, cfg.threshold)[begin:begin + size].copy()
+    want_t[:fade] *= ramp[:, None]
+    want_t[size - fade:] *= ramp[::-1, None]
+    assert np.abs(got_t - want_t).max() <= 1e-12
+    # a result shorter than the preview window is kept whole, without fades
+    short = 0.1 * rng.randn(sr * 3, 2)
+    preview.create_preview(short, short, cfg, None, mg.Result(pr, "DOUBLE"))
+    got, _ = audio_io.read_wav(pr)
+    assert np.array_equal(got, short)
+
+
+def test_process_rejects_an_empty_result_list():
+    with pytest.raises(RuntimeError, match="The result list is empty"):
+        mg.process("a.wav", "b.wav", [])
