@@ -41,18 +41,25 @@ struct Conv2Args {
     float* pair_peak;      // [npairs] max(|yL|,|yR|) per pair, or nullptr
 };
 
-template <int LOG2N>
+// TSHIFT: taps per block = N >> TSHIFT.  1 = the usual N = 2F (half of every block is fresh output);
+// 2 = "wide" blocks N = 4F (three quarters fresh: 28 % less transform work per frame, but a
+// 16384-point block for F = 4096 allows only one workgroup per CU).
+template <int LOG2N, int TSHIFT = 1>
 struct Conv2Block {
     using F = Fft2<LOG2N>;
     static constexpr int N = F::N;
     static constexpr int T = F::T;
-    static constexpr int TAPS = N / 2;
+    static constexpr int TAPS = N >> TSHIFT;
+    static constexpr int LOUT = N - TAPS;             // fresh output frames per block
     static constexpr int R0 = F::R0;
     static constexpr int RL = F::RL;
     static constexpr int S0 = F::S(0);
     static constexpr int CNT0 = F::CNT(0);
-    static constexpr int HALF = R0 / 2;              // outputs kept per pass-0 butterfly
-    static constexpr int NLOAD = R0 + HALF;          // frames loaded per pass-0 butterfly
+    static constexpr int SKIP = TAPS / S0 > 0 ? TAPS / S0 : 0;   // leading outputs of a butterfly that are circular garbage
+    static constexpr int HALF = R0 - SKIP;           // outputs kept per pass-0 butterfly
+    static constexpr int BSTEP = LOUT / S0;          // block B = block A advanced by BSTEP butterfly inputs
+    static constexpr int NLOAD = R0 + BSTEP;         // frames loaded per pass-0 butterfly
+    static_assert(TAPS % S0 == 0 && LOUT % S0 == 0 || F::partial(0), "block geometry must follow the pass-0 stride");
 
     struct Persist {
         typename F::Tw0 tw0;
@@ -73,14 +80,14 @@ struct Conv2Block {
     // y = sum_k h_k * x delayed by k*P), partition k reads the N + P frames starting at
     //     pair*N + K*P/2 - (k+1)*P
     // (scipy's "same" centring puts half of the filter into the future); K = 1 is the plain case.
-    static MGX_HD long long first_output(long long pair) { return pair * (long long)N; }
+    static MGX_HD long long first_output(long long pair) { return pair * (long long)(2 * LOUT); }
     static MGX_HD long long first_input(long long pair, int parts = 1, int k = 0) {
-        return pair * (long long)N + (long long)parts * TAPS / 2 - (long long)(k + 1) * TAPS;
+        return first_output(pair) + (long long)parts * TAPS / 2 - (long long)(k + 1) * TAPS;
     }
     // every frame the pair touches lies inside the track: no bounds checks needed
     static MGX_HD bool interior(long long pair, long long n, int parts = 1) {
-        return first_input(pair, parts, parts - 1) >= 0 && first_input(pair, parts, 0) + N + TAPS <= n &&
-               first_output(pair) + N <= n;
+        return first_input(pair, parts, parts - 1) >= 0 && first_input(pair, parts, 0) + N + LOUT <= n &&
+               first_output(pair) + 2 * LOUT <= n;
     }
 
     // ---- phase F0: global -> registers -> pass 0 -> LDS, channel SIDE ? side : mid --------
@@ -120,7 +127,7 @@ struct Conv2Block {
             }
             float2 v[R0];
             MGX_UNROLL
-            for (int j = 0; j < R0; ++j) v[j] = make_float2(ch[j], ch[j + HALF]);
+            for (int j = 0; j < R0; ++j) v[j] = make_float2(ch[j], ch[j + BSTEP]);
             F::fwd0_store(v, tid, c, tw, lds);
         }
     }
@@ -195,7 +202,7 @@ struct Conv2Block {
             float2 v[R0];
             F::inv0_load(v, tid, c, tw, lds);
             MGX_UNROLL
-            for (int j = 0; j < HALF; ++j) k.v[c][j] = v[HALF + j];
+            for (int j = 0; j < HALF; ++j) k.v[c][j] = v[SKIP + j];
         }
     }
 
@@ -216,7 +223,7 @@ struct Conv2Block {
             float2 ya[HALF], yb[HALF];
             MGX_UNROLL
             for (int j = 0; j < HALF; ++j) {
-                const float2 m = k.v[c][j], s = v[HALF + j];
+                const float2 m = k.v[c][j], s = v[SKIP + j];
                 ya[j] = make_float2(m.x + s.x, m.x - s.x);
                 yb[j] = make_float2(m.y + s.y, m.y - s.y);
             }
@@ -224,7 +231,7 @@ struct Conv2Block {
             if (edge) {
                 MGX_UNROLL
                 for (int j = 0; j < HALF; ++j) {
-                    const long long fa = oa + (long long)j * S0, fb = fa + TAPS;
+                    const long long fa = oa + (long long)j * S0, fb = fa + LOUT;
                     if (fa < a.n) {
                         a.y[fa] = ya[j];
                         if (a.ymid) a.ymid[fa] = k.v[c][j].x;
@@ -242,7 +249,7 @@ struct Conv2Block {
                 MGX_UNROLL
                 for (int j = 0; j < HALF; ++j) {
                     st_f2(dst, lane, (unsigned)(j * S0 * 8), ya[j]);
-                    st_f2(dst, lane, (unsigned)((j * S0 + TAPS) * 8), yb[j]);
+                    st_f2(dst, lane, (unsigned)((j * S0 + LOUT) * 8), yb[j]);
                     peak = fmaxf(peak, fmaxf(fmaxf(fabsf(ya[j].x), fabsf(ya[j].y)),
                                              fmaxf(fabsf(yb[j].x), fabsf(yb[j].y))));
                 }
@@ -252,7 +259,7 @@ struct Conv2Block {
                     MGX_UNROLL
                     for (int j = 0; j < HALF; ++j) {
                         st_f1(dm, lane4, (unsigned)(j * S0 * 4), k.v[c][j].x);
-                        st_f1(dm, lane4, (unsigned)((j * S0 + TAPS) * 4), k.v[c][j].y);
+                        st_f1(dm, lane4, (unsigned)((j * S0 + LOUT) * 4), k.v[c][j].y);
                     }
                 }
             }

@@ -353,14 +353,14 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     return 0;
 }
 
-template <int LOG2N, bool MULTI>
+template <int LOG2N, bool MULTI, int TSHIFT = 1>
 static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr,
                        int repeat) {
     using F = Fft2<LOG2N>;
     const size_t lds = conv_lds_bytes<LOG2N>();
-    MGX_TRY(allow_lds(k_conv_prep<LOG2N>, lds));
-    MGX_TRY((allow_lds(k_conv<LOG2N, MULTI>, lds)));
-    hipLaunchKernelGGL(k_conv_prep<LOG2N>, dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev, a.tw,
+    MGX_TRY((allow_lds(k_conv_prep<LOG2N, TSHIFT>, lds)));
+    MGX_TRY((allow_lds(k_conv<LOG2N, MULTI, TSHIFT>, lds)));
+    hipLaunchKernelGGL((k_conv_prep<LOG2N, TSHIFT>), dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev, a.tw,
                        (float2*)h->filt.p, a.parts, gain_ptr, gain);
     HIP_TRY(hipGetLastError());
     MGX_TRY(ensure(h, h->block_peak, (size_t)a.npairs * sizeof(float)));
@@ -373,7 +373,7 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
     const unsigned grid = (unsigned)(((std::min<long long>(a.npairs, cap) + 7) / 8) * 8);
     if (repeat > 1) HIP_TRY(hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < repeat; ++r)
-        hipLaunchKernelGGL((k_conv<LOG2N, MULTI>), dim3(grid), dim3(F::T), lds, h->stream, a);
+        hipLaunchKernelGGL((k_conv<LOG2N, MULTI, TSHIFT>), dim3(grid), dim3(F::T), lds, h->stream, a);
     if (repeat > 1) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -396,6 +396,7 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     }
     const size_t nb = (size_t)1 << log2b;
     const int parts = (int)((size_t)2 * taps / nb);
+    const long long pair_frames = (long long)nb;
     MGX_TRY(ensure(h, h->filt, 2 * (size_t)parts * nb * sizeof(float2)));
     Conv2Args a;
     a.x = reinterpret_cast<const float2*>(x);
@@ -405,7 +406,7 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     a.h_mid = (const float2*)h->filt.p;
     a.h_side = (const float2*)h->filt.p + (size_t)parts * nb;
     a.parts = parts;
-    a.npairs = (n + (long long)nb - 1) / (long long)nb;
+    a.npairs = (n + pair_frames - 1) / pair_frames;
     a.pair_peak = nullptr;
     MGX_TRY(get_twiddles(h, log2b, &a.tw));
     if (npairs_out) *npairs_out = a.npairs;

@@ -64,11 +64,11 @@ constexpr size_t conv_lds_bytes() {
 }
 
 // one pair of output blocks: mid channel, then side channel + epilogue (conv2_kernel.h)
-template <int LOG2N, bool SIDE, bool MULTI>
+template <int LOG2N, bool SIDE, bool MULTI, int TSHIFT>
 __device__ __forceinline__ void conv_channel(int tid, long long pair, bool edge, const Conv2Args& a,
-                                             const typename Conv2Block<LOG2N>::Persist& ps, float2* lds,
+                                             const typename Conv2Block<LOG2N, TSHIFT>::Persist& ps, float2* lds,
                                              const float2* mid_table) {
-    using CB = Conv2Block<LOG2N>;
+    using CB = Conv2Block<LOG2N, TSHIFT>;
     using F = Fft2<LOG2N>;
     const float2* h = SIDE ? a.h_side : a.h_mid;
     typename CB::RowFilter rf;
@@ -105,17 +105,17 @@ __device__ __forceinline__ void conv_channel(int tid, long long pair, bool edge,
         __syncthreads();
     }
 }
-template <int LOG2N, bool MULTI>
+template <int LOG2N, bool MULTI, int TSHIFT>
 __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2Args& a,
-                                           const typename Conv2Block<LOG2N>::Persist& ps, float2* lds,
+                                           const typename Conv2Block<LOG2N, TSHIFT>::Persist& ps, float2* lds,
                                            const float2* mid_table) {
-    using CB = Conv2Block<LOG2N>;
+    using CB = Conv2Block<LOG2N, TSHIFT>;
     const bool edge = !CB::interior(pair, a.n, a.parts);
     typename CB::Kept kept;
-    conv_channel<LOG2N, false, MULTI>(tid, pair, edge, a, ps, lds, mid_table);
+    conv_channel<LOG2N, false, MULTI, TSHIFT>(tid, pair, edge, a, ps, lds, mid_table);
     CB::phase_keep_mid(tid, ps, lds, kept);
     __syncthreads();
-    conv_channel<LOG2N, true, MULTI>(tid, pair, edge, a, ps, lds, mid_table);
+    conv_channel<LOG2N, true, MULTI, TSHIFT>(tid, pair, edge, a, ps, lds, mid_table);
     return CB::phase_store(tid, pair, edge, a, ps, lds, kept);
 }
 
@@ -125,9 +125,9 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2A
 // not from HBM.  Placement only affects speed, never results.
 // MULTI = more than one filter partition (its own instantiation: the accumulator row costs registers
 // the plain kernel should not pay for)
-template <int LOG2N, bool MULTI>
+template <int LOG2N, bool MULTI, int TSHIFT = 1>
 __global__ __launch_bounds__(Fft2<LOG2N>::T, 2) void k_conv(Conv2Args a) {
-    using CB = Conv2Block<LOG2N>;
+    using CB = Conv2Block<LOG2N, TSHIFT>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, 2) void k_conv(Conv2Args a) {
         // not have.  An empty asm makes the values opaque per iteration.
 #pragma unroll
         for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
-        const float pk = conv_pair<LOG2N, MULTI>(tid, pair, a, ps, lds, mid_table);
+        const float pk = conv_pair<LOG2N, MULTI, TSHIFT>(tid, pair, a, ps, lds, mid_table);
         const float bp = block_max<F::T>(pk, scratch);
         if (tid == 0 && a.pair_peak) a.pair_peak[pair] = bp;
         __syncthreads();
@@ -155,10 +155,10 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, 2) void k_conv(Conv2Args a) {
 
 // filter spectra: grid = 2 * parts; taps = [2][parts * N/2] float (mid then side), tables =
 // [2][parts][N] float2.  Workgroup (ch, k) transforms partition k of channel ch.
-template <int LOG2N>
+template <int LOG2N, int TSHIFT = 1>
 __global__ __launch_bounds__(Fft2<LOG2N>::T) void k_conv_prep(const float* taps, const float2* tw, float2* tables,
                                                               int parts, const double* gain_ptr, double gain) {
-    using CB = Conv2Block<LOG2N>;
+    using CB = Conv2Block<LOG2N, TSHIFT>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);

@@ -29,12 +29,12 @@ static std::vector<float2> twiddles(int n) {
 #define FOR_THREADS(T_) for (int tid = 0; tid < (T_); ++tid)
 
 // ---------------------------------------------------------------------------
-template <int LOG2N>
+template <int LOG2N, int TSHIFT = 1>
 static int conv_impl(const float* x, long long n, const double* fir_mid, const double* fir_side, int taps,
                      double gain, float* y, float* ymid, double* peak) {
-    using CB = Conv2Block<LOG2N>;
+    using CB = Conv2Block<LOG2N, TSHIFT>;
     using F = typename CB::F;
-    const int parts = 2 * taps / F::N;
+    const int parts = TSHIFT == 1 ? 2 * taps / F::N : 1;
     const std::vector<float2> tw = twiddles(F::N);
     std::vector<float2> lds(F::LDS_ELEMS), mid_table(F::MID_TABLE + 1), tables((size_t)2 * parts * F::N);
     std::vector<float> h(2 * taps);
@@ -57,7 +57,7 @@ static int conv_impl(const float* x, long long n, const double* fir_mid, const d
     a.h_side = tables.data() + (size_t)parts * F::N;
     a.tw = tw.data();
     a.parts = parts;
-    a.npairs = (n + F::N - 1) / F::N;
+    a.npairs = (n + 2 * CB::LOUT - 1) / (2 * CB::LOUT);
     a.pair_peak = nullptr;
     float pk = 0.f;
     std::vector<typename CB::Kept> kept(F::T);
@@ -108,6 +108,16 @@ extern "C" int emu_convolve_blocked(const float* x, long long n, const double* f
 #define CASE(L) case L: return conv_impl<L>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
         CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
+        default: return -4;
+    }
+}
+// "wide" blocks: N = 4 * taps
+extern "C" int emu_convolve_wide(const float* x, long long n, const double* fir_mid, const double* fir_side,
+                                 int taps, double gain, float* y, float* ymid, double* peak) {
+    switch (ilog2_exact(taps) + 2) {
+        case 9: return conv_impl<9, 2>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
+        case 11: return conv_impl<11, 2>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
+        case 14: return conv_impl<14, 2>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
         default: return -4;
     }
 }

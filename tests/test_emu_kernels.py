@@ -87,6 +87,24 @@ def test_partitioned_convolution_phases(emu, taps, block_log2, n):
     assert abs(peak.value - np.abs(y).max()) <= 1e-6
 
 
+@pytest.mark.parametrize("taps,n", [(128, 3000), (512, 1), (512, 9000), (4096, 30000)])
+def test_wide_block_convolution_phases(emu, taps, n):
+    """Blocks of N = 4*taps (three quarters of every block are fresh output)."""
+    rng = np.random.RandomState(taps + n)
+    x = np.ascontiguousarray((0.3 * rng.randn(n, 2)).astype(np.float32))
+    hm, hs = rng.randn(taps) / np.sqrt(taps), rng.randn(taps) / np.sqrt(taps)
+    y = np.zeros((n, 2), dtype=np.float32)
+    ymid = np.zeros(n, dtype=np.float32)
+    peak = ctypes.c_double()
+    rc = emu.emu_convolve_wide(_fp(x), ctypes.c_longlong(n), _dp(hm), _dp(hs), ctypes.c_int(taps),
+                               ctypes.c_double(1.1), _fp(y), _fp(ymid), ctypes.byref(peak))
+    assert rc == 0
+    mid, side = mo.mid_side(x.astype(np.float64))
+    want, want_mid = mo.convolve_same(mid * 1.1, hm, side * 1.1, hs)
+    assert rms_error(y, want) <= 1e-6
+    assert rms_error(ymid, want_mid) <= 1e-6
+
+
 def test_convolution_identity(emu):
     # scipy "same" centring (match_frequencies.py:112): delta at (F-1)//2 is the identity
     rng = np.random.RandomState(5)
