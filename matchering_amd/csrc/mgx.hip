@@ -74,7 +74,7 @@ struct mgx_handle {
     std::map<int, float2*> twiddles;
     TrackWork track[2];
     DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars;
-    DevBuf lim_published, lim_ctrl, lim_weights, round_ctr;
+    DevBuf lim_published, lim_ctrl, lim_weights, round_ctr, band, band_info;
     std::vector<double> lim_weights_host;
     DevBuf fir_scratch;
     std::map<const FirPlanHost*, PlanDev> plan_dev;               // uploaded plan blobs + dense operators
@@ -559,7 +559,7 @@ int mgx_destroy(mgx_handle* h) {
     hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
-                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch, &h->round_ctr};
+                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch, &h->round_ctr, &h->band, &h->band_info};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (TrackWork& w : h->track) {
@@ -818,6 +818,11 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
             HIP_TRY(hipMemsetAsync(h->round_ctr.p, 0, h->round_ctr.bytes, h->stream));
         }
         ra.arrivals = (unsigned*)h->round_ctr.p;
+        const size_t wgs = (size_t)ra.divisions * ra.chunks;
+        MGX_TRY(ensure(h, h->band, ((size_t)n_target + wgs * BAND_SLACK) * sizeof(float)));
+        MGX_TRY(ensure(h, h->band_info, wgs * sizeof(BandInfo)));
+        ra.band = (float*)h->band.p;
+        ra.info = (BandInfo*)h->band_info.p;
         ra.reference_match_rms = &((const TrackStats*)rw.stats.p)->match_rms;
         ra.eps = cfg->min_value;
         ra.threshold = cfg->threshold;
@@ -827,6 +832,7 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         const int rounds = cfg->rms_correction_steps;
         for (int step = 0; step < rounds; ++step) {
             ra.final_peaks = step == rounds - 1 ? (const float*)h->block_peak.p : nullptr;
+            ra.build_band = step == 0 ? 1 : 0;
             hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, ra);
         }
         if (rounds == 0)

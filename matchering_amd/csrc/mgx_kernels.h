@@ -638,6 +638,24 @@ __global__ __launch_bounds__(1024) void k_correction_step(const double* partial,
 // (MI355X_MICROARCH.md, fanin / splitk-seam): partials are published write-through (sc1) and drained
 // before the ticket, the last arriver acquires before reading them.  With `final_peaks` the same
 // workgroup also derives the peak / limiter early-out / normalisation scalars (k_finalize_scalars).
+// Band bookkeeping of one workgroup's chunk (k_correction_round).  Every correction coefficient is
+// close to 1 (it is the ratio of two loudness estimates of nearly the same signal), so the
+// accumulated gain g stays inside [BAND_G_LO, BAND_G_HI].  For such g a sample with
+// |m| <= 1/BAND_G_HI is never clipped (contributes g^2 m^2), one with |m| > 1/BAND_G_LO always is
+// (contributes 1), and only the few samples in between -- the band -- need to be looked at again.
+// Round 0 streams the whole mid plane once, evaluates its own sum directly AND leaves
+// {sum of m^2 of the never-clipped, count of the always-clipped, the band's values compacted per
+// wave}; later rounds read just that (a few MB instead of 85) unless the gain has left the range,
+// in which case they stream the plane again.  The split is exact: sum min(g^2 m^2, 1) is the same
+// number either way, up to float64 summation order.
+constexpr double BAND_G_LO = 0.7, BAND_G_HI = 1.5;
+constexpr int BAND_SLACK = 2048;             // floats of padding per workgroup in the band buffer
+struct BandInfo {
+    double unclipped_sumsq;                  // A: sum of m^2 over |m| <= 1/BAND_G_HI
+    double clipped_count;                    // C: samples with |m| > 1/BAND_G_LO
+    int count[4];                            // band samples compacted by each of the four waves
+    int pad[2];
+};
 struct RoundArgs {
     const float* mid;
     long long piece;
@@ -649,6 +667,9 @@ struct RoundArgs {
     CorrectionState* cs;
     const float* final_peaks;   // per-pair peaks of the convolution, or null
     long long npeaks;
+    float* band;                // [n + workgroups * BAND_SLACK] compacted band samples
+    BandInfo* info;             // [workgroups]
+    int build_band;             // 1: round 0 (stream + build), 0: later rounds (use the band if g allows)
 };
 __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
     MGX_LDS;
@@ -660,29 +681,80 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
     const long long b = (long long)d * a.piece + ch * len;
     const long long e = min((long long)(d + 1) * a.piece, b + len);
     const double g = a.cs->gain;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // this workgroup's slice of the band buffer, one compacted list per wave
+    const long long wave_cap = (len + 3) / 4 + BAND_SLACK / 4 - 4;
+    float* wave_band = a.band + b + (long long)blockIdx.x * BAND_SLACK + wave * wave_cap;
+    BandInfo* info = a.info + blockIdx.x;
     double acc = 0.0;
     // float64 product then clip: the reference clips the float64 mid (dsp.py:109-110)
     auto add = [&](float v) {
         const double c = fmin(fmax((double)v * g, -1.0), 1.0);
         acc = fma(c, c, acc);
     };
-    // scalar head up to a 16-byte boundary, float4 body (64 B per thread in flight), scalar tail
-    const long long head = min(e, (b + 3) & ~3ll);
-    if (b + threadIdx.x < head) add(a.mid[b + threadIdx.x]);
-    const long long body_end = head + ((e - head) & ~3ll);
-    long long i = head + 4ll * threadIdx.x;
-    for (; i + 3 * 1024 < body_end; i += 4 * 1024) {
-        float4 v[4];
+    const bool use_band = !a.build_band && g >= BAND_G_LO && g <= BAND_G_HI;
+    if (use_band) {
+        const int count = info->count[wave];
+        for (int k = lane; k < count; k += 64) add(wave_band[k]);
+        if (threadIdx.x == 0) acc += g * g * info->unclipped_sumsq + info->clipped_count;
+    } else {
+        double low = 0.0, high = 0.0;
+        int filled = 0;                       // band samples this wave has stored: must stay wave-uniform,
+                                              // so every lane walks the same iterations and masks with `ok`
+        const unsigned long long below = (1ull << lane) - 1ull;
+        auto visit = [&](float v, bool ok) {
+            if (ok) add(v);
+            if (a.build_band) {
+                const double m = fabs((double)v);
+                const bool never = ok && m <= 1.0 / BAND_G_HI, always = ok && m > 1.0 / BAND_G_LO;
+                if (never) low = fma(m, m, low);
+                if (always) high += 1.0;
+                const bool in_band = ok && !never && !always;
+                const unsigned long long mask = __ballot(in_band);
+                if (in_band) wave_band[filled + __popcll(mask & below)] = v;
+                filled += __popcll(mask);
+            }
+        };
+        // scalar head up to a 16-byte boundary, float4 body (64 B per thread in flight), scalar tail
+        const long long head = min(e, (b + 3) & ~3ll);
+        {
+            const bool ok = b + threadIdx.x < head;
+            visit(ok ? a.mid[b + threadIdx.x] : 0.f, ok);
+        }
+        const long long body_end = head + ((e - head) & ~3ll);
+        for (long long s0 = head; s0 < body_end; s0 += 4 * 1024) {
+            float4 v[4];
+            bool ok[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(a.mid + i + u * 1024);
+            for (int u = 0; u < 4; ++u) {
+                const long long i = s0 + u * 1024 + 4ll * threadIdx.x;
+                ok[u] = i < body_end;
+                v[u] = ok[u] ? *reinterpret_cast<const float4*>(a.mid + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { add(v[u].x); add(v[u].y); add(v[u].z); add(v[u].w); }
+            for (int u = 0; u < 4; ++u) {
+                visit(v[u].x, ok[u]);
+                visit(v[u].y, ok[u]);
+                visit(v[u].z, ok[u]);
+                visit(v[u].w, ok[u]);
+            }
+        }
+        {
+            const bool ok = body_end + threadIdx.x < e;
+            visit(ok ? a.mid[body_end + threadIdx.x] : 0.f, ok);
+        }
+        if (a.build_band) {
+            if (lane == 0) info->count[wave] = filled;
+            const double lo = block_sum<256>(low, red);
+            __syncthreads();
+            const double hi = block_sum<256>(high, red + 8);
+            if (threadIdx.x == 0) {
+                info->unclipped_sumsq = lo;
+                info->clipped_count = hi;
+            }
+            __syncthreads();
+        }
     }
-    for (; i < body_end; i += 1024) {
-        const float4 v = *reinterpret_cast<const float4*>(a.mid + i);
-        add(v.x); add(v.y); add(v.z); add(v.w);
-    }
-    if (body_end + threadIdx.x < e) add(a.mid[body_end + threadIdx.x]);
     const double s = block_sum<256>(acc, red);
     if (threadIdx.x == 0) {
         // write-through 8-byte store + drained vmcnt instead of a release fence (a fence per workgroup
