@@ -218,13 +218,18 @@ def main():
 
             ocfg = mo.params(internal_sample_rate=args.sample_rate)
             need = (False, True, False) if args.workload == "8min_fir_only" else (True, False, False)
-            t0 = time.perf_counter()
-            mo.master(target, reference, ocfg, *need)
-            cpu_s = time.perf_counter() - t0
+            runs = []
+            t_all = time.perf_counter()
+            while len(runs) < 3 or (time.perf_counter() - t_all < 10.0 and len(runs) < 8):
+                t0 = time.perf_counter()
+                mo.master(target, reference, ocfg, *need)
+                runs.append(time.perf_counter() - t0)
+            cpu_s = min(runs)
             line["cpu_baseline"] = {"value": round(n / cpu_s / 1e6, 3), "unit": "Msamples/s", "cores": 1,
-                                    "kind": "port", "seconds": round(cpu_s, 2),
-                                    "sample": f"the same {args.seconds:.0f} s pair, one run of oracle/mastering_oracle.py "
-                                              f"(numpy/scipy float64 restatement of stages.main, single thread), "
+                                    "kind": "port", "seconds": round(cpu_s, 2), "runs": len(runs),
+                                    "sample": f"the same {args.seconds:.0f} s pair, best of {len(runs)} runs of "
+                                              f"oracle/mastering_oracle.py (numpy/scipy float64 restatement of "
+                                              f"stages.main, single thread; {sum(runs):.0f} s of CPU work), "
                                               f"host has {os.cpu_count()} logical cores"}
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
     if ranks.rank == 0:

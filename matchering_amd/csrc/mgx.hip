@@ -345,9 +345,15 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     // the cosine table rides in LDS when it fits (F <= 8192), otherwise it is read through L2
     const bool cos_in_lds = ((size_t)pl.fft + pl.bins + 1024) * sizeof(double) <= (size_t)150 * 1024;
     const size_t lds_taps = ((cos_in_lds ? (size_t)pl.fft : 0) + pl.bins + 1024) * sizeof(double);
-    MGX_TRY(allow_lds(k_fir_taps, lds_taps));
-    hipLaunchKernelGGL(k_fir_taps, dim3(pl.fft / 64, 2), dim3(1024), lds_taps, h->stream, pl, (const double*)scratch,
-                       (float*)h->taps.p, cos_in_lds ? 1 : 0);
+    if (cos_in_lds) {
+        MGX_TRY(allow_lds(k_fir_taps<true>, lds_taps));
+        hipLaunchKernelGGL(k_fir_taps<true>, dim3(pl.fft / 64, 2), dim3(1024), lds_taps, h->stream, pl,
+                           (const double*)scratch, (float*)h->taps.p);
+    } else {
+        MGX_TRY(allow_lds(k_fir_taps<false>, lds_taps));
+        hipLaunchKernelGGL(k_fir_taps<false>, dim3(pl.fft / 64, 2), dim3(1024), lds_taps, h->stream, pl,
+                           (const double*)scratch, (float*)h->taps.p);
+    }
     HIP_TRY(hipGetLastError());
     h->last_taps = cfg->fft_size;
     return 0;

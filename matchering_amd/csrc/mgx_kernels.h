@@ -536,19 +536,18 @@ __global__ __launch_bounds__(1024) void k_fir_b(FirPlanView pl, double* scratch)
 }
 // irfft + ifftshift + Hann (match_frequencies.py:98-99).  grid = (F/64, 2); a workgroup
 // computes 64 taps, 16 lanes each summing a slice of the bins.
-__global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double* scratch, float* taps /* [2][F] */,
-                                                   int cos_in_lds) {
+template <bool COS_IN_LDS>
+__global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double* scratch, float* taps /* [2][F] */) {
     MGX_LDS;
     double* sm = reinterpret_cast<double*>(mgx_smem);       // [bins]
     double* red = sm + pl.bins;                             // [1024]
     double* cos_lds = red + 1024;                           // [F] when it fits
     const int plane = blockIdx.y, f = pl.fft, half = f / 2;
     const FirScratch s = fir_scratch(const_cast<double*>(scratch), pl, plane);
-    if (cos_in_lds)
+    if (COS_IN_LDS)
         for (int i = threadIdx.x; i < f; i += 1024) cos_lds[i] = pl.cos_table[i];
     for (int i = threadIdx.x; i < pl.bins; i += 1024) sm[i] = s.smooth[i];
     __syncthreads();
-    const double* cosv = cos_in_lds ? cos_lds : pl.cos_table;
     const int i = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
     const int mm = (i + half) & (f - 1);
     const int per = (half - 1 + 15) / 16;                   // bins 1 .. half-1 split over 16 lanes
@@ -556,7 +555,7 @@ __global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double*
     double acc = 0.0;
     int idx = (int)(((long long)k0 * mm) & (f - 1));
     for (int k = k0; k < k1; ++k) {
-        acc = fma(sm[k], cosv[idx], acc);
+        acc = fma(sm[k], COS_IN_LDS ? cos_lds[idx] : pl.cos_table[idx], acc);
         idx = (idx + mm) & (f - 1);
     }
     red[threadIdx.x] = acc;
