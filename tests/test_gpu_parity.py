@@ -243,3 +243,39 @@ def test_process_files_end_to_end(tmp_path):
     assert rms_error(audio_io.read_wav(outs["norm"])[0], want[2]) <= RMS_TOL
     assert audio_io.read_wav(outs["pr"])[0].shape == (6 * sr, 2)
     assert audio_io.read_wav(outs["pt"])[0].shape == (6 * sr, 2)
+
+
+def test_rccl_single_rank_collectives():
+    """The FIR exchange of the multi-GPU path (mgx_comm_*, RCCL) on a one-rank communicator: the
+    calls, the stream ordering and the payload (the FIR designed by the last mgx_master) are the ones
+    bench.py uses with N ranks; only the number of peers differs."""
+    import ctypes
+
+    from matchering_amd._native import check, library
+    from matchering_amd.device import default_device
+    import matchering_amd as mg
+
+    lib = library()
+    dev = default_device()
+    t, r = build_inputs(CASES["quiet_reference"])
+    cfg = make_config(CASES["quiet_reference"]["config"])
+    td, rd = dev.upload(t), dev.upload(r)
+    out = dev.alloc(t.shape[0] * 8)
+    dev.master(td, t.shape[0], rd, r.shape[0], cfg.to_native(), result=None, result_no_limiter=out)
+    uid = ctypes.create_string_buffer(128)
+    check(lib.mgx_comm_unique_id(uid))
+    check(lib.mgx_comm_init(dev.handle, uid, 0, 1))
+    try:
+        taps_dev, taps = ctypes.c_void_p(), ctypes.c_int32()
+        check(lib.mgx_last_fir(dev.handle, ctypes.byref(taps_dev), ctypes.byref(taps)))
+        assert taps.value == cfg.fft_size
+        count = 2 * taps.value
+        table = dev.alloc(count * 4)
+        check(lib.mgx_comm_allgather_f32(dev.handle, taps_dev, ctypes.c_void_p(table.ptr), count))
+        check(lib.mgx_comm_broadcast_f32(dev.handle, ctypes.c_void_p(table.ptr), count, 0))
+        dev.synchronize()
+        own = dev.download(int(taps_dev.value), (2, taps.value))
+        got = dev.download(table, (2, taps.value))
+        assert np.array_equal(own, got) and np.all(np.isfinite(own)) and np.abs(own).max() > 0
+    finally:
+        check(lib.mgx_comm_destroy(dev.handle))
