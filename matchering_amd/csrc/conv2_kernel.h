@@ -28,6 +28,26 @@
 
 namespace mgx {
 
+// Cache policy of the streaming accesses.  The output is stored non-temporal (aux 2): it is not read
+// again by this kernel and must not push the input frames out of the L2 before their second use
+// (measured 197 -> 175 us and 70 MB less fetched per 8-minute track).  Non-temporal or sc0 LOADS were
+// measured slower (198 / 186 us) and stay at the default policy; the macros remain for experiments.
+#ifndef MGX_CONV_ST_AUX
+#define MGX_CONV_ST_AUX 2
+#endif
+#ifndef MGX_CONV_LD2_AUX
+#define MGX_CONV_LD2_AUX 0
+#endif
+#ifndef MGX_CONV_ONE_LOAD_PATH
+#define MGX_CONV_ONE_LOAD_PATH 1
+#endif
+#ifndef MGX_CONV_LD1_AUX
+#define MGX_CONV_LD1_AUX 0
+#endif
+#ifndef MGX_CONV_H_AUX
+#define MGX_CONV_H_AUX 0
+#endif
+
 struct Conv2Args {
     const float2* x;       // (n,2) interleaved L/R input frames
     long long n;           // frames
@@ -39,14 +59,18 @@ struct Conv2Args {
     int parts;             // filter partitions K: taps = K * N/2 (1 = plain overlap-save)
     long long npairs;      // ceil(n / N)
     float* pair_peak;      // [npairs] max(|yL|,|yR|) per pair, or nullptr
+#ifdef MGX_CONV_STAMPS
+    long long* stamps;     // [workgroups][8 pairs][32] s_memtime values (timing experiments)
+#endif
 };
 
 // TSHIFT: taps per block = N >> TSHIFT.  1 = the usual N = 2F (half of every block is fresh output);
 // 2 = "wide" blocks N = 4F (three quarters fresh: 28 % less transform work per frame, but a
 // 16384-point block for F = 4096 allows only one workgroup per CU).
-template <int LOG2N, int TSHIFT = 1>
+// V: transform plan variant (fft2.h); 1 = twice the threads, half the registers each.
+template <int LOG2N, int TSHIFT = 1, int V = 0>
 struct Conv2Block {
-    using F = Fft2<LOG2N>;
+    using F = Fft2<LOG2N, V>;
     static constexpr int N = F::N;
     static constexpr int T = F::T;
     static constexpr int TAPS = N >> TSHIFT;
@@ -90,46 +114,105 @@ struct Conv2Block {
                first_output(pair) + 2 * LOUT <= n;
     }
 
-    // ---- phase F0: global -> registers -> pass 0 -> LDS, channel SIDE ? side : mid --------
-    // `edge` is uniform over the workgroup: only pairs touching the ends of the track pay for
-    // bounds checks.
-    template <bool SIDE>
-    static MGX_HD void phase_load(int tid, long long pair, bool edge, const Conv2Args& a, const Persist& ps,
-                                  float2* lds, int part = 0) {
+    // ---- phase F0: global -> registers -> pass 0 -> LDS ----------------------------------------
+    // Split in two so that the kernel can issue the loads one or two phases before it needs the
+    // frames (software pipelining: a workgroup's memory and arithmetic phases would otherwise
+    // simply alternate): fetch_frames() only issues the loads into `raw`, phase_pass0() consumes
+    // them.  `edge` is uniform over the workgroup: only pairs touching the ends of the track pay
+    // for bounds checks.
+    struct Raw {
+        float2 f[CNT0][NLOAD];
+    };
+    // C0, C1: which of the thread's CNT0 butterflies to fetch for ([C0, C1))
+    template <int AUX = 0, int C0 = 0, int C1 = CNT0>
+    static MGX_HD void fetch_frames(int tid, long long pair, bool edge, const Conv2Args& a, int part, Raw& raw) {
         if (!active0(tid)) return;
         const long long i0 = first_input(pair, a.parts, part);
+        MGX_UNROLL
+        for (int c = C0; c < C1; ++c) {
+            const int u = tid + c * T;
+            // one 32-bit lane offset (mgx_hd.h MemView); frames outside the track read as zeros
+            const MemView src = mem_view(a.x, a.n * 8);
+            const unsigned lane = ((unsigned)i0 + (unsigned)u) * 8u;
+#if MGX_CONV_ONE_LOAD_PATH
+            MGX_UNROLL
+            for (int j = 0; j < NLOAD; ++j) raw.f[c][j] = ld_f2_or_zero<AUX>(src, lane + (unsigned)(j * S0 * 8));
+#else
+            if (edge) {
+                MGX_UNROLL
+                for (int j = 0; j < NLOAD; ++j) raw.f[c][j] = ld_f2_or_zero<AUX>(src, lane + (unsigned)(j * S0 * 8));
+            } else {
+                MGX_UNROLL
+                for (int j = 0; j < NLOAD; ++j) raw.f[c][j] = ld_f2<AUX>(src, lane, (unsigned)(j * S0 * 8));   // literal displacements
+            }
+#endif
+        }
+    }
+    // mid/side of the fetched frames (dsp.py:57-64), the two blocks of the pair packed into one
+    // complex sequence, pass 0 -> LDS.  The mid pass also forms the side samples and leaves them in
+    // `held` (NLOAD*CNT0 floats) for the side pass, which then needs no second read of the frames.
+    struct Held {
+        float s[CNT0][NLOAD];
+    };
+    static MGX_HD void phase_pass0_mid(int tid, const Raw& raw, const Persist& ps, float2* lds, Held& held) {
+        if (!active0(tid)) return;
         typename F::Tw0Full tw;
         F::expand_tw0(ps.tw0, tw);
         MGX_UNROLL
         for (int c = 0; c < CNT0; ++c) {
-            const int u = tid + c * T;
-            float2 f[NLOAD];
-            if (edge) {
-                MGX_UNROLL
-                for (int j = 0; j < NLOAD; ++j) {
-                    const long long g = i0 + u + (long long)j * S0;
-                    const bool ok = g >= 0 && g < a.n;
-                    const float2 t = a.x[ok ? g : 0];
-                    f[j] = make_float2(ok ? t.x : 0.f, ok ? t.y : 0.f);
-                }
-            } else {
-                // uniform displacement + one 32-bit lane offset (mgx_hd.h MemView)
-                const MemView src = mem_view(a.x, a.n * 8);
-                const unsigned lane = ((unsigned)i0 + (unsigned)u) * 8u;     // displacements below are literals
-                MGX_UNROLL
-                for (int j = 0; j < NLOAD; ++j) f[j] = ld_f2(src, lane, (unsigned)(j * S0 * 8));
-            }
             float ch[NLOAD];
             MGX_UNROLL
             for (int j = 0; j < NLOAD; ++j) {
-                const float m = (f[j].x + f[j].y) * 0.5f;        // dsp.py:59-60
-                ch[j] = SIDE ? m - f[j].y : m;                   // dsp.py:62
+                const float2 f = raw.f[c][j];
+                ch[j] = (f.x + f.y) * 0.5f;                      // dsp.py:59-60
+                held.s[c][j] = ch[j] - f.y;                      // dsp.py:62
             }
             float2 v[R0];
             MGX_UNROLL
             for (int j = 0; j < R0; ++j) v[j] = make_float2(ch[j], ch[j + BSTEP]);
             F::fwd0_store(v, tid, c, tw, lds);
         }
+    }
+    static MGX_HD void phase_pass0_side(int tid, const Held& held, const Persist& ps, float2* lds) {
+        if (!active0(tid)) return;
+        typename F::Tw0Full tw;
+        F::expand_tw0(ps.tw0, tw);
+        MGX_UNROLL
+        for (int c = 0; c < CNT0; ++c) {
+            float2 v[R0];
+            MGX_UNROLL
+            for (int j = 0; j < R0; ++j) v[j] = make_float2(held.s[c][j], held.s[c][j + BSTEP]);
+            F::fwd0_store(v, tid, c, tw, lds);
+        }
+    }
+    // one channel straight from the frames (filter partitions: a different window per partition)
+    template <bool SIDE>
+    static MGX_HD void phase_pass0(int tid, const Raw& raw, const Persist& ps, float2* lds) {
+        if (!active0(tid)) return;
+        typename F::Tw0Full tw;
+        F::expand_tw0(ps.tw0, tw);
+        MGX_UNROLL
+        for (int c = 0; c < CNT0; ++c) {
+            float ch[NLOAD];
+            MGX_UNROLL
+            for (int j = 0; j < NLOAD; ++j) {
+                const float2 f = raw.f[c][j];
+                const float m = (f.x + f.y) * 0.5f;
+                ch[j] = SIDE ? m - f.y : m;
+            }
+            float2 v[R0];
+            MGX_UNROLL
+            for (int j = 0; j < R0; ++j) v[j] = make_float2(ch[j], ch[j + BSTEP]);
+            F::fwd0_store(v, tid, c, tw, lds);
+        }
+    }
+    // both at once (filter partitions, tests)
+    template <bool SIDE>
+    static MGX_HD void phase_load(int tid, long long pair, bool edge, const Conv2Args& a, const Persist& ps,
+                                  float2* lds, int part = 0) {
+        Raw raw;
+        fetch_frames<SIDE ? MGX_CONV_LD2_AUX : MGX_CONV_LD1_AUX>(tid, pair, edge, a, part, raw);
+        phase_pass0<SIDE>(tid, raw, ps, lds);
     }
 
     // ---- middle passes --------------------------------------------------------------------------
@@ -150,7 +233,7 @@ struct Conv2Block {
         if (!F::has_row(tid)) return;
         const MemView hv = mem_view(h, (long long)N * 8);
         MGX_UNROLL
-        for (int q = 0; q < RL; ++q) f.h[q] = ld_f2(hv, (unsigned)tid * 8u, (unsigned)(q * F::L * 8));
+        for (int q = 0; q < RL; ++q) f.h[q] = ld_f2<MGX_CONV_H_AUX>(hv, (unsigned)tid * 8u, (unsigned)(q * F::L * 8));
     }
     static MGX_HD void phase_filter(int tid, const RowFilter& f, float2* lds) {
         if (!F::has_row(tid)) return;
@@ -207,7 +290,85 @@ struct Conv2Block {
     }
 
     // ---- phase I0 (side channel) + epilogue: L = mid + side, R = mid - side (dsp.py:67-68) ----
+    // In two steps -- all output frames into registers, then all stores -- so that the kernel can
+    // issue the next pair's loads in between: ahead of the stores in the memory queue, and at the
+    // point where the fewest registers are live.
+    struct Outputs {
+        float2 ya[CNT0][HALF], yb[CNT0][HALF];        // (L, R) of blocks A and B
+    };
+    static MGX_HD void outputs_of(int tid, int c, const typename F::Tw0Full& tw, const float2* lds, const Kept& k,
+                                  Outputs& o) {
+        float2 v[R0];
+        F::inv0_load(v, tid, c, tw, lds);
+        MGX_UNROLL
+        for (int j = 0; j < HALF; ++j) {
+            const float2 m = k.v[c][j], s = v[SKIP + j];
+            o.ya[c][j] = make_float2(m.x + s.x, m.x - s.x);
+            o.yb[c][j] = make_float2(m.y + s.y, m.y - s.y);
+        }
+    }
+    static MGX_HD void phase_outputs(int tid, const Persist& ps, const float2* lds, const Kept& k, Outputs& o) {
+        if (!active0(tid)) return;
+        typename F::Tw0Full tw;
+        F::expand_tw0(ps.tw0, tw);
+        MGX_UNROLL
+        for (int c = 0; c < CNT0; ++c) outputs_of(tid, c, tw, lds, k, o);
+    }
     // returns this thread's max(|yL|,|yR|) over the frames it stored
+    static MGX_HD float store_outputs(int tid, long long pair, bool edge, const Conv2Args& a, const Kept& k,
+                                      const Outputs& o) {
+        float peak = 0.f;
+        if (!active0(tid)) return peak;
+        MGX_UNROLL
+        for (int c = 0; c < CNT0; ++c) peak = fmaxf(peak, store_outputs_of(tid, c, pair, edge, a, k, o));
+        return peak;
+    }
+    static MGX_HD float store_outputs_of(int tid, int c, long long pair, bool edge, const Conv2Args& a, const Kept& k,
+                                         const Outputs& o) {
+        float peak = 0.f;
+        const long long o0 = first_output(pair);
+        {
+            const int u = tid + c * T;
+            const long long oa = o0 + u;
+            if (edge) {
+                MGX_UNROLL
+                for (int j = 0; j < HALF; ++j) {
+                    const long long fa = oa + (long long)j * S0, fb = fa + LOUT;
+                    if (fa < a.n) {
+                        a.y[fa] = o.ya[c][j];
+                        if (a.ymid) a.ymid[fa] = k.v[c][j].x;
+                        peak = fmaxf(peak, fmaxf(fabsf(o.ya[c][j].x), fabsf(o.ya[c][j].y)));
+                    }
+                    if (fb < a.n) {
+                        a.y[fb] = o.yb[c][j];
+                        if (a.ymid) a.ymid[fb] = k.v[c][j].y;
+                        peak = fmaxf(peak, fmaxf(fabsf(o.yb[c][j].x), fabsf(o.yb[c][j].y)));
+                    }
+                }
+            } else {
+                const MemView dst = mem_view(a.y, a.n * 8);
+                const unsigned lane = ((unsigned)o0 + (unsigned)u) * 8u;
+                MGX_UNROLL
+                for (int j = 0; j < HALF; ++j) {
+                    st_f2<MGX_CONV_ST_AUX>(dst, lane, (unsigned)(j * S0 * 8), o.ya[c][j]);
+                    st_f2<MGX_CONV_ST_AUX>(dst, lane, (unsigned)((j * S0 + LOUT) * 8), o.yb[c][j]);
+                    peak = fmaxf(peak, fmaxf(fmaxf(fabsf(o.ya[c][j].x), fabsf(o.ya[c][j].y)),
+                                             fmaxf(fabsf(o.yb[c][j].x), fabsf(o.yb[c][j].y))));
+                }
+                if (a.ymid) {
+                    const MemView dm = mem_view(a.ymid, a.n * 4);
+                    const unsigned lane4 = ((unsigned)o0 + (unsigned)u) * 4u;
+                    MGX_UNROLL
+                    for (int j = 0; j < HALF; ++j) {
+                        st_f1<MGX_CONV_ST_AUX>(dm, lane4, (unsigned)(j * S0 * 4), k.v[c][j].x);
+                        st_f1<MGX_CONV_ST_AUX>(dm, lane4, (unsigned)((j * S0 + LOUT) * 4), k.v[c][j].y);
+                    }
+                }
+            }
+        }
+        return peak;
+    }
+    // both steps butterfly by butterfly (fewer registers live at once)
     static MGX_HD float phase_store(int tid, long long pair, bool edge, const Conv2Args& a, const Persist& ps,
                                     const float2* lds, const Kept& k) {
         float peak = 0.f;
@@ -248,8 +409,8 @@ struct Conv2Block {
                 const unsigned lane = ((unsigned)o0 + (unsigned)u) * 8u;
                 MGX_UNROLL
                 for (int j = 0; j < HALF; ++j) {
-                    st_f2(dst, lane, (unsigned)(j * S0 * 8), ya[j]);
-                    st_f2(dst, lane, (unsigned)((j * S0 + LOUT) * 8), yb[j]);
+                    st_f2<MGX_CONV_ST_AUX>(dst, lane, (unsigned)(j * S0 * 8), ya[j]);
+                    st_f2<MGX_CONV_ST_AUX>(dst, lane, (unsigned)((j * S0 + LOUT) * 8), yb[j]);
                     peak = fmaxf(peak, fmaxf(fmaxf(fabsf(ya[j].x), fabsf(ya[j].y)),
                                              fmaxf(fabsf(yb[j].x), fabsf(yb[j].y))));
                 }
@@ -258,8 +419,8 @@ struct Conv2Block {
                     const unsigned lane4 = ((unsigned)o0 + (unsigned)u) * 4u;
                     MGX_UNROLL
                     for (int j = 0; j < HALF; ++j) {
-                        st_f1(dm, lane4, (unsigned)(j * S0 * 4), k.v[c][j].x);
-                        st_f1(dm, lane4, (unsigned)((j * S0 + LOUT) * 4), k.v[c][j].y);
+                        st_f1<MGX_CONV_ST_AUX>(dm, lane4, (unsigned)(j * S0 * 4), k.v[c][j].x);
+                        st_f1<MGX_CONV_ST_AUX>(dm, lane4, (unsigned)((j * S0 + LOUT) * 4), k.v[c][j].y);
                     }
                 }
             }

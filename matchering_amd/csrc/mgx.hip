@@ -180,7 +180,7 @@ static int analysis_workgroups_per_cu(int log2f) {
         default: return 1;
     }
     const int by_lds = (int)((size_t)160 * 1024 / lds), by_waves = 2048 / threads;
-    return std::max(1, std::min(8, std::min(by_lds, by_waves)));
+    return std::max(1, std::min(MGX_ANALYZE_MAX_WGS, std::min(by_lds, by_waves)));
 }
 
 template <int LOG2N>
@@ -359,14 +359,14 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     return 0;
 }
 
-template <int LOG2N, bool MULTI, int TSHIFT = 1>
+template <int LOG2N, bool MULTI, int TSHIFT = 1, int V = 0>
 static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr,
                        int repeat) {
-    using F = Fft2<LOG2N>;
-    const size_t lds = conv_lds_bytes<LOG2N>();
-    MGX_TRY((allow_lds(k_conv_prep<LOG2N, TSHIFT>, lds)));
-    MGX_TRY((allow_lds(k_conv<LOG2N, MULTI, TSHIFT>, lds)));
-    hipLaunchKernelGGL((k_conv_prep<LOG2N, TSHIFT>), dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev, a.tw,
+    using F = Fft2<LOG2N, V>;
+    const size_t lds = conv_lds_bytes<LOG2N, V>();
+    MGX_TRY((allow_lds(k_conv_prep<LOG2N, TSHIFT, V>, lds)));
+    MGX_TRY((allow_lds(k_conv<LOG2N, MULTI, TSHIFT, V>, lds)));
+    hipLaunchKernelGGL((k_conv_prep<LOG2N, TSHIFT, V>), dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev, a.tw,
                        (float2*)h->filt.p, a.parts, gain_ptr, gain);
     HIP_TRY(hipGetLastError());
     MGX_TRY(ensure(h, h->block_peak, (size_t)a.npairs * sizeof(float)));
@@ -377,9 +377,27 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
     const int per_cu = std::max(1, std::min(2048 / F::T, (int)((size_t)160 * 1024 / lds)));
     const long long cap = (long long)dev_cus * per_cu;
     const unsigned grid = (unsigned)(((std::min<long long>(a.npairs, cap) + 7) / 8) * 8);
+#ifdef MGX_CONV_STAMPS
+    static long long* stamps_dev = nullptr;
+    const size_t stamp_words = (size_t)grid * 8 * 32;
+    if (!stamps_dev) HIP_TRY(hipMalloc(&stamps_dev, (size_t)4096 * 8 * 32 * sizeof(long long)));
+    HIP_TRY(hipMemsetAsync(stamps_dev, 0, stamp_words * sizeof(long long), h->stream));
+    a.stamps = stamps_dev;
+#endif
     if (repeat > 1) HIP_TRY(hipEventRecord(h->ev0, h->stream));
     for (int r = 0; r < repeat; ++r)
-        hipLaunchKernelGGL((k_conv<LOG2N, MULTI, TSHIFT>), dim3(grid), dim3(F::T), lds, h->stream, a);
+        hipLaunchKernelGGL((k_conv<LOG2N, MULTI, TSHIFT, V>), dim3(grid), dim3(F::T), lds, h->stream, a);
+#ifdef MGX_CONV_STAMPS
+    if (const char* path = std::getenv("MGX_STAMPS_OUT")) {
+        std::vector<long long> host(stamp_words);
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(host.data(), stamps_dev, stamp_words * sizeof(long long), hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(path, "wb")) {
+            std::fwrite(host.data(), sizeof(long long), stamp_words, f);
+            std::fclose(f);
+        }
+    }
+#endif
     if (repeat > 1) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipGetLastError());
     return 0;
@@ -416,6 +434,8 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     a.pair_peak = nullptr;
     MGX_TRY(get_twiddles(h, log2b, &a.tw));
     if (npairs_out) *npairs_out = a.npairs;
+    static const bool thin = std::getenv("MGX_EXP_CONV_THIN") != nullptr;
+    if (thin && parts == 1 && log2b == 13) return launch_conv<13, false, 1, 1>(h, a, taps_dev, gain, gain_ptr, repeat);
     if (parts > 1) {
         if (log2b == 13) return launch_conv<13, true>(h, a, taps_dev, gain, gain_ptr, repeat);
         if (log2b == 10) return launch_conv<10, true>(h, a, taps_dev, gain, gain_ptr, repeat);
@@ -796,8 +816,10 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     // stage 1 (stages.py:38-104): both tracks analysed in one pass each
     TrackWork& tw = h->track[0];
     TrackWork& rw = h->track[1];
+    static const bool ref_first = std::getenv("MGX_EXP_REF_FIRST") != nullptr;
+    if (ref_first) MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
     MGX_TRY(run_analysis(h, target_dev, n_target, cfg, 0, tw));
-    MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
+    if (!ref_first) MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
     MGX_TRY(run_levels(h, cfg, &tw, &rw));
     // stage 2 (stages.py:107-135): FIR design on the device, then the overlap-save convolution with
     // the level gain of stages.py:80-88 (a device scalar) folded into the filter spectra

@@ -69,33 +69,59 @@ __device__ __forceinline__ MemView mem_view(const void* p, long long bytes) {
                                             0x00020000);
     return v;
 }
+// AUX: cache-policy bits of the buffer instruction (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX = 0>
 __device__ __forceinline__ float2 ld_f2(MemView m, unsigned voff, unsigned soff) {
     typedef unsigned u2_t __attribute__((ext_vector_type(2)));
-    const u2_t t = __builtin_amdgcn_raw_buffer_load_b64(m.r, voff, soff, 0);
+    const u2_t t = __builtin_amdgcn_raw_buffer_load_b64(m.r, voff, soff, AUX);
     const unsigned a = t.x, b = t.y;
     return make_float2(__uint_as_float(a), __uint_as_float(b));
 }
+// Load whose lane offset may lie outside the view (before its start the 32-bit offset has wrapped to
+// ~4 G, past its end it exceeds the size): the buffer range check returns zeros for such lanes, which
+// is exactly the zero padding a convolution wants at the ends of a track.  The whole offset sits in
+// the VGPR so that the check sees all of it.
+template <int AUX = 0>
+__device__ __forceinline__ float2 ld_f2_or_zero(MemView m, unsigned voff) {
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    const u2_t t = __builtin_amdgcn_raw_buffer_load_b64(m.r, voff, 0, AUX);
+    const unsigned a = t.x, b = t.y;
+    return make_float2(__uint_as_float(a), __uint_as_float(b));
+}
+template <int AUX = 0>
 __device__ __forceinline__ void st_f2(MemView m, unsigned voff, unsigned soff, float2 v) {
     typedef unsigned u2_t __attribute__((ext_vector_type(2)));
     u2_t t;
     t.x = __float_as_uint(v.x);
     t.y = __float_as_uint(v.y);
-    __builtin_amdgcn_raw_buffer_store_b64(t, m.r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(t, m.r, voff, soff, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void st_f1(MemView m, unsigned voff, unsigned soff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), m.r, voff, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), m.r, voff, soff, AUX);
 }
 #else
 struct MemView {
     char* p;
+    unsigned long long bytes;
 };
-inline MemView mem_view(const void* p, long long) { return MemView{const_cast<char*>(static_cast<const char*>(p))}; }
+inline MemView mem_view(const void* p, long long bytes) {
+    return MemView{const_cast<char*>(static_cast<const char*>(p)), (unsigned long long)bytes};
+}
+template <int AUX = 0>
+inline float2 ld_f2_or_zero(MemView m, unsigned voff) {
+    if ((unsigned long long)voff + 8 > m.bytes) return float2{0.f, 0.f};
+    return *reinterpret_cast<const float2*>(m.p + (size_t)voff);
+}
+template <int AUX = 0>
 inline float2 ld_f2(MemView m, unsigned voff, unsigned soff) {
     return *reinterpret_cast<const float2*>(m.p + (size_t)voff + (size_t)soff);
 }
+template <int AUX = 0>
 inline void st_f2(MemView m, unsigned voff, unsigned soff, float2 v) {
     *reinterpret_cast<float2*>(m.p + (size_t)voff + (size_t)soff) = v;
 }
+template <int AUX = 0>
 inline void st_f1(MemView m, unsigned voff, unsigned soff, float v) {
     *reinterpret_cast<float*>(m.p + (size_t)voff + (size_t)soff) = v;
 }

@@ -58,77 +58,187 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // ---------------------------------------------------------------------------
 // convolution
 // ---------------------------------------------------------------------------
-template <int LOG2N>
+template <int LOG2N, int V = 0>
 constexpr size_t conv_lds_bytes() {
-    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 64;
+    return ((size_t)Fft2<LOG2N, V>::LDS_ELEMS + Fft2<LOG2N, V>::MID_TABLE) * sizeof(float2) + 64;
 }
 
-// one pair of output blocks: mid channel, then side channel + epilogue (conv2_kernel.h)
-template <int LOG2N, bool SIDE, bool MULTI, int TSHIFT>
-__device__ __forceinline__ void conv_channel(int tid, long long pair, bool edge, const Conv2Args& a,
-                                             const typename Conv2Block<LOG2N, TSHIFT>::Persist& ps, float2* lds,
-                                             const float2* mid_table) {
-    using CB = Conv2Block<LOG2N, TSHIFT>;
-    using F = Fft2<LOG2N>;
+// The phases of a kernel share index arithmetic (LDS addresses derived from the thread id).  Left
+// alone, the compiler computes it once and keeps dozens of addresses alive across the whole
+// kernel -- in scratch memory once the registers run out.  An empty asm makes the id opaque so
+// that each phase re-derives its few addresses instead (the same goes for loop-invariant LDS
+// table reads: hoisted out of a persistent loop they would live in scratch).
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+// workgroups of k_conv a CU holds (LDS and thread limits), and the waves per SIMD that makes: the
+// register budget the kernel is compiled for
+template <int LOG2N, int V = 0>
+constexpr int conv_workgroups_per_cu() {
+    constexpr int by_lds = (int)((size_t)160 * 1024 / conv_lds_bytes<LOG2N, V>());
+    constexpr int by_threads = 2048 / Fft2<LOG2N, V>::T;
+    constexpr int w = by_lds < by_threads ? by_lds : by_threads;
+    return w < 1 ? 1 : (w > 2 ? 2 : w);             // more than two co-resident transforms do not pay
+}
+template <int LOG2N, int V = 0>
+constexpr int conv_waves_per_simd() {
+    constexpr int w = conv_workgroups_per_cu<LOG2N, V>() * (Fft2<LOG2N, V>::T / 64) / 4;
+    return w < 2 ? 2 : w;
+}
+
+// Phase timeline (timing experiments only: -DMGX_CONV_STAMPS): thread 0 records s_memtime at every
+// phase boundary of its first pairs; tools/conv_stamps.py turns the dump into a table.
+struct Stamper {
+#ifdef MGX_CONV_STAMPS
+    long long* p;
+    int i;
+    __device__ __forceinline__ void mark(int tid) {
+        if (tid == 0 && p) p[i] = (long long)__builtin_amdgcn_s_memtime();
+        ++i;
+    }
+#else
+    __device__ __forceinline__ void mark(int) {}
+#endif
+};
+
+// Software pipelining of the frame loads: how many of a thread's CNT0 pass-0 butterflies get their
+// frames fetched one pair ahead (issued between the epilogue's arithmetic and its stores, so that they
+// are in flight while the stores drain).  Off: at the 256 registers two workgroups per CU leave a
+// wave, the 2*NLOAD registers per butterfly in flight make the 8192-point kernel spill, and a
+// spilling kernel is far slower than an unpipelined one (measured 294 vs 153 us with everything
+// ahead).  Kept as an experiment switch (-DMGX_CONV_AHEAD=1).
+#ifndef MGX_CONV_AHEAD
+#define MGX_CONV_AHEAD 0
+#endif
+template <int LOG2N, bool MULTI, int TSHIFT, int V>
+constexpr int conv_ahead() {
+    constexpr int cnt = Conv2Block<LOG2N, TSHIFT, V>::CNT0;
+    return MULTI ? 0 : (MGX_CONV_AHEAD < cnt ? MGX_CONV_AHEAD : cnt);
+}
+
+// One channel of one pair, from pass 0 (`pass0`) up to the inverse middle pass (conv2_kernel.h).
+template <int LOG2N, bool SIDE, int TSHIFT, int V, class Pass0>
+__device__ __forceinline__ void conv_channel(int tid, const Conv2Args& a, float2* lds, const float2* mid_table,
+                                             Stamper& sm, Pass0 pass0) {
+    using CB = Conv2Block<LOG2N, TSHIFT, V>;
+    using F = Fft2<LOG2N, V>;
+    typename CB::RowFilter rf;
+    pass0();
+    // (the scheduler must not lift the filter loads above pass 0: there is no room for them yet)
+    __builtin_amdgcn_sched_barrier(0);
+    CB::fetch_filter(tid, SIDE ? a.h_side : a.h_mid, rf);      // a phase early: the middle pass hides its latency
+    sm.mark(tid);
+    __syncthreads();
+    sm.mark(tid);
+    if (F::P == 3) {
+        CB::phase_fwd_mid(opaque(tid), lds, mid_table);
+        sm.mark(tid);
+        __syncthreads();
+        sm.mark(tid);
+    }
+    CB::phase_filter(tid, rf, lds);
+    sm.mark(tid);
+    __syncthreads();
+    sm.mark(tid);
+    if (F::P == 3) {
+        CB::phase_inv_mid(opaque(tid), lds, mid_table);
+        sm.mark(tid);
+        __syncthreads();
+        sm.mark(tid);
+    }
+    __builtin_amdgcn_sched_barrier(0);      // keeps the next phase's LDS reads from being lifted into this one
+}
+// uniformly partitioned overlap-save: one forward transform per filter partition, products
+// accumulated on the thread's row, one inverse transform
+template <int LOG2N, bool SIDE, int TSHIFT, int V>
+__device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair, bool edge, const Conv2Args& a,
+                                                         const typename Conv2Block<LOG2N, TSHIFT, V>::Persist& ps,
+                                                         float2* lds, const float2* mid_table) {
+    using CB = Conv2Block<LOG2N, TSHIFT, V>;
+    using F = Fft2<LOG2N, V>;
     const float2* h = SIDE ? a.h_side : a.h_mid;
     typename CB::RowFilter rf;
-    if (!MULTI) {
-        CB::template phase_load<SIDE>(tid, pair, edge, a, ps, lds);
-        CB::fetch_filter(tid, h, rf);
+    typename CB::RowAcc acc;
+    CB::clear_acc(acc);
+    for (int k = 0; k < a.parts; ++k) {
+        CB::template phase_load<SIDE>(tid, pair, edge, a, ps, lds, k);
+        CB::fetch_filter(tid, h + (size_t)k * F::N, rf);
         __syncthreads();
         if (F::P == 3) {
             CB::phase_fwd_mid(tid, lds, mid_table);
             __syncthreads();
         }
-        CB::phase_filter(tid, rf, lds);
-    } else {
-        // uniformly partitioned overlap-save: one forward transform per filter partition, products
-        // accumulated on the thread's row, one inverse transform
-        typename CB::RowAcc acc;
-        CB::clear_acc(acc);
-        for (int k = 0; k < a.parts; ++k) {
-            CB::template phase_load<SIDE>(tid, pair, edge, a, ps, lds, k);
-            CB::fetch_filter(tid, h + (size_t)k * F::N, rf);
-            __syncthreads();
-            if (F::P == 3) {
-                CB::phase_fwd_mid(tid, lds, mid_table);
-                __syncthreads();
-            }
-            CB::phase_accumulate(tid, rf, lds, acc);
-            __syncthreads();
-        }
-        CB::phase_finish_row(tid, acc, lds);
+        CB::phase_accumulate(tid, rf, lds, acc);
+        __syncthreads();
     }
+    CB::phase_finish_row(tid, acc, lds);
     __syncthreads();
     if (F::P == 3) {
-        CB::phase_inv_mid(tid, lds, mid_table);
+        CB::phase_inv_mid(opaque(tid), lds, mid_table);
         __syncthreads();
     }
 }
-template <int LOG2N, bool MULTI, int TSHIFT>
-__device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2Args& a,
-                                           const typename Conv2Block<LOG2N, TSHIFT>::Persist& ps, float2* lds,
-                                           const float2* mid_table) {
-    using CB = Conv2Block<LOG2N, TSHIFT>;
+
+// One pair of output blocks: mid channel, then side channel + epilogue.  On entry `raw` holds the
+// pair's frames (or, unpipelined / partitioned, nothing); on exit those of pair `next` (< 0: none).
+template <int LOG2N, bool MULTI, int TSHIFT, int V>
+__device__ __forceinline__ float conv_pair(int tid, long long pair, long long next, const Conv2Args& a,
+                                           const typename Conv2Block<LOG2N, TSHIFT, V>::Persist& ps,
+                                           typename Conv2Block<LOG2N, TSHIFT, V>::Raw& raw, float2* lds,
+                                           const float2* mid_table, Stamper& sm) {
+    using CB = Conv2Block<LOG2N, TSHIFT, V>;
+    constexpr int AHEAD = conv_ahead<LOG2N, MULTI, TSHIFT, V>();
     const bool edge = !CB::interior(pair, a.n, a.parts);
     typename CB::Kept kept;
-    conv_channel<LOG2N, false, MULTI, TSHIFT>(tid, pair, edge, a, ps, lds, mid_table);
-    CB::phase_keep_mid(tid, ps, lds, kept);
-    __syncthreads();
-    conv_channel<LOG2N, true, MULTI, TSHIFT>(tid, pair, edge, a, ps, lds, mid_table);
-    return CB::phase_store(tid, pair, edge, a, ps, lds, kept);
+    sm.mark(tid);
+    if (MULTI) {
+        conv_channel_partitioned<LOG2N, false, TSHIFT, V>(tid, pair, edge, a, ps, lds, mid_table);
+        CB::phase_keep_mid(tid, ps, lds, kept);
+        __syncthreads();
+        conv_channel_partitioned<LOG2N, true, TSHIFT, V>(tid, pair, edge, a, ps, lds, mid_table);
+    } else {
+        typename CB::Held held;
+        // frames of the thread's first AHEAD butterflies are already on their way (issued by the previous pair)
+        CB::template fetch_frames<MGX_CONV_LD1_AUX, AHEAD, CB::CNT0>(tid, pair, edge, a, 0, raw);
+        conv_channel<LOG2N, false, TSHIFT, V>(
+            tid, a, lds, mid_table, sm, [&]() { CB::phase_pass0_mid(tid, raw, ps, lds, held); });
+        CB::phase_keep_mid(tid, ps, lds, kept);
+        sm.mark(tid);
+        __syncthreads();
+        sm.mark(tid);
+        conv_channel<LOG2N, true, TSHIFT, V>(
+            tid, a, lds, mid_table, sm, [&]() { CB::phase_pass0_side(tid, held, ps, lds); });
+    }
+    // epilogue: outputs into registers, the next pair's loads, then the stores behind them
+    float pk;
+    if (AHEAD > 0) {
+        typename CB::Outputs out;
+        CB::phase_outputs(tid, ps, lds, kept, out);
+        __builtin_amdgcn_sched_barrier(0);
+        if (next >= 0)
+            CB::template fetch_frames<MGX_CONV_LD1_AUX, 0, AHEAD>(tid, next, !CB::interior(next, a.n, a.parts), a, 0, raw);
+        __builtin_amdgcn_sched_barrier(0);
+        pk = CB::store_outputs(tid, pair, edge, a, kept, out);
+    } else {
+        pk = CB::phase_store(tid, pair, edge, a, ps, lds, kept);
+    }
+    sm.mark(tid);
+    return pk;
 }
 
 // Persistent workgroups.  gridDim.x is a multiple of 8; workgroup w is (observed to be) placed on
 // XCD w % 8, so XCD x walks its own contiguous eighth of the track and the workgroups resident on
 // it work on neighbouring pairs: the overlap between neighbours is re-read from that XCD's L2,
 // not from HBM.  Placement only affects speed, never results.
+// Two workgroups per CU (LDS): the second launch bound is waves per SIMD, i.e. the register budget.
 // MULTI = more than one filter partition (its own instantiation: the accumulator row costs registers
 // the plain kernel should not pay for)
-template <int LOG2N, bool MULTI, int TSHIFT = 1>
-__global__ __launch_bounds__(Fft2<LOG2N>::T, 2) void k_conv(Conv2Args a) {
-    using CB = Conv2Block<LOG2N, TSHIFT>;
-    using F = Fft2<LOG2N>;
+template <int LOG2N, bool MULTI, int TSHIFT = 1, int V = 0>
+__global__ __launch_bounds__((Fft2<LOG2N, V>::T), (conv_waves_per_simd<LOG2N, V>())) void k_conv(Conv2Args a) {
+    using CB = Conv2Block<LOG2N, TSHIFT, V>;
+    using F = Fft2<LOG2N, V>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
     float2* mid_table = lds + F::LDS_ELEMS;
@@ -140,26 +250,39 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, 2) void k_conv(Conv2Args a) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const long long per = (a.npairs + 7) >> 3;
     const long long end = min(a.npairs, (xcd + 1) * per);
-    for (long long pair = xcd * per + slot; pair < end; pair += slots) {
+    typename CB::Raw raw;
+    const long long first = xcd * per + slot;
+    constexpr int AHEAD = conv_ahead<LOG2N, MULTI, TSHIFT, V>();
+    if (AHEAD > 0 && first < end)
+        CB::template fetch_frames<MGX_CONV_LD1_AUX, 0, AHEAD>(tid, first, !CB::interior(first, a.n, a.parts), a, 0, raw);
+    for (long long pair = first; pair < end; pair += slots) {
         // The pass-0 twiddles stay in registers across pairs, but nothing derived from them (or
         // from the thread id) should: hoisted out of this loop it would sit in VGPRs it does
         // not have.  An empty asm makes the values opaque per iteration.
 #pragma unroll
         for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
-        const float pk = conv_pair<LOG2N, MULTI, TSHIFT>(tid, pair, a, ps, lds, mid_table);
+        Stamper sm;
+#ifdef MGX_CONV_STAMPS
+        const long long it = (pair - (xcd * per + slot)) / slots;
+        sm.p = a.stamps && it < 8 ? a.stamps + ((long long)blockIdx.x * 8 + it) * 32 : nullptr;
+        sm.i = 0;
+#endif
+        const long long next = pair + slots < end ? pair + slots : -1;
+        const float pk = conv_pair<LOG2N, MULTI, TSHIFT, V>(tid, pair, next, a, ps, raw, lds, mid_table, sm);
         const float bp = block_max<F::T>(pk, scratch);
         if (tid == 0 && a.pair_peak) a.pair_peak[pair] = bp;
         __syncthreads();
+        sm.mark(tid);
     }
 }
 
 // filter spectra: grid = 2 * parts; taps = [2][parts * N/2] float (mid then side), tables =
 // [2][parts][N] float2.  Workgroup (ch, k) transforms partition k of channel ch.
-template <int LOG2N, int TSHIFT = 1>
-__global__ __launch_bounds__(Fft2<LOG2N>::T) void k_conv_prep(const float* taps, const float2* tw, float2* tables,
+template <int LOG2N, int TSHIFT = 1, int V = 0>
+__global__ __launch_bounds__((Fft2<LOG2N, V>::T)) void k_conv_prep(const float* taps, const float2* tw, float2* tables,
                                                               int parts, const double* gain_ptr, double gain) {
-    using CB = Conv2Block<LOG2N, TSHIFT>;
-    using F = Fft2<LOG2N>;
+    using CB = Conv2Block<LOG2N, TSHIFT, V>;
+    using F = Fft2<LOG2N, V>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
     float2* mid_table = lds + F::LDS_ELEMS;
@@ -185,9 +308,16 @@ constexpr size_t analysis_lds_bytes() {
 }
 
 // waves per SIMD the LDS footprint admits (4 SIMDs per CU): the register budget follows from it
+#ifndef MGX_ANALYZE_MAX_WGS
+#define MGX_ANALYZE_MAX_WGS 8          // experiments: cap the workgroups per CU (more registers each)
+#endif
+#ifndef MGX_ANALYZE_PREFETCH
+#define MGX_ANALYZE_PREFETCH 0
+#endif
 template <int LOG2N>
 constexpr int analysis_waves_per_simd() {
-    constexpr int wgs = (int)((size_t)160 * 1024 / analysis_lds_bytes<LOG2N>());
+    constexpr int by_lds = (int)((size_t)160 * 1024 / analysis_lds_bytes<LOG2N>());
+    constexpr int wgs = by_lds < MGX_ANALYZE_MAX_WGS ? by_lds : MGX_ANALYZE_MAX_WGS;
     constexpr int w = (wgs > 8 ? 8 : wgs) * (Fft2<LOG2N>::T / 64) / 4;
     return w < 1 ? 1 : (w > 8 ? 8 : w);
 }
@@ -210,11 +340,20 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
     __syncthreads();
     const int s0 = ch * a.segs_per_wg;
     const int s1 = min(a.segs_per_piece, s0 + a.segs_per_wg);
+#if MGX_ANALYZE_PREFETCH
+    typename AB::Raw ahead;
+    if (s0 < s1) AB::fetch(tid, (long long)d * a.piece + (long long)s0 * F::N, a, ahead);
+#endif
     for (int s = s0; s < s1; ++s) {
         // (a software prefetch of the next segment was tried: at 128 VGPRs the 32 registers it pins
         // spill, which stalls on the very loads it was meant to hide)
         typename AB::Raw raw;
+#if MGX_ANALYZE_PREFETCH
+        raw = ahead;
+        if (s + 1 < s1) AB::fetch(tid, (long long)d * a.piece + (long long)(s + 1) * F::N, a, ahead);
+#else
         AB::fetch(tid, (long long)d * a.piece + (long long)s * F::N, a, raw);
+#endif
         AB::phase_load(tid, raw, ps, th, lds);
         lds_barrier();
         if (F::P == 3) {
@@ -920,15 +1059,6 @@ __device__ __forceinline__ Affine compose_waves(const Affine* totals, Affine exc
     }
     if (whole) *whole = all;
     return affine_then(before, exclusive_in_wave);
-}
-
-// The phases of a kernel share index arithmetic (LDS addresses derived from the thread id).  Left
-// alone, the compiler computes it once and keeps dozens of addresses alive across the whole
-// kernel -- in scratch memory once the registers run out.  An empty asm makes the id opaque so
-// that each phase re-derives its few addresses instead.
-__device__ __forceinline__ int opaque(int v) {
-    asm volatile("" : "+v"(v));
-    return v;
 }
 
 __global__ __launch_bounds__(Limiter2Block::T, 4) void k_limit(Limiter2Args a) {

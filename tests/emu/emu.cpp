@@ -28,11 +28,31 @@ static std::vector<float2> twiddles(int n) {
 
 #define FOR_THREADS(T_) for (int tid = 0; tid < (T_); ++tid)
 
+// Middle pass of a transform.  A split pass (fft2.h: two lanes share a butterfly and run in lockstep
+// on the GPU) is emulated as its two halves in separate thread loops.
+template <class F>
+static void mid_pass(bool inverse, float2* lds, const float2* table) {
+    if (F::P != 3) return;
+    if (F::SPLIT_MID) {
+        std::vector<typename F::MidHalf> h(F::T);
+        if (inverse) {
+            FOR_THREADS(F::T) F::inv_mid_gather(tid, lds, table, h[tid]);
+            FOR_THREADS(F::T) F::inv_mid_scatter(tid, h[tid], lds);
+        } else {
+            FOR_THREADS(F::T) F::fwd_mid_gather(tid, lds, h[tid]);
+            FOR_THREADS(F::T) F::fwd_mid_scatter(tid, h[tid], lds, table);
+        }
+    } else {
+        if (inverse) { FOR_THREADS(F::T) F::inv_mid(tid, lds, table); }
+        else { FOR_THREADS(F::T) F::fwd_mid(tid, lds, table); }
+    }
+}
+
 // ---------------------------------------------------------------------------
-template <int LOG2N, int TSHIFT = 1>
+template <int LOG2N, int TSHIFT = 1, int V = 0>
 static int conv_impl(const float* x, long long n, const double* fir_mid, const double* fir_side, int taps,
                      double gain, float* y, float* ymid, double* peak) {
-    using CB = Conv2Block<LOG2N, TSHIFT>;
+    using CB = Conv2Block<LOG2N, TSHIFT, V>;
     using F = typename CB::F;
     const int parts = TSHIFT == 1 ? 2 * taps / F::N : 1;
     const std::vector<float2> tw = twiddles(F::N);
@@ -44,7 +64,7 @@ static int conv_impl(const float* x, long long n, const double* fir_mid, const d
     for (int ch = 0; ch < 2; ++ch)
         for (int k = 0; k < parts; ++k) {
             FOR_THREADS(F::T) CB::phase_load_taps(tid, h.data() + ((size_t)ch * parts + k) * CB::TAPS, ps[tid], lds.data());
-            FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
+            mid_pass<F>(false, lds.data(), mid_table.data());
             FOR_THREADS(F::T) CB::phase_write_filter(tid, lds.data(), (float)(gain / F::N),
                                                      tables.data() + ((size_t)ch * parts + k) * F::N);
         }
@@ -62,20 +82,28 @@ static int conv_impl(const float* x, long long n, const double* fir_mid, const d
     float pk = 0.f;
     std::vector<typename CB::Kept> kept(F::T);
     std::vector<typename CB::RowAcc> acc(F::T);
+    std::vector<typename CB::Held> held(F::T);
     // one channel of one pair, exactly the phase sequence of conv_channel() in mgx_kernels.h
     auto channel = [&](long long pair, bool edge, bool side) {
         const float2* hh = side ? a.h_side : a.h_mid;
         if (parts == 1) {
-            if (side) { FOR_THREADS(F::T) CB::template phase_load<true>(tid, pair, edge, a, ps[tid], lds.data()); }
-            else { FOR_THREADS(F::T) CB::template phase_load<false>(tid, pair, edge, a, ps[tid], lds.data()); }
-            FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
+            // as conv_pair() in mgx_kernels.h: the mid pass reads the frames and leaves the side samples
+            if (side) { FOR_THREADS(F::T) CB::phase_pass0_side(tid, held[tid], ps[tid], lds.data()); }
+            else {
+                FOR_THREADS(F::T) {
+                    typename CB::Raw raw;
+                    CB::fetch_frames(tid, pair, edge, a, 0, raw);
+                    CB::phase_pass0_mid(tid, raw, ps[tid], lds.data(), held[tid]);
+                }
+            }
+            mid_pass<F>(false, lds.data(), mid_table.data());
             FOR_THREADS(F::T) { typename CB::RowFilter rf; CB::fetch_filter(tid, hh, rf); CB::phase_filter(tid, rf, lds.data()); }
         } else {
             FOR_THREADS(F::T) CB::clear_acc(acc[tid]);
             for (int k = 0; k < parts; ++k) {
                 if (side) { FOR_THREADS(F::T) CB::template phase_load<true>(tid, pair, edge, a, ps[tid], lds.data(), k); }
                 else { FOR_THREADS(F::T) CB::template phase_load<false>(tid, pair, edge, a, ps[tid], lds.data(), k); }
-                FOR_THREADS(F::T) CB::phase_fwd_mid(tid, lds.data(), mid_table.data());
+                mid_pass<F>(false, lds.data(), mid_table.data());
                 FOR_THREADS(F::T) {
                     typename CB::RowFilter rf;
                     CB::fetch_filter(tid, hh + (size_t)k * F::N, rf);
@@ -84,7 +112,7 @@ static int conv_impl(const float* x, long long n, const double* fir_mid, const d
             }
             FOR_THREADS(F::T) CB::phase_finish_row(tid, acc[tid], lds.data());
         }
-        FOR_THREADS(F::T) CB::phase_inv_mid(tid, lds.data(), mid_table.data());
+        mid_pass<F>(true, lds.data(), mid_table.data());
     };
     for (long long pair = 0; pair < a.npairs; ++pair) {
         const bool edge = !CB::interior(pair, n, parts);
@@ -118,6 +146,15 @@ extern "C" int emu_convolve_wide(const float* x, long long n, const double* fir_
         case 9: return conv_impl<9, 2>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
         case 11: return conv_impl<11, 2>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
         case 14: return conv_impl<14, 2>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
+        default: return -4;
+    }
+}
+// "thin" transform plans (fft2.h, V = 1): rows of 16, twice the threads
+extern "C" int emu_convolve_thin(const float* x, long long n, const double* fir_mid, const double* fir_side,
+                                 int taps, double gain, float* y, float* ymid, double* peak) {
+    switch (ilog2_exact(taps) + 1) {
+        case 12: return conv_impl<12, 1, 1>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
+        case 13: return conv_impl<13, 1, 1>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
         default: return -4;
     }
 }
@@ -165,7 +202,7 @@ static int analyze_impl(const float* x, long long n, const mgx_config* cfg, int 
         for (int s = s0; s < s1; ++s) {
             const long long start = d * piece + (long long)s * F::N;
             FOR_THREADS(F::T) { typename AB::Raw raw; AB::fetch(tid, start, a, raw); AB::phase_load(tid, raw, ps[tid], th[tid], lds.data()); }
-            FOR_THREADS(F::T) AB::phase_fwd_mid(tid, lds.data(), mid_table.data());
+            mid_pass<F>(false, lds.data(), mid_table.data());
             FOR_THREADS(F::T) AB::phase_row(tid, th[tid], lds.data());
             FOR_THREADS(F::T) AB::phase_magnitudes(tid, th[tid], lds.data());
         }
