@@ -506,7 +506,7 @@ struct Limiter2Block {
                 const float2 v0 = scaled(make_float2(q.x, q.y), g), v1 = scaled(make_float2(q.z, q.w), g);
                 const float s0 = own_gain(v0, k0, with_gain, a.threshold) * post;
                 const float s1 = own_gain(v1, k1, with_gain, a.threshold) * post;
-                *reinterpret_cast<float4*>(a.out + f) = make_float4(v0.x * s0, v0.y * s0, v1.x * s1, v1.y * s1);
+                st_stream(reinterpret_cast<float4*>(a.out + f), make_float4(v0.x * s0, v0.y * s0, v1.x * s1, v1.y * s1));
             } else {
                 if (f < a.n) {
                     const float2 v = scaled(a.y[f], g);

@@ -127,6 +127,27 @@ inline void st_f1(MemView m, unsigned voff, unsigned soff, float v) {
 }
 #endif
 
+// Streaming stores: data this kernel will not read again goes out non-temporal so that it does not
+// evict what is still to be re-read from the L2 (the convolution's input frames, the limiter's).
+MGX_HD void st_stream(float4* p, float4 v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_HOST_EMU) && !defined(MGX_NO_STREAM_STORES)
+    typedef float v4_t __attribute__((ext_vector_type(4)));
+    v4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4_t*>(p));
+#else
+    *p = v;
+#endif
+}
+MGX_HD void st_stream(float2* p, float2 v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_HOST_EMU) && !defined(MGX_NO_STREAM_STORES)
+    typedef float v2_t __attribute__((ext_vector_type(2)));
+    v2_t t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<v2_t*>(p));
+#else
+    *p = v;
+#endif
+}
+
 // sqrt to 1 ulp (v_sqrt_f32) for magnitudes; the library sqrtf adds a denormal-safe refinement
 // sequence that costs ~15 instructions
 MGX_HD float fast_sqrt(float x) {

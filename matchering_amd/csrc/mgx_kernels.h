@@ -994,6 +994,7 @@ __global__ __launch_bounds__(256) void k_scale_outputs(const float2* y, long lon
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float2 v = y[i];
         const double l = (double)v.x * g, r = (double)v.y * g;
+        // (plain stores: non-temporal ones measured 58 vs 54 us here)
         if (out_plain) out_plain[i] = make_float2((float)l, (float)r);
         if (out_normalized) out_normalized[i] = make_float2((float)(l / inv), (float)(r / inv));
     }
