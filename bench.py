@@ -212,6 +212,40 @@ def main():
             stages.main(target, reference, cfg, need_default=False, need_no_limiter=True, device=dev)
             line["pcie_inclusive"] = {"value": round(n / (time.perf_counter() - t0) / 1e6, 2), "unit": "Msamples/s",
                                       "note": "pageable numpy in/out through stages.main, one pair"}
+            # config #4's share of one GPU: eight four-minute pairs, resident in HBM, submitted round-robin
+            # to two device handles (two HIP streams) so that one pair's short serial kernels overlap
+            # the other's streaming ones -- the batch front end's lanes (matchering_amd/batch.py)
+            if args.seconds == 480.0:
+                lanes = [dev, Device(ranks.local)]
+                half_t, half_r = make_pair(args.seconds / 2, args.sample_rate, pair=100)
+                nb, nrb = half_t.shape[0], half_r.shape[0]
+                bufs = []
+                for k in range(8):
+                    d = lanes[k % 2]
+                    bufs.append((d, d.upload(half_t), d.upload(half_r), d.alloc(nb * 8)))
+
+                def batch_pass(only=None):
+                    for d, tb, rb, ob in bufs:
+                        (only or d).master(tb, nb, rb, nrb, native, result=ob, want_report=False)
+                    for d in lanes:
+                        d.synchronize()
+
+                times = {}
+                for name, only in (("one_lane", dev), ("two_lanes", None)):
+                    batch_pass(only)
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        batch_pass(only)
+                    times[name] = (time.perf_counter() - t0) / 3
+                line["batch_8x4min_full"] = {
+                    "value": round(8 * nb / times["two_lanes"] / 1e6, 2), "unit": "Msamples/s",
+                    "ms_per_batch": round(times["two_lanes"] * 1e3, 3),
+                    "one_lane_ms_per_batch": round(times["one_lane"] * 1e3, 3),
+                    "note": "8 four-minute pairs per GPU (config #4's share), full pipeline, two handles"}
+                for d, tb, rb, ob in bufs:
+                    for b in (tb, rb, ob):
+                        b.release()
+                lanes[1].close()
         if not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import mastering_oracle as mo

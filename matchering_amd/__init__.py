@@ -14,3 +14,4 @@ from .config import Config, LimiterConfig  # noqa: F401
 from .core import process  # noqa: F401
 from .audio_io import load  # noqa: F401
 from .checker import check  # noqa: F401
+from .batch import master_many, process_batch  # noqa: F401  (no counterpart in the reference)

@@ -1,0 +1,240 @@
+"""Batch front end: many independent target/reference pairs on one or several MI355X.
+
+The reference has no batch API (``core.process`` masters exactly one pair, core.py:32-121; batches
+are left to the external matchering-cli, README.md:146-147).  Pairs share nothing, so the batch
+axis shards without any data-path collective:
+
+* across GPUs: pair ``i`` belongs to rank ``i mod world_size``, one process per GPU.  Ranks are read
+  from the environment ``torch.distributed.run`` (or any launcher) sets -- RANK, WORLD_SIZE,
+  LOCAL_RANK -- and no rank ever talks to another one here;
+* inside a rank: ``lanes`` device handles (each its own HIP stream and workspace) are fed by one
+  thread each.  A pair's kernels form a dependent chain with short single-workgroup links (FIR
+  design, level-correction decisions) and its PCIe copies run in one direction at a time; a second
+  lane fills those holes with another pair's work;
+* around the GPU: decoding and encoding of audio files is host work that takes far longer than
+  mastering, so ``process_batch`` keeps ``io_threads`` loaders ahead of the lanes and writes
+  results behind them.
+
+``master_many`` works on arrays in memory, ``process_batch`` on files with the reference's
+``Result`` objects.  Command line (one rank)::
+
+    python -m matchering_amd.batch jobs.json
+
+and on a node with 8 GPUs::
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        -m matchering_amd.batch jobs.json
+
+``jobs.json`` is a list of ``{"target": path, "reference": path, "results": [{"file": path,
+"subtype": "PCM_16", "use_limiter": true, "normalize": true}, ...]}``.
+"""
+
+import json
+import os
+import queue
+import sys
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+from .config import Config
+from .log import Code, ModuleError
+from .results import Result
+
+
+def rank_and_world(rank=None, world_size=None):
+    """(rank, world_size, local_rank) from the arguments or the launcher's environment."""
+    r = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+    w = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else int(world_size)
+    local = int(os.environ.get("LOCAL_RANK", str(r)))
+    if not 0 <= r < w:
+        raise ValueError(f"rank {r} outside world of {w}")
+    return r, w, local
+
+
+def shard(items, rank, world_size):
+    """Indices of the items rank ``rank`` owns: ``i mod world_size == rank``."""
+    return list(range(rank, len(items), world_size))
+
+
+class _Lanes:
+    """``lanes`` worker threads, each bound to its own device handle, draining one job queue."""
+
+    def __init__(self, make_worker, lanes):
+        self.jobs = queue.Queue()
+        self.failure = None
+        self.threads = [threading.Thread(target=self._run, args=(make_worker, lane), daemon=True)
+                        for lane in range(lanes)]
+        for t in self.threads:
+            t.start()
+
+    def _run(self, make_worker, lane):
+        worker = None
+        while True:
+            item = self.jobs.get()
+            if item is None:
+                return
+            index, payload, done = item
+            try:
+                if self.failure is not None:
+                    raise RuntimeError("batch aborted")
+                if worker is None:
+                    worker = make_worker(lane)
+                done(index, worker(payload), None)
+            except BaseException as exc:           # recorded and re-raised by close()
+                if self.failure is None:
+                    self.failure = exc
+                done(index, None, exc)
+
+    def submit(self, index, payload, done):
+        self.jobs.put((index, payload, done))
+
+    def close(self):
+        for _ in self.threads:
+            self.jobs.put(None)
+        for t in self.threads:
+            t.join()
+        if self.failure is not None:
+            raise self.failure
+
+
+def _device_worker(device_index, config, needs, master):
+    """A callable mastering one (target, reference) array pair on its own device handle."""
+    if master is not None:                         # tests inject a stand-in for the GPU
+        return lambda pair: master(pair[0], pair[1], config, *needs)
+    from .device import Device
+    from .stages import main
+
+    dev = Device(device_index)
+    return lambda pair: main(pair[0], pair[1], config, *needs, device=dev)
+
+
+def master_many(pairs, config=None, need_default=True, need_no_limiter=False,
+                need_no_limiter_normalized=False, device_index=0, lanes=2, master=None):
+    """``stages.main`` over a list of (target, reference) arrays on ONE GPU, ``lanes`` pairs in flight.
+
+    Returns the list of result triples in the order of ``pairs``.  Results are bit-identical to
+    calling ``stages.main`` pair by pair: lanes only change when work is submitted, never what is
+    computed."""
+    config = config if config is not None else Config()
+    needs = (need_default, need_no_limiter, need_no_limiter_normalized)
+    out = [None] * len(pairs)
+
+    def done(index, value, exc):
+        out[index] = value
+
+    pool = _Lanes(lambda lane: _device_worker(device_index, config, needs, master), max(1, min(lanes, len(pairs) or 1)))
+    for i, pair in enumerate(pairs):
+        pool.submit(i, pair, done)
+    pool.close()
+    return out
+
+
+def _needs_of(results):
+    return (any(r.use_limiter for r in results),
+            any(not r.use_limiter and not r.normalize for r in results),
+            any(not r.use_limiter and r.normalize for r in results))
+
+
+def _load_job(job, config):
+    """Load + check both files of a job (core.py:52-74), on a host thread."""
+    from .audio_io import load
+    from .checker import check, check_equality
+    from .utils import get_temp_folder
+
+    temp_folder = config.temp_folder if config.temp_folder else get_temp_folder(job["results"])
+    target, rate_t = load(job["target"], "target", temp_folder)
+    target, rate_t = check(target, rate_t, config, "target")
+    reference, rate_r = load(job["reference"], "reference", temp_folder)
+    reference, rate_r = check(reference, rate_r, config, "reference")
+    if not config.allow_equality:
+        check_equality(target, reference)
+    if (not (rate_t == rate_r == config.internal_sample_rate)
+            or not (target.shape[1] == reference.shape[1] == 2)
+            or not (target.shape[0] > config.fft_size and reference.shape[0] > config.fft_size)):
+        raise ModuleError(Code.ERROR_VALIDATION)
+    return target, reference
+
+
+def _save_job(job, triple, config):
+    from .audio_io import save
+
+    result, plain, normalized = triple
+    for wanted in job["results"]:
+        chosen = result if wanted.use_limiter else (normalized if wanted.normalize else plain)
+        save(wanted.file, chosen, config.internal_sample_rate, wanted.subtype)
+
+
+def process_batch(jobs, config=None, rank=None, world_size=None, device_index=None, lanes=2, io_threads=4,
+                  master=None):
+    """``process`` for a list of jobs, this rank's share only.
+
+    ``jobs``: dicts with "target", "reference" (paths) and "results" (list of ``Result``).  Returns
+    the indices of the jobs this rank mastered.  The first failing job aborts the rank's batch and
+    its exception is re-raised (after the jobs already in flight have finished)."""
+    config = config if config is not None else Config()
+    r, w, local = rank_and_world(rank, world_size)
+    mine = shard(jobs, r, w)
+    for i in mine:
+        if not jobs[i].get("results"):
+            raise RuntimeError("The result list is empty")
+    device_index = local if device_index is None else device_index
+    savers = []
+
+    with ThreadPoolExecutor(max_workers=max(1, io_threads)) as io:
+        def worker_for(lane):
+            workers = {}
+
+            def run(item):
+                index, arrays = item
+                needs = _needs_of(jobs[index]["results"])
+                if needs not in workers:
+                    workers[needs] = _device_worker(device_index, config, needs, master)
+                return workers[needs](arrays)
+            return run
+
+        pool = _Lanes(worker_for, max(1, lanes))
+
+        def done(index, triple, exc):
+            if exc is None:
+                savers.append(io.submit(_save_job, jobs[index], triple, config))
+
+        # loaders run at most `io_threads` jobs ahead of the lanes
+        ahead = [io.submit(_load_job, jobs[i], config) for i in mine[:io_threads]]
+        nxt = len(ahead)
+        try:
+            for k, i in enumerate(mine):
+                arrays = ahead[k].result()
+                if nxt < len(mine):
+                    ahead.append(io.submit(_load_job, jobs[mine[nxt]], config))
+                    nxt += 1
+                pool.submit(i, (i, arrays), done)
+        finally:
+            pool.close()
+        for s in savers:
+            s.result()
+    return mine
+
+
+def jobs_from_json(path):
+    with open(path) as fh:
+        raw = json.load(fh)
+    jobs = []
+    for item in raw:
+        results = [Result(r["file"], subtype=r.get("subtype", "PCM_16"), use_limiter=r.get("use_limiter", True),
+                          normalize=r.get("normalize", True)) for r in item["results"]]
+        jobs.append({"target": item["target"], "reference": item["reference"], "results": results})
+    return jobs
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) != 1:
+        raise SystemExit(__doc__)
+    jobs = jobs_from_json(argv[0])
+    r, w, _ = rank_and_world()
+    done = process_batch(jobs)
+    print(f"rank {r}/{w}: mastered {len(done)} of {len(jobs)} pairs")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,124 @@
+"""Batch front end (matchering_amd/batch.py): sharding by rank,
+lanes, file pipeline.  On the CPU the GPU is replaced by the float64 oracle through the ``master``
+hook (the hook exists for exactly this: the product path has no CPU implementation)."""
+
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import mastering_oracle as mo
+import matchering_amd as mg
+from matchering_amd import audio_io, batch
+from matchering_amd.synth import synth
+
+
+def _oracle_master(target, reference, config, need_default, need_no_limiter, need_no_limiter_normalized):
+    ocfg = mo.params(internal_sample_rate=config.internal_sample_rate, fft_size=config.fft_size)
+    out = mo.master(np.asarray(target, dtype=np.float64), np.asarray(reference, dtype=np.float64), ocfg,
+                    need_default, need_no_limiter, need_no_limiter_normalized)
+    return tuple(None if o is None else o.astype(np.float32) for o in out)
+
+
+def _pairs(count, seconds=1.5, rate=8000):
+    out = []
+    for b in range(count):
+        t = (0.5 * synth(seconds, rate, 1 + 2 * b)).astype(np.float32)
+        r = np.clip(2.5 * synth(seconds, rate, 2 + 2 * b), -1, 1).astype(np.float32)
+        out.append((t, r))
+    return out
+
+
+def test_shard_is_a_partition():
+    items = list(range(13))
+    for world in (1, 2, 3, 8, 16):
+        seen = sorted(i for r in range(world) for i in batch.shard(items, r, world))
+        assert seen == items
+        assert all(i % world == r for r in range(world) for i in batch.shard(items, r, world))
+
+
+def test_rank_from_environment(monkeypatch):
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert batch.rank_and_world() == (3, 8, 3)
+    assert batch.rank_and_world(1, 2)[:2] == (1, 2)
+    with pytest.raises(ValueError):
+        batch.rank_and_world(2, 2)
+
+
+def test_master_many_keeps_order_and_matches_single_runs():
+    cfg = mg.Config(internal_sample_rate=8000, fft_size=256, max_piece_size=2)
+    pairs = _pairs(5)
+    seen_threads = set()
+
+    def master(t, r, c, *needs):
+        seen_threads.add(threading.get_ident())
+        return _oracle_master(t, r, c, *needs)
+
+    many = batch.master_many(pairs, cfg, need_default=True, need_no_limiter=True, lanes=2, master=master)
+    assert len(many) == len(pairs) and 1 <= len(seen_threads) <= 2
+    for (t, r), triple in zip(pairs, many):
+        want = _oracle_master(t, r, cfg, True, True, False)
+        assert np.array_equal(triple[0], want[0]) and np.array_equal(triple[1], want[1]) and triple[2] is None
+
+
+def test_master_many_reraises_the_first_failure():
+    cfg = mg.Config(internal_sample_rate=8000, fft_size=256, max_piece_size=2)
+
+    def master(t, r, c, *needs):
+        raise RuntimeError("device lost")
+
+    with pytest.raises(RuntimeError, match="device lost"):
+        batch.master_many(_pairs(3), cfg, master=master)
+
+
+def test_process_batch_files_two_ranks(tmp_path):
+    rate = 8000
+    cfg = mg.Config(internal_sample_rate=rate, fft_size=256, max_piece_size=2)
+    jobs = []
+    for b, (t, r) in enumerate(_pairs(4, seconds=2.0, rate=rate)):
+        tp, rp = str(tmp_path / f"t{b}.wav"), str(tmp_path / f"r{b}.wav")
+        audio_io.write_wav(tp, t, rate, "FLOAT")
+        audio_io.write_wav(rp, r, rate, "FLOAT")
+        jobs.append({"target": tp, "reference": rp,
+                     "results": [mg.Result(str(tmp_path / f"out{b}.wav"), "FLOAT"),
+                                 mg.Result(str(tmp_path / f"plain{b}.wav"), "FLOAT", use_limiter=False, normalize=False)]})
+    done = []
+    for rank in (0, 1):
+        done += batch.process_batch(jobs, cfg, rank=rank, world_size=2, lanes=2, io_threads=2, master=_oracle_master)
+    assert sorted(done) == [0, 1, 2, 3]
+    for b, job in enumerate(jobs):
+        t, _ = audio_io.read_wav(job["target"])
+        r, _ = audio_io.read_wav(job["reference"])
+        want = _oracle_master(t, r, cfg, True, True, False)
+        got, _ = audio_io.read_wav(str(tmp_path / f"out{b}.wav"))
+        plain, _ = audio_io.read_wav(str(tmp_path / f"plain{b}.wav"))
+        assert np.abs(got - want[0]).max() <= 1e-6 and np.abs(plain - want[1]).max() <= 1e-6
+
+
+def test_jobs_from_json(tmp_path):
+    path = tmp_path / "jobs.json"
+    path.write_text(json.dumps([{"target": "a.wav", "reference": "b.wav",
+                                 "results": [{"file": "o.wav", "subtype": "PCM_24", "use_limiter": False}]}]))
+    jobs = batch.jobs_from_json(str(path))
+    assert jobs[0]["target"] == "a.wav" and jobs[0]["results"][0].subtype == "PCM_24"
+    assert jobs[0]["results"][0].use_limiter is False and jobs[0]["results"][0].normalize is True
+
+
+@pytest.mark.gpu
+def test_gpu_lanes_are_bit_identical_to_single_runs():
+    from matchering_amd import stages
+
+    cfg = mg.Config()
+    pairs = []
+    for b in range(4):
+        t = (0.5 * synth(6.0, 44100, 1 + 2 * b)).astype(np.float32)
+        r = np.clip(2.5 * synth(5.0, 44100, 2 + 2 * b), -1, 1).astype(np.float32)
+        pairs.append((t, r))
+    many = batch.master_many(pairs, cfg, need_default=True, need_no_limiter=True, lanes=2)
+    for (t, r), triple in zip(pairs, many):
+        want = stages.main(t, r, cfg, need_default=True, need_no_limiter=True)
+        assert np.array_equal(triple[0], want[0]) and np.array_equal(triple[1], want[1])

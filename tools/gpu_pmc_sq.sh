@@ -4,5 +4,5 @@ TAG=$1; CNT=$2; WL=${3:-8min_full}
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT/pmc -o r -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --workload $WL > $OUT/pmc.log 2>&1
 F=$(find $OUT/pmc -name "*counter_collection.csv" | head -1)
-for C in $CNT; do python tools/pmc_summary.py $F $C | head -5; done
+for C in $CNT; do python tools/pmc_summary.py $F $C | grep -i "${KPAT:-.}" | head -${KN:-5}; done
 rm -rf $OUT/pmc

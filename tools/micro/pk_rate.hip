@@ -21,6 +21,8 @@ __device__ __forceinline__ S2 cmul_s(S2 a, S2 w) { return {a.x * w.x - a.y * w.y
 
 template <bool PK>
 __global__ __launch_bounds__(256) void k(float* out, int iters, float wx, float wy) {
+    extern __shared__ float occupancy_limiter[];     // dynamic LDS sets the workgroups per CU
+    if (iters < 0) occupancy_limiter[threadIdx.x] = 0.f;
     const int t = threadIdx.x + blockIdx.x * 256;
     if (PK) {
         v2f v[8], w = {wx, wy};
@@ -70,23 +72,29 @@ int main() {
         printf("cmul_pk = (%g, %g) want (6.375, 4);  sub_mi_pk = (%g, %g) want (-5, -1.25)\n", h[0], h[1], h[2], h[3]);
     }
     float* out;
-    const int wgs = 256 * 8, iters = 20000;
-    hipMalloc(&out, wgs * 256 * 4);
+    const int iters = 20000;
+    hipMalloc(&out, 256 * 8 * 256 * 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int pk = 0; pk < 2; ++pk)
-        for (int rep = 0; rep < 3; ++rep) {
-            hipEventRecord(e0);
-            if (pk) k<true><<<wgs, 256>>>(out, iters, 0.6f, 0.8f);
-            else k<false><<<wgs, 256>>>(out, iters, 0.6f, 0.8f);
-            hipEventRecord(e1);
-            hipEventSynchronize(e1);
-            float ms;
-            hipEventElapsedTime(&ms, e0, e1);
-            // complex ops per iteration per thread: 4 add, 4 sub, 4 cmul = 8*2 + 4*6 = 40 flop
-            const double flop = (double)wgs * 256 * iters * 40;
-            printf("%s rep %d: %.3f ms  %.1f TFLOP/s\n", pk ? "packed" : "scalar", rep, ms, flop / ms * 1e-9);
-        }
+    // waves per SIMD = workgroups per CU (256 threads = one wave on each of the 4 SIMDs)
+    for (int per_cu : {1, 2, 4, 8}) {
+        const int wgs = 256 * per_cu;
+        const size_t lds = (size_t)160 * 1024 / per_cu - 2048;
+        hipFuncSetAttribute((const void*)k<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void*)k<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        for (int pk = 0; pk < 2; ++pk)
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0);
+                if (pk) k<true><<<wgs, 256, lds>>>(out, iters, 0.6f, 0.8f);
+                else k<false><<<wgs, 256, lds>>>(out, iters, 0.6f, 0.8f);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                const double flop = (double)wgs * 256 * iters * 40;
+                if (rep) printf("%d waves/SIMD %s: %.3f ms  %.1f TFLOP/s\n", per_cu, pk ? "packed" : "scalar", ms, flop / ms * 1e-9);
+            }
+    }
     return 0;
 }
