@@ -204,9 +204,23 @@ static int run_analysis(mgx_handle* h, const float* x, long long n, const mgx_co
     // the kernel's duration (every workgroup runs segs_per_wg segments back to back).
     int dev_cus = 256;
     HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device));
-    const int slots = dev_cus * analysis_workgroups_per_cu(ilog2_exact(f));
-    const int want_chunks = std::min(w.segs_per_piece, std::max(1, slots / w.divisions));
-    w.segs_per_wg = (w.segs_per_piece + want_chunks - 1) / want_chunks;
+    // Every workgroup runs segs_per_wg segments back to back and a CU's residents share its
+    // throughput, so the kernel lasts about as long as the busiest CU has segments: ceil(workgroups /
+    // CUs) * segs_per_wg.  Pick the segments per workgroup that minimise it (ties: more workgroups).
+    const int per_cu = analysis_workgroups_per_cu(ilog2_exact(f));
+    long long best_cost = -1;
+    for (int s = 1; s <= w.segs_per_piece; ++s) {
+        const int chunks = (w.segs_per_piece + s - 1) / s;
+        const long long wgs = (long long)w.divisions * chunks;
+        const long long deep = (wgs + dev_cus - 1) / dev_cus;
+        if (deep > per_cu) continue;
+        const long long cost = deep * s;
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            w.segs_per_wg = s;
+        }
+    }
+    if (best_cost < 0) w.segs_per_wg = w.segs_per_piece;     // more pieces than resident slots
     w.chunks = (w.segs_per_piece + w.segs_per_wg - 1) / w.segs_per_wg;
     const int nwg = w.divisions * w.chunks;
     MGX_TRY(ensure(h, w.wg_sumsq, (size_t)nwg * sizeof(double)));
