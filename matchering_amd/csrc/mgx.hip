@@ -476,8 +476,24 @@ static int run_clipped_sumsq(mgx_handle* h, const float* mid, long long piece, i
     return 0;
 }
 
+// look-back words and control block of a limiter launch over n frames (allocated, not initialised)
+static int limiter_state(mgx_handle* h, long long n, const mgx_config* cfg, unsigned long long** published,
+                         long long* words, int** ticket) {
+    LimiterParams lp;
+    const std::string err = limiter_params(*cfg, lp);
+    if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
+    const long long nchunks = (n + lp.geo.chunk - 1) / lp.geo.chunk;
+    MGX_TRY(ensure(h, h->lim_published, (size_t)3 * nchunks * sizeof(unsigned long long)));
+    MGX_TRY(ensure_ctrl(h));
+    *published = (unsigned long long*)h->lim_published.p;
+    *words = 3 * nchunks;
+    *ticket = (int*)h->lim_ctrl.p;
+    return 0;
+}
+
+// preset_done: the caller's previous kernel has already preset the look-back words and the ticket
 static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_config* cfg, const double* gain_dev,
-                       const double* post_dev, const int* active_dev, float* out) {
+                       const double* post_dev, const int* active_dev, float* out, bool preset_done = false) {
     LimiterParams lp;
     const std::string err = limiter_params(*cfg, lp);
     if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
@@ -512,8 +528,10 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     a.published = (unsigned long long*)h->lim_published.p;
     a.ticket = (int*)h->lim_ctrl.p;
     a.error = a.ticket + 1;
-    HIP_TRY(hipMemsetAsync(h->lim_published.p, 0xff, pub_bytes, h->stream));
-    HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 4, h->stream));       // ticket only: a raised error sticks
+    if (!preset_done) {
+        HIP_TRY(hipMemsetAsync(h->lim_published.p, 0xff, pub_bytes, h->stream));
+        HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 4, h->stream));   // ticket only: a raised error sticks
+    }
     const size_t lds = Limiter2Block::LDS_BYTES;
     MGX_TRY(allow_lds(k_limit, lds));
     hipLaunchKernelGGL(k_limit, dim3((unsigned)a.nchunks), dim3(Limiter2Block::T), lds, h->stream, a);
@@ -846,6 +864,7 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     // stage 3 (stages.py:138-170): scalar feedback stays on the device; one launch per round, the last
     // round also derives the peak / early-out / normalisation scalars (the state was reset by k_fir_raw)
     CorrectionState* cs = (CorrectionState*)h->cstate.p;
+    bool limiter_preset = false;
     {
         RoundArgs ra;
         ra.mid = (const float*)h->mid.p;
@@ -872,8 +891,15 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         ra.npeaks = nblocks;
         const size_t lds_step = (size_t)(64 + tw.divisions + (size_t)ra.divisions * ra.chunks) * sizeof(double);
         const int rounds = cfg->rms_correction_steps;
+        ra.lim_published = nullptr;
+        ra.lim_words = 0;
+        ra.lim_ticket = nullptr;
         for (int step = 0; step < rounds; ++step) {
             ra.final_peaks = step == rounds - 1 ? (const float*)h->block_peak.p : nullptr;
+            if (result_dev && step == rounds - 1) {
+                MGX_TRY(limiter_state(h, n_target, cfg, &ra.lim_published, &ra.lim_words, &ra.lim_ticket));
+                limiter_preset = true;
+            }
             ra.build_band = step == 0 ? 1 : 0;
             hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, ra);
         }
@@ -892,7 +918,8 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     }
     if (result_dev) {
         const double* post = &((const TrackStats*)rw.stats.p)->amplitude_c;
-        MGX_TRY(run_limiter(h, (const float*)h->y.p, n_target, cfg, &cs->gain, post, &cs->limiter_active, result_dev));
+        MGX_TRY(run_limiter(h, (const float*)h->y.p, n_target, cfg, &cs->gain, post, &cs->limiter_active, result_dev,
+                            limiter_preset));
     }
     if (report) {
         MGX_TRY(ensure_pinned(h, 1 << 16));

@@ -808,6 +808,11 @@ struct RoundArgs {
     float* band;                // [n + workgroups * BAND_SLACK] compacted band samples
     BandInfo* info;             // [workgroups]
     int build_band;             // 1: round 0 (stream + build), 0: later rounds (use the band if g allows)
+    // the limiter's look-back words, preset to "unpublished" here when a limiter launch follows (saves
+    // two fill launches on the stream); null otherwise
+    unsigned long long* lim_published;
+    long long lim_words;
+    int* lim_ticket;
 };
 __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
     MGX_LDS;
@@ -820,6 +825,11 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
     const long long e = min((long long)(d + 1) * a.piece, b + len);
     const double g = a.cs->gain;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (a.lim_published) {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.lim_words; i += (long long)gridDim.x * 256)
+            a.lim_published[i] = ~0ull;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.lim_ticket = 0;      // ticket only: a raised error sticks
+    }
     // this workgroup's slice of the band buffer, one compacted list per wave
     const long long wave_cap = (len + 3) / 4 + BAND_SLACK / 4 - 4;
     float* wave_band = a.band + b + (long long)blockIdx.x * BAND_SLACK + wave * wave_cap;
