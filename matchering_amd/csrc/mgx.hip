@@ -848,10 +848,10 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     // stage 1 (stages.py:38-104): both tracks analysed in one pass each
     TrackWork& tw = h->track[0];
     TrackWork& rw = h->track[1];
-    static const bool ref_first = std::getenv("MGX_EXP_REF_FIRST") != nullptr;
-    if (ref_first) MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
+    // (analysing the reference first, so that the target is the fresher track in the Infinity Cache when
+    // the convolution reads it, was measured: no difference)
     MGX_TRY(run_analysis(h, target_dev, n_target, cfg, 0, tw));
-    if (!ref_first) MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
+    MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
     MGX_TRY(run_levels(h, cfg, &tw, &rw));
     // stage 2 (stages.py:107-135): FIR design on the device, then the overlap-save convolution with
     // the level gain of stages.py:80-88 (a device scalar) folded into the filter spectra
