@@ -38,9 +38,6 @@ namespace mgx {
 #ifndef MGX_CONV_LD2_AUX
 #define MGX_CONV_LD2_AUX 0
 #endif
-#ifndef MGX_CONV_ONE_LOAD_PATH
-#define MGX_CONV_ONE_LOAD_PATH 1
-#endif
 #ifndef MGX_CONV_LD1_AUX
 #define MGX_CONV_LD1_AUX 0
 #endif
@@ -108,44 +105,39 @@ struct Conv2Block {
     static MGX_HD long long first_input(long long pair, int parts = 1, int k = 0) {
         return first_output(pair) + (long long)parts * TAPS / 2 - (long long)(k + 1) * TAPS;
     }
-    // every frame the pair touches lies inside the track: no bounds checks needed
+    // every frame the pair touches lies inside the track
     static MGX_HD bool interior(long long pair, long long n, int parts = 1) {
         return first_input(pair, parts, parts - 1) >= 0 && first_input(pair, parts, 0) + N + LOUT <= n &&
                first_output(pair) + 2 * LOUT <= n;
     }
 
     // ---- phase F0: global -> registers -> pass 0 -> LDS ----------------------------------------
-    // Split in two so that the kernel can issue the loads one or two phases before it needs the
-    // frames (software pipelining: a workgroup's memory and arithmetic phases would otherwise
-    // simply alternate): fetch_frames() only issues the loads into `raw`, phase_pass0() consumes
-    // them.  `edge` is uniform over the workgroup: only pairs touching the ends of the track pay
-    // for bounds checks.
+    // fetch_frames() issues the loads into `raw`, phase_pass0*() consume them.  There is no separate
+    // code path for pairs at the ends of the track: frames past its end read as zeros through the
+    // buffer range check, and only a window that starts BEFORE the track (the first pair) forms
+    // its offsets differently.
     struct Raw {
         float2 f[CNT0][NLOAD];
     };
-    // C0, C1: which of the thread's CNT0 butterflies to fetch for ([C0, C1))
-    template <int AUX = 0, int C0 = 0, int C1 = CNT0>
-    static MGX_HD void fetch_frames(int tid, long long pair, bool edge, const Conv2Args& a, int part, Raw& raw) {
+    template <int AUX = 0>
+    static MGX_HD void fetch_frames(int tid, long long pair, const Conv2Args& a, int part, Raw& raw) {
         if (!active0(tid)) return;
         const long long i0 = first_input(pair, a.parts, part);
         MGX_UNROLL
-        for (int c = C0; c < C1; ++c) {
+        for (int c = 0; c < CNT0; ++c) {
             const int u = tid + c * T;
             // one 32-bit lane offset (mgx_hd.h MemView); frames outside the track read as zeros
             const MemView src = mem_view(a.x, a.n * 8);
             const unsigned lane = ((unsigned)i0 + (unsigned)u) * 8u;
-#if MGX_CONV_ONE_LOAD_PATH
-            MGX_UNROLL
-            for (int j = 0; j < NLOAD; ++j) raw.f[c][j] = ld_f2_or_zero<AUX>(src, lane + (unsigned)(j * S0 * 8));
-#else
-            if (edge) {
+            if (i0 < 0) {
+                // the window starts before the track: the displacement goes into the lane offset, which
+                // then wraps to the frame's true offset where there is one
                 MGX_UNROLL
                 for (int j = 0; j < NLOAD; ++j) raw.f[c][j] = ld_f2_or_zero<AUX>(src, lane + (unsigned)(j * S0 * 8));
             } else {
                 MGX_UNROLL
                 for (int j = 0; j < NLOAD; ++j) raw.f[c][j] = ld_f2<AUX>(src, lane, (unsigned)(j * S0 * 8));   // literal displacements
             }
-#endif
         }
     }
     // mid/side of the fetched frames (dsp.py:57-64), the two blocks of the pair packed into one
@@ -211,7 +203,7 @@ struct Conv2Block {
     static MGX_HD void phase_load(int tid, long long pair, bool edge, const Conv2Args& a, const Persist& ps,
                                   float2* lds, int part = 0) {
         Raw raw;
-        fetch_frames<SIDE ? MGX_CONV_LD2_AUX : MGX_CONV_LD1_AUX>(tid, pair, edge, a, part, raw);
+        fetch_frames<SIDE ? MGX_CONV_LD2_AUX : MGX_CONV_LD1_AUX>(tid, pair, a, part, raw);
         phase_pass0<SIDE>(tid, raw, ps, lds);
     }
 
@@ -290,85 +282,9 @@ struct Conv2Block {
     }
 
     // ---- phase I0 (side channel) + epilogue: L = mid + side, R = mid - side (dsp.py:67-68) ----
-    // In two steps -- all output frames into registers, then all stores -- so that the kernel can
-    // issue the next pair's loads in between: ahead of the stores in the memory queue, and at the
-    // point where the fewest registers are live.
-    struct Outputs {
-        float2 ya[CNT0][HALF], yb[CNT0][HALF];        // (L, R) of blocks A and B
-    };
-    static MGX_HD void outputs_of(int tid, int c, const typename F::Tw0Full& tw, const float2* lds, const Kept& k,
-                                  Outputs& o) {
-        float2 v[R0];
-        F::inv0_load(v, tid, c, tw, lds);
-        MGX_UNROLL
-        for (int j = 0; j < HALF; ++j) {
-            const float2 m = k.v[c][j], s = v[SKIP + j];
-            o.ya[c][j] = make_float2(m.x + s.x, m.x - s.x);
-            o.yb[c][j] = make_float2(m.y + s.y, m.y - s.y);
-        }
-    }
-    static MGX_HD void phase_outputs(int tid, const Persist& ps, const float2* lds, const Kept& k, Outputs& o) {
-        if (!active0(tid)) return;
-        typename F::Tw0Full tw;
-        F::expand_tw0(ps.tw0, tw);
-        MGX_UNROLL
-        for (int c = 0; c < CNT0; ++c) outputs_of(tid, c, tw, lds, k, o);
-    }
-    // returns this thread's max(|yL|,|yR|) over the frames it stored
-    static MGX_HD float store_outputs(int tid, long long pair, bool edge, const Conv2Args& a, const Kept& k,
-                                      const Outputs& o) {
-        float peak = 0.f;
-        if (!active0(tid)) return peak;
-        MGX_UNROLL
-        for (int c = 0; c < CNT0; ++c) peak = fmaxf(peak, store_outputs_of(tid, c, pair, edge, a, k, o));
-        return peak;
-    }
-    static MGX_HD float store_outputs_of(int tid, int c, long long pair, bool edge, const Conv2Args& a, const Kept& k,
-                                         const Outputs& o) {
-        float peak = 0.f;
-        const long long o0 = first_output(pair);
-        {
-            const int u = tid + c * T;
-            const long long oa = o0 + u;
-            if (edge) {
-                MGX_UNROLL
-                for (int j = 0; j < HALF; ++j) {
-                    const long long fa = oa + (long long)j * S0, fb = fa + LOUT;
-                    if (fa < a.n) {
-                        a.y[fa] = o.ya[c][j];
-                        if (a.ymid) a.ymid[fa] = k.v[c][j].x;
-                        peak = fmaxf(peak, fmaxf(fabsf(o.ya[c][j].x), fabsf(o.ya[c][j].y)));
-                    }
-                    if (fb < a.n) {
-                        a.y[fb] = o.yb[c][j];
-                        if (a.ymid) a.ymid[fb] = k.v[c][j].y;
-                        peak = fmaxf(peak, fmaxf(fabsf(o.yb[c][j].x), fabsf(o.yb[c][j].y)));
-                    }
-                }
-            } else {
-                const MemView dst = mem_view(a.y, a.n * 8);
-                const unsigned lane = ((unsigned)o0 + (unsigned)u) * 8u;
-                MGX_UNROLL
-                for (int j = 0; j < HALF; ++j) {
-                    st_f2<MGX_CONV_ST_AUX>(dst, lane, (unsigned)(j * S0 * 8), o.ya[c][j]);
-                    st_f2<MGX_CONV_ST_AUX>(dst, lane, (unsigned)((j * S0 + LOUT) * 8), o.yb[c][j]);
-                    peak = fmaxf(peak, fmaxf(fmaxf(fabsf(o.ya[c][j].x), fabsf(o.ya[c][j].y)),
-                                             fmaxf(fabsf(o.yb[c][j].x), fabsf(o.yb[c][j].y))));
-                }
-                if (a.ymid) {
-                    const MemView dm = mem_view(a.ymid, a.n * 4);
-                    const unsigned lane4 = ((unsigned)o0 + (unsigned)u) * 4u;
-                    MGX_UNROLL
-                    for (int j = 0; j < HALF; ++j) {
-                        st_f1<MGX_CONV_ST_AUX>(dm, lane4, (unsigned)(j * S0 * 4), k.v[c][j].x);
-                        st_f1<MGX_CONV_ST_AUX>(dm, lane4, (unsigned)((j * S0 + LOUT) * 4), k.v[c][j].y);
-                    }
-                }
-            }
-        }
-        return peak;
-    }
-    // both steps butterfly by butterfly (fewer registers live at once)
+    // returns this thread's max(|yL|,|yR|) over the frames it stored;  One code path for every pair:
+    // stores beyond the end of the track are dropped by the buffer range check, only the peak needs
+    // to know which frames exist.
     static MGX_HD float phase_store(int tid, long long pair, bool edge, const Conv2Args& a, const Persist& ps,
                                     const float2* lds, const Kept& k) {
         float peak = 0.f;
@@ -376,53 +292,28 @@ struct Conv2Block {
         const long long o0 = first_output(pair);
         typename F::Tw0Full tw;
         F::expand_tw0(ps.tw0, tw);
+        const MemView dst = mem_view(a.y, a.n * 8);
+        const MemView dm = mem_view(a.ymid, a.ymid ? a.n * 4 : 0);
+        const unsigned frames = (unsigned)a.n;
         MGX_UNROLL
         for (int c = 0; c < CNT0; ++c) {
-            const int u = tid + c * T;
+            const unsigned first = (unsigned)o0 + (unsigned)(tid + c * T);
             float2 v[R0];
             F::inv0_load(v, tid, c, tw, lds);
-            float2 ya[HALF], yb[HALF];
             MGX_UNROLL
             for (int j = 0; j < HALF; ++j) {
                 const float2 m = k.v[c][j], s = v[SKIP + j];
-                ya[j] = make_float2(m.x + s.x, m.x - s.x);
-                yb[j] = make_float2(m.y + s.y, m.y - s.y);
-            }
-            const long long oa = o0 + u;
-            if (edge) {
-                MGX_UNROLL
-                for (int j = 0; j < HALF; ++j) {
-                    const long long fa = oa + (long long)j * S0, fb = fa + LOUT;
-                    if (fa < a.n) {
-                        a.y[fa] = ya[j];
-                        if (a.ymid) a.ymid[fa] = k.v[c][j].x;
-                        peak = fmaxf(peak, fmaxf(fabsf(ya[j].x), fabsf(ya[j].y)));
-                    }
-                    if (fb < a.n) {
-                        a.y[fb] = yb[j];
-                        if (a.ymid) a.ymid[fb] = k.v[c][j].y;
-                        peak = fmaxf(peak, fmaxf(fabsf(yb[j].x), fabsf(yb[j].y)));
-                    }
-                }
-            } else {
-                const MemView dst = mem_view(a.y, a.n * 8);
-                const unsigned lane = ((unsigned)o0 + (unsigned)u) * 8u;
-                MGX_UNROLL
-                for (int j = 0; j < HALF; ++j) {
-                    st_f2<MGX_CONV_ST_AUX>(dst, lane, (unsigned)(j * S0 * 8), ya[j]);
-                    st_f2<MGX_CONV_ST_AUX>(dst, lane, (unsigned)((j * S0 + LOUT) * 8), yb[j]);
-                    peak = fmaxf(peak, fmaxf(fmaxf(fabsf(ya[j].x), fabsf(ya[j].y)),
-                                             fmaxf(fabsf(yb[j].x), fabsf(yb[j].y))));
-                }
-                if (a.ymid) {
-                    const MemView dm = mem_view(a.ymid, a.n * 4);
-                    const unsigned lane4 = ((unsigned)o0 + (unsigned)u) * 4u;
-                    MGX_UNROLL
-                    for (int j = 0; j < HALF; ++j) {
-                        st_f1<MGX_CONV_ST_AUX>(dm, lane4, (unsigned)(j * S0 * 4), k.v[c][j].x);
-                        st_f1<MGX_CONV_ST_AUX>(dm, lane4, (unsigned)((j * S0 + LOUT) * 4), k.v[c][j].y);
-                    }
-                }
+                const float2 ya = make_float2(m.x + s.x, m.x - s.x);
+                const float2 yb = make_float2(m.y + s.y, m.y - s.y);
+                const unsigned fa = first + (unsigned)(j * S0), fb = fa + (unsigned)LOUT;
+                // output offsets are never negative, so the literal displacement may stay in the scalar
+                // operand: the range check adds it to the lane offset (tools/micro/buffer_range.hip)
+                st_f2<MGX_CONV_ST_AUX>(dst, first * 8u, (unsigned)(j * S0 * 8), ya);
+                st_f2<MGX_CONV_ST_AUX>(dst, first * 8u, (unsigned)((j * S0 + LOUT) * 8), yb);
+                st_f1<MGX_CONV_ST_AUX>(dm, first * 4u, (unsigned)(j * S0 * 4), m.x);
+                st_f1<MGX_CONV_ST_AUX>(dm, first * 4u, (unsigned)((j * S0 + LOUT) * 4), m.y);
+                const float pa = fmaxf(fabsf(ya.x), fabsf(ya.y)), pb = fmaxf(fabsf(yb.x), fabsf(yb.y));
+                peak = fmaxf(peak, fmaxf(!edge || fa < frames ? pa : 0.f, !edge || fb < frames ? pb : 0.f));
             }
         }
         return peak;

@@ -55,8 +55,12 @@ MGX_HD float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }
 // so a thread keeps ONE 32-bit lane offset and the per-access displacement is a scalar add
 // -- no 64-bit vector address arithmetic and nothing for the compiler to hoist into VGPRs.
 // Offsets are unsigned 32-bit byte counts (a 15-minute 96 kHz stereo float track is 691 MB).
-// The hardware range check is not relied upon: callers only issue in-range accesses.
-// Under the host emulation a view is a plain pointer.
+// The hardware range check IS relied upon at the ends of a track: an access is out of range when
+// lane offset + scalar displacement + size exceeds the view (the sum does not wrap), loads then
+// return zero and stores are dropped (tools/micro/buffer_range.hip).  A lane offset that has wrapped
+// below zero is therefore always out of range, whatever the displacement: code that may start
+// before the view adds the displacement into the lane offset instead (`ld_f2_or_zero`).
+// Under the host emulation a view is a pointer plus its size, with the same rule.
 // ---------------------------------------------------------------------------
 #if defined(__HIPCC__) && !defined(MGX_HOST_EMU)
 struct MemView {
@@ -88,6 +92,24 @@ __device__ __forceinline__ float2 ld_f2_or_zero(MemView m, unsigned voff) {
     const unsigned a = t.x, b = t.y;
     return make_float2(__uint_as_float(a), __uint_as_float(b));
 }
+// Stores and 4-byte loads of the same kind: lanes whose offset lies outside the view are dropped /
+// read zero by the buffer range check, so kernels need no separate code path for the ends of a track.
+template <int AUX = 0>
+__device__ __forceinline__ void st_f2_in_range(MemView m, unsigned voff, float2 v) {
+    typedef unsigned u2_t __attribute__((ext_vector_type(2)));
+    u2_t t;
+    t.x = __float_as_uint(v.x);
+    t.y = __float_as_uint(v.y);
+    __builtin_amdgcn_raw_buffer_store_b64(t, m.r, voff, 0, AUX);
+}
+template <int AUX = 0>
+__device__ __forceinline__ void st_f1_in_range(MemView m, unsigned voff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), m.r, voff, 0, AUX);
+}
+template <int AUX = 0>
+__device__ __forceinline__ float ld_f1_or_zero(MemView m, unsigned voff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(m.r, voff, 0, AUX));
+}
 template <int AUX = 0>
 __device__ __forceinline__ void st_f2(MemView m, unsigned voff, unsigned soff, float2 v) {
     typedef unsigned u2_t __attribute__((ext_vector_type(2)));
@@ -97,34 +119,52 @@ __device__ __forceinline__ void st_f2(MemView m, unsigned voff, unsigned soff, f
     __builtin_amdgcn_raw_buffer_store_b64(t, m.r, voff, soff, AUX);
 }
 template <int AUX = 0>
+__device__ __forceinline__ float ld_f1(MemView m, unsigned voff, unsigned soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(m.r, voff, soff, AUX));
+}
+template <int AUX = 0>
 __device__ __forceinline__ void st_f1(MemView m, unsigned voff, unsigned soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), m.r, voff, soff, AUX);
 }
 #else
+// Host emulation with the semantics of the hardware range check (tools/micro/buffer_range.hip): an
+// access is out of range when lane offset + scalar displacement + size exceeds the view, WITHOUT
+// 32-bit wrap-around of the sum; loads then return zero and stores are dropped.
 struct MemView {
     char* p;
     unsigned long long bytes;
 };
 inline MemView mem_view(const void* p, long long bytes) {
-    return MemView{const_cast<char*>(static_cast<const char*>(p)), (unsigned long long)bytes};
+    return MemView{const_cast<char*>(static_cast<const char*>(p)), (unsigned long long)(bytes > 0 ? bytes : 0)};
 }
-template <int AUX = 0>
-inline float2 ld_f2_or_zero(MemView m, unsigned voff) {
-    if ((unsigned long long)voff + 8 > m.bytes) return float2{0.f, 0.f};
-    return *reinterpret_cast<const float2*>(m.p + (size_t)voff);
+inline bool mem_in_range(MemView m, unsigned voff, unsigned soff, unsigned size) {
+    return (unsigned long long)voff + soff + size <= m.bytes;
 }
 template <int AUX = 0>
 inline float2 ld_f2(MemView m, unsigned voff, unsigned soff) {
+    if (!mem_in_range(m, voff, soff, 8)) return float2{0.f, 0.f};
     return *reinterpret_cast<const float2*>(m.p + (size_t)voff + (size_t)soff);
 }
 template <int AUX = 0>
+inline float2 ld_f2_or_zero(MemView m, unsigned voff) { return ld_f2<AUX>(m, voff, 0); }
+template <int AUX = 0>
 inline void st_f2(MemView m, unsigned voff, unsigned soff, float2 v) {
-    *reinterpret_cast<float2*>(m.p + (size_t)voff + (size_t)soff) = v;
+    if (mem_in_range(m, voff, soff, 8)) *reinterpret_cast<float2*>(m.p + (size_t)voff + (size_t)soff) = v;
 }
 template <int AUX = 0>
-inline void st_f1(MemView m, unsigned voff, unsigned soff, float v) {
-    *reinterpret_cast<float*>(m.p + (size_t)voff + (size_t)soff) = v;
+inline void st_f2_in_range(MemView m, unsigned voff, float2 v) { st_f2<AUX>(m, voff, 0, v); }
+template <int AUX = 0>
+inline float ld_f1(MemView m, unsigned voff, unsigned soff) {
+    return mem_in_range(m, voff, soff, 4) ? *reinterpret_cast<const float*>(m.p + (size_t)voff + (size_t)soff) : 0.f;
 }
+template <int AUX = 0>
+inline float ld_f1_or_zero(MemView m, unsigned voff) { return ld_f1<AUX>(m, voff, 0); }
+template <int AUX = 0>
+inline void st_f1(MemView m, unsigned voff, unsigned soff, float v) {
+    if (mem_in_range(m, voff, soff, 4)) *reinterpret_cast<float*>(m.p + (size_t)voff + (size_t)soff) = v;
+}
+template <int AUX = 0>
+inline void st_f1_in_range(MemView m, unsigned voff, float v) { st_f1<AUX>(m, voff, 0, v); }
 #endif
 
 // Streaming stores: data this kernel will not read again goes out non-temporal so that it does not

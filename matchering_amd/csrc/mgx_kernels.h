@@ -103,21 +103,6 @@ struct Stamper {
 #endif
 };
 
-// Software pipelining of the frame loads: how many of a thread's CNT0 pass-0 butterflies get their
-// frames fetched one pair ahead (issued between the epilogue's arithmetic and its stores, so that they
-// are in flight while the stores drain).  Off: at the 256 registers two workgroups per CU leave a
-// wave, the 2*NLOAD registers per butterfly in flight make the 8192-point kernel spill, and a
-// spilling kernel is far slower than an unpipelined one (measured 294 vs 153 us with everything
-// ahead).  Kept as an experiment switch (-DMGX_CONV_AHEAD=1).
-#ifndef MGX_CONV_AHEAD
-#define MGX_CONV_AHEAD 0
-#endif
-template <int LOG2N, bool MULTI, int TSHIFT, int V>
-constexpr int conv_ahead() {
-    constexpr int cnt = Conv2Block<LOG2N, TSHIFT, V>::CNT0;
-    return MULTI ? 0 : (MGX_CONV_AHEAD < cnt ? MGX_CONV_AHEAD : cnt);
-}
-
 // One channel of one pair, from pass 0 (`pass0`) up to the inverse middle pass (conv2_kernel.h).
 template <int LOG2N, bool SIDE, int TSHIFT, int V, class Pass0>
 __device__ __forceinline__ void conv_channel(int tid, const Conv2Args& a, float2* lds, const float2* mid_table,
@@ -181,15 +166,15 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
     }
 }
 
-// One pair of output blocks: mid channel, then side channel + epilogue.  On entry `raw` holds the
-// pair's frames (or, unpipelined / partitioned, nothing); on exit those of pair `next` (< 0: none).
+// One pair of output blocks: mid channel, then side channel + epilogue.
+// (Issuing the NEXT pair's frame loads before the epilogue's stores -- software pipelining -- was
+// built and measured: the 48-96 registers in flight make the 8192-point kernel spill at the 256 a
+// wave has here, and a spilling kernel is far slower than an unpipelined one, 294 vs 153 us.)
 template <int LOG2N, bool MULTI, int TSHIFT, int V>
-__device__ __forceinline__ float conv_pair(int tid, long long pair, long long next, const Conv2Args& a,
-                                           const typename Conv2Block<LOG2N, TSHIFT, V>::Persist& ps,
-                                           typename Conv2Block<LOG2N, TSHIFT, V>::Raw& raw, float2* lds,
+__device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2Args& a,
+                                           const typename Conv2Block<LOG2N, TSHIFT, V>::Persist& ps, float2* lds,
                                            const float2* mid_table, Stamper& sm) {
     using CB = Conv2Block<LOG2N, TSHIFT, V>;
-    constexpr int AHEAD = conv_ahead<LOG2N, MULTI, TSHIFT, V>();
     const bool edge = !CB::interior(pair, a.n, a.parts);
     typename CB::Kept kept;
     sm.mark(tid);
@@ -199,9 +184,9 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, long long ne
         __syncthreads();
         conv_channel_partitioned<LOG2N, true, TSHIFT, V>(tid, pair, edge, a, ps, lds, mid_table);
     } else {
+        typename CB::Raw raw;
         typename CB::Held held;
-        // frames of the thread's first AHEAD butterflies are already on their way (issued by the previous pair)
-        CB::template fetch_frames<MGX_CONV_LD1_AUX, AHEAD, CB::CNT0>(tid, pair, edge, a, 0, raw);
+        CB::template fetch_frames<MGX_CONV_LD1_AUX>(tid, pair, a, 0, raw);
         conv_channel<LOG2N, false, TSHIFT, V>(
             tid, a, lds, mid_table, sm, [&]() { CB::phase_pass0_mid(tid, raw, ps, lds, held); });
         CB::phase_keep_mid(tid, ps, lds, kept);
@@ -211,19 +196,7 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, long long ne
         conv_channel<LOG2N, true, TSHIFT, V>(
             tid, a, lds, mid_table, sm, [&]() { CB::phase_pass0_side(tid, held, ps, lds); });
     }
-    // epilogue: outputs into registers, the next pair's loads, then the stores behind them
-    float pk;
-    if (AHEAD > 0) {
-        typename CB::Outputs out;
-        CB::phase_outputs(tid, ps, lds, kept, out);
-        __builtin_amdgcn_sched_barrier(0);
-        if (next >= 0)
-            CB::template fetch_frames<MGX_CONV_LD1_AUX, 0, AHEAD>(tid, next, !CB::interior(next, a.n, a.parts), a, 0, raw);
-        __builtin_amdgcn_sched_barrier(0);
-        pk = CB::store_outputs(tid, pair, edge, a, kept, out);
-    } else {
-        pk = CB::phase_store(tid, pair, edge, a, ps, lds, kept);
-    }
+    const float pk = CB::phase_store(tid, pair, edge, a, ps, lds, kept);
     sm.mark(tid);
     return pk;
 }
@@ -250,11 +223,7 @@ __global__ __launch_bounds__((Fft2<LOG2N, V>::T), (conv_waves_per_simd<LOG2N, V>
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
     const long long per = (a.npairs + 7) >> 3;
     const long long end = min(a.npairs, (xcd + 1) * per);
-    typename CB::Raw raw;
     const long long first = xcd * per + slot;
-    constexpr int AHEAD = conv_ahead<LOG2N, MULTI, TSHIFT, V>();
-    if (AHEAD > 0 && first < end)
-        CB::template fetch_frames<MGX_CONV_LD1_AUX, 0, AHEAD>(tid, first, !CB::interior(first, a.n, a.parts), a, 0, raw);
     for (long long pair = first; pair < end; pair += slots) {
         // The pass-0 twiddles stay in registers across pairs, but nothing derived from them (or
         // from the thread id) should: hoisted out of this loop it would sit in VGPRs it does
@@ -267,8 +236,7 @@ __global__ __launch_bounds__((Fft2<LOG2N, V>::T), (conv_waves_per_simd<LOG2N, V>
         sm.p = a.stamps && it < 8 ? a.stamps + ((long long)blockIdx.x * 8 + it) * 32 : nullptr;
         sm.i = 0;
 #endif
-        const long long next = pair + slots < end ? pair + slots : -1;
-        const float pk = conv_pair<LOG2N, MULTI, TSHIFT, V>(tid, pair, next, a, ps, raw, lds, mid_table, sm);
+        const float pk = conv_pair<LOG2N, MULTI, TSHIFT, V>(tid, pair, a, ps, lds, mid_table, sm);
         const float bp = block_max<F::T>(pk, scratch);
         if (tid == 0 && a.pair_peak) a.pair_peak[pair] = bp;
         __syncthreads();

@@ -92,7 +92,7 @@ static int conv_impl(const float* x, long long n, const double* fir_mid, const d
             else {
                 FOR_THREADS(F::T) {
                     typename CB::Raw raw;
-                    CB::fetch_frames(tid, pair, edge, a, 0, raw);
+                    CB::fetch_frames(tid, pair, a, 0, raw);
                     CB::phase_pass0_mid(tid, raw, ps[tid], lds.data(), held[tid]);
                 }
             }
