@@ -756,6 +756,16 @@ __global__ __launch_bounds__(1024) void k_correction_step(const double* partial,
 // number either way, up to float64 summation order.
 constexpr double BAND_G_LO = 0.7, BAND_G_HI = 1.5;
 constexpr int BAND_SLACK = 2048;             // floats of padding per workgroup in the band buffer
+// float32 thresholds on |m|, each rounded towards the inside of the band: |m| <= never implies
+// |m| <= 1/BAND_G_HI exactly, |m| >= always implies |m| > 1/BAND_G_LO
+__device__ __forceinline__ float band_threshold_never() {
+    const float t = (float)(1.0 / BAND_G_HI);
+    return (double)t <= 1.0 / BAND_G_HI ? t : __uint_as_float(__float_as_uint(t) - 1u);
+}
+__device__ __forceinline__ float band_threshold_always() {
+    const float t = (float)(1.0 / BAND_G_LO);
+    return (double)t > 1.0 / BAND_G_LO ? t : __uint_as_float(__float_as_uint(t) + 1u);
+}
 struct BandInfo {
     double unclipped_sumsq;                  // A: sum of m^2 over |m| <= 1/BAND_G_HI
     double clipped_count;                    // C: samples with |m| > 1/BAND_G_LO
@@ -814,17 +824,24 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
         for (int k = lane; k < count; k += 64) add(wave_band[k]);
         if (threadIdx.x == 0) acc += g * g * info->unclipped_sumsq + info->clipped_count;
     } else {
-        double low = 0.0, high = 0.0;
-        int filled = 0;                       // band samples this wave has stored: must stay wave-uniform,
-                                              // so every lane walks the same iterations and masks with `ok`
+        // Straight-line per-sample code (no divergent branches: every lane walks the same iterations and
+        // masks with `ok`; a branchy version of this loop made round 0 instruction-bound).  The band
+        // test runs in float32 against thresholds rounded INTO the band, which can only move a sample
+        // from the closed-form parts into the list -- the sum is the same either way.
+        double low = 0.0;
+        int filled = 0, clipped = 0;          // wave-uniform: band samples stored, always-clipped samples seen
         const unsigned long long below = (1ull << lane) - 1ull;
+        const float t_never = band_threshold_never(), t_always = band_threshold_always();
+        const bool build = a.build_band != 0;
         auto visit = [&](float v, bool ok) {
-            if (ok) add(v);
-            if (a.build_band) {
-                const double m = fabs((double)v);
-                const bool never = ok && m <= 1.0 / BAND_G_HI, always = ok && m > 1.0 / BAND_G_LO;
-                if (never) low = fma(m, m, low);
-                if (always) high += 1.0;
+            const double d = (double)(ok ? v : 0.f);
+            const double c = fmin(fmax(d * g, -1.0), 1.0);
+            acc = fma(c, c, acc);
+            if (build) {                       // uniform
+                const float m = fabsf(v);
+                const bool never = ok && m <= t_never, always = ok && m >= t_always;
+                low = fma(never ? d : 0.0, d, low);
+                clipped += __popcll(__ballot(always));
                 const bool in_band = ok && !never && !always;
                 const unsigned long long mask = __ballot(in_band);
                 if (in_band) wave_band[filled + __popcll(mask & below)] = v;
@@ -859,11 +876,11 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
             const bool ok = body_end + threadIdx.x < e;
             visit(ok ? a.mid[body_end + threadIdx.x] : 0.f, ok);
         }
-        if (a.build_band) {
+        if (build) {
             if (lane == 0) info->count[wave] = filled;
             const double lo = block_sum<256>(low, red);
             __syncthreads();
-            const double hi = block_sum<256>(high, red + 8);
+            const double hi = block_sum<256>(lane == 0 ? (double)clipped : 0.0, red + 8);
             if (threadIdx.x == 0) {
                 info->unclipped_sumsq = lo;
                 info->clipped_count = hi;
