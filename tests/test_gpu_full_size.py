@@ -108,3 +108,18 @@ def test_eight_4min_pairs_in_two_lanes_match_the_oracle():
         assert rms_error(many[b][0], want) <= RMS_TOL
     thr = mg.Config().threshold
     assert all(np.abs(m[0]).max() <= thr * (1 + 1e-5) for m in many)
+
+
+def test_maximum_length_15min_against_the_oracle():
+    """The longest track the reference accepts (``max_length`` = 15 minutes, defaults.py; checker.py:58):
+    39.7 M frames, 61 pieces, 4846 block pairs."""
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd.synth import make_pair
+
+    t, r = make_pair(900.0, 44100, pair=3)
+    got = stages.main(t, r, mg.Config(), need_default=True, need_no_limiter=True)
+    want = mo.master(t, r, mo.params(), True, True, False)
+    for mine, ref in zip(got[:2], want[:2]):
+        assert rms_error(mine, ref) <= RMS_TOL
+    assert np.abs(got[0]).max() <= mg.Config().threshold * (1 + 1e-5)
