@@ -148,18 +148,22 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
     typename CB::RowAcc acc;
     CB::clear_acc(acc);
     for (int k = 0; k < a.parts; ++k) {
-        CB::template phase_load<SIDE>(tid, pair, edge, a, ps, lds, k);
+        CB::template phase_load<SIDE>(opaque(tid), pair, edge, a, ps, lds, k);
+        __builtin_amdgcn_sched_barrier(0);
         CB::fetch_filter(tid, h + (size_t)k * F::N, rf);
         __syncthreads();
         if (F::P == 3) {
-            CB::phase_fwd_mid(tid, lds, mid_table);
+            CB::phase_fwd_mid(opaque(tid), lds, mid_table);
             __syncthreads();
         }
+        __builtin_amdgcn_sched_barrier(0);
         CB::phase_accumulate(tid, rf, lds, acc);
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
     }
     CB::phase_finish_row(tid, acc, lds);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     if (F::P == 3) {
         CB::phase_inv_mid(opaque(tid), lds, mid_table);
         __syncthreads();
@@ -660,10 +664,26 @@ __global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double*
     const int per = (half - 1 + 15) / 16;                   // bins 1 .. half-1 split over 16 lanes
     const int k0 = 1 + lane * per, k1 = min(half, k0 + per);
     double acc = 0.0;
-    int idx = (int)(((long long)k0 * mm) & (f - 1));
-    for (int k = k0; k < k1; ++k) {
-        acc = fma(sm[k], COS_IN_LDS ? cos_lds[idx] : pl.cos_table[idx], acc);
-        idx = (idx + mm) & (f - 1);
+    if (COS_IN_LDS) {
+        int idx = (int)(((long long)k0 * mm) & (f - 1));
+        for (int k = k0; k < k1; ++k) {
+            acc = fma(sm[k], cos_lds[idx], acc);
+            idx = (idx + mm) & (f - 1);
+        }
+    } else {
+        // The table does not fit the LDS (F = 16384): a look-up per term would be a gather through the
+        // L2 (measured 780 us per pair).  cos(2 pi k mm / F) for the slice's consecutive k by rotation
+        // instead: start and step come from the table (exact), the steps in between cost four
+        // float64 operations each and add ~1e-13 of error over a slice.
+        const int i0 = (int)(((long long)k0 * mm) & (f - 1));
+        double c = pl.cos_table[i0], sn = pl.cos_table[(i0 - f / 4) & (f - 1)];        // sin x = cos(x - pi/2)
+        const double dc = pl.cos_table[mm], ds = pl.cos_table[(mm - f / 4) & (f - 1)];
+        for (int k = k0; k < k1; ++k) {
+            acc = fma(sm[k], c, acc);
+            const double cn = fma(c, dc, -sn * ds);
+            sn = fma(sn, dc, c * ds);
+            c = cn;
+        }
     }
     red[threadIdx.x] = acc;
     __syncthreads();
