@@ -1,0 +1,68 @@
+"""The drop-in boundary without a GPU: libmgx.so loads, exports every function include/mgx.h
+declares, its structs have the layout the ctypes mirror assumes (checked against the C compiler's
+view of the header), and the entry points that need no device behave.  No compute is called here.
+"""
+
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+from matchering_amd import _native
+
+HEADER = os.path.join(ROOT, "include", "mgx.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return sorted(set(re.findall(r"\b(mgx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_binds():
+    names = declared_functions()
+    assert len(names) >= 25
+    assert sorted(_native.SYMBOLS) == names
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_native.LIB_PATH) if os.path.exists(_native.LIB_PATH) else _native.library()
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} is declared in include/mgx.h but not exported by libmgx.so"
+
+
+def test_struct_layouts_match_the_c_compiler(tmp_path):
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mgx.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu\\n", sizeof(mgx_config), sizeof(mgx_report),\n'
+                   '  offsetof(mgx_config, lowess_delta), offsetof(mgx_config, release_filter_coefficient),\n'
+                   '  offsetof(mgx_report, limiter_active)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    c = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert c[0] == ctypes.sizeof(_native.MgxConfig)
+    assert c[1] == ctypes.sizeof(_native.MgxReport)
+    assert c[2] == _native.MgxConfig.lowess_delta.offset
+    assert c[3] == _native.MgxConfig.release_filter_coefficient.offset
+    assert c[4] == _native.MgxReport.limiter_active.offset
+
+
+def test_entry_points_that_need_no_device():
+    lib = _native.library()
+    assert lib.mgx_version() > 0
+    cfg = _native.MgxConfig()
+    assert lib.mgx_config_default(ctypes.byref(cfg)) == 0
+    assert cfg.internal_sample_rate == 44100 and cfg.fft_size == 4096 and cfg.rms_correction_steps == 4
+    assert abs(cfg.threshold - (2 ** 15 - 61) / 2 ** 15) < 1e-15          # defaults.py:64
+    n = ctypes.c_int(-1)
+    rc = lib.mgx_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible: the no-device behaviour cannot be observed here")
+    h = ctypes.c_void_p()
+    rc = lib.mgx_create(0, ctypes.byref(h))
+    assert rc < 0 and not h.value                      # no CPU path: creation fails, loudly
+    assert lib.mgx_last_error()                        # ... with a message
