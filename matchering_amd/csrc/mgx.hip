@@ -166,6 +166,15 @@ static int check_config(const mgx_config* c) {
     return 0;
 }
 
+// Kernels address a track through a buffer view with 32-bit byte offsets (mgx_hd.h MemView): 8 bytes
+// per frame plus the look-ahead of a convolution block must stay below 4 GiB.  That is 3.3 hours at
+// 44.1 kHz; the reference stops at max_length = 15 minutes by default (defaults.py, checker.py:58).
+static int check_length(long long n) {
+    const long long max_frames = (0xfffffff0ll >> 3) - (1 << 16);
+    if (n > max_frames) return fail(MGX_ERR_UNSUPPORTED, "tracks longer than 536 million frames are not implemented");
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // stage runners (asynchronous on h->stream)
 // ---------------------------------------------------------------------------
@@ -196,6 +205,7 @@ static int run_analysis(mgx_handle* h, const float* x, long long n, const mgx_co
                         TrackWork& w) {
     const int f = cfg->fft_size, half = f / 2;
     if (n <= f) return fail(MGX_ERR_ARGUMENT, "track must be longer than fft_size frames (core.py:69-74)");
+    MGX_TRY(check_length(n));
     piece_geometry(n, cfg->max_piece_size, w.divisions, w.piece);
     w.segs_per_piece = (int)(w.piece / f);
     if (w.segs_per_piece < 1)
@@ -426,6 +436,7 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
                     const double* gain_ptr = nullptr) {
     const int l = ilog2_exact(taps);
     if (l < 0) return fail(MGX_ERR_ARGUMENT, "FIR length must be a power of two");
+    MGX_TRY(check_length(n));
     int log2b = l + 1;
     if (log2b > 14) log2b = 13;
     if (const char* forced = std::getenv("MGX_CONV_BLOCK_LOG2")) {
