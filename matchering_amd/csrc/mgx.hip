@@ -65,6 +65,7 @@ struct TrackWork {              // per-track analysis workspace + results (devic
 struct PlanDev {
     void* blob = nullptr;       // FirPlanHost tables
     double* M = nullptr;        // [bins][bins] raw -> smooth operator
+    int2* band = nullptr;       // [bins] columns [x, y) of each row that matter (k_fir_band)
 };
 
 struct mgx_handle {
@@ -308,7 +309,7 @@ static int run_levels(mgx_handle* h, const mgx_config* cfg, TrackWork* first, Tr
 // device-side FIR design (fir_plan.h): spectra partial sums of both tracks -> h->taps ([2][F] float),
 // level gain c0 -> h->scalars[0].  No host synchronisation.  The chain raw -> smooth is one dense
 // operator per plan (mgx_kernels.h), built on first use.
-static int build_fir_operator(mgx_handle* h, const FirPlanView& pl, double** out) {
+static int build_fir_operator(mgx_handle* h, const FirPlanView& pl, double** out, int2** band_out) {
     const size_t per = (size_t)3 * pl.bins + (size_t)3 * pl.nlog + pl.lw.anchors;
     const int batch = std::min(pl.bins, 256);
     double* scratch = nullptr;
@@ -324,10 +325,14 @@ static int build_fir_operator(mgx_handle* h, const FirPlanView& pl, double** out
         hipLaunchKernelGGL(k_fir_gather, dim3((nb + 255) / 256, pl.bins), dim3(256), 0, h->stream, pl, scratch, col0,
                            nb, M);
     }
+    int2* band = nullptr;
+    HIP_TRY(hipMalloc((void**)&band, (size_t)pl.bins * sizeof(int2)));
+    hipLaunchKernelGGL(k_fir_band, dim3(pl.bins), dim3(256), 0, h->stream, (const double*)M, pl.bins, band);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipFree(scratch));
     *out = M;
+    *band_out = band;
     return 0;
 }
 
@@ -340,7 +345,7 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     if (it == h->plan_dev.end()) {
         HIP_TRY(hipMalloc(&pd.blob, plan->blob_bytes()));
         HIP_TRY(hipMemcpy(pd.blob, plan->blob(), plan->blob_bytes(), hipMemcpyHostToDevice));
-        MGX_TRY(build_fir_operator(h, plan->view(pd.blob), &pd.M));
+        MGX_TRY(build_fir_operator(h, plan->view(pd.blob), &pd.M, &pd.band));
         h->plan_dev[plan.get()] = pd;
         h->plans.push_back(plan);
     } else {
@@ -365,7 +370,7 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     hipLaunchKernelGGL(k_fir_raw, dim3((pl.bins + 255) / 256, 2), dim3(256), 0, h->stream, pl, in, raw,
                        (double*)h->scalars.p, (CorrectionState*)h->cstate.p);
     hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
-                       (const double*)raw, scratch);
+                       (const int2*)pd.band, (const double*)raw, scratch);
     // the cosine table rides in LDS when it fits (F <= 8192), otherwise it is read through L2
     const bool cos_in_lds = ((size_t)pl.fft + pl.bins + 1024) * sizeof(double) <= (size_t)150 * 1024;
     const size_t lds_taps = ((cos_in_lds ? (size_t)pl.fft : 0) + pl.bins + 1024) * sizeof(double);
@@ -640,6 +645,7 @@ int mgx_destroy(mgx_handle* h) {
     for (auto& kv : h->plan_dev) {
         if (kv.second.blob) hipFree(kv.second.blob);
         if (kv.second.M) hipFree(kv.second.M);
+        if (kv.second.band) hipFree(kv.second.band);
     }
     if (h->pinned) hipHostFree(h->pinned);
     hipEventDestroy(h->ev0);

@@ -29,6 +29,11 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
 // scratch: at least (threads/64) floats / doubles of LDS; result valid on thread 0
 template <int THREADS>
 __device__ __forceinline__ float block_max(float v, float* scratch) {
@@ -583,27 +588,56 @@ __global__ __launch_bounds__(256) void k_fir_raw(FirPlanView pl, FirInputs in, d
     const double ar = spectrum_at(in.part_r, plane, pl.bins, k) * sc_r;
     raw[(size_t)plane * pl.bins + k] = ar / fmax(pl.min_value, at);
 }
-// smooth[plane][i] = sum_j M[i][j] raw[plane][j]: one 256-thread workgroup per row, both channels per
-// pass over the row, every load of the row in flight at once (bins <= 256 * MATVEC_PER_THREAD)
-__global__ __launch_bounds__(256) void k_fir_matvec(FirPlanView pl, const double* M, const double* raw,
-                                                    double* scratch) {
+// The operator is numerically banded: LOWESS looks at 3.75 % of the log-frequency grid and the
+// splines' influence decays geometrically, so outside a window around the diagonal (about a third of
+// the bin index wide) every entry is below 1e-18 of the row's largest.  k_fir_band records that
+// window per row once per plan; the product then reads only it (a sixth of the matrix).
+constexpr double BAND_EPS = 1e-18;
+__global__ __launch_bounds__(256) void k_fir_band(const double* M, int bins, int2* band) {
+    __shared__ double dred[4];
+    __shared__ int ired[2][4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const double* m = M + (size_t)row * bins;
+    double mx = 0.0;
+    for (int j = tid; j < bins; j += 256) mx = fmax(mx, fabs(m[j]));
+    mx = wave_max_f64(mx);
+    if ((tid & 63) == 0) dred[tid >> 6] = mx;
+    __syncthreads();
+    const double cut = fmax(fmax(dred[0], dred[1]), fmax(dred[2], dred[3])) * BAND_EPS;
+    int lo = bins, hi = 0;
+    for (int j = tid; j < bins; j += 256)
+        if (fabs(m[j]) > cut) { lo = min(lo, j); hi = max(hi, j + 1); }
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if ((tid & 63) == 0) { ired[0][tid >> 6] = lo; ired[1][tid >> 6] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+        lo = min(min(ired[0][0], ired[0][1]), min(ired[0][2], ired[0][3]));
+        hi = max(max(ired[1][0], ired[1][1]), max(ired[1][2], ired[1][3]));
+        band[row] = lo < hi ? make_int2(lo, hi) : make_int2(0, 0);
+    }
+}
+// smooth[plane][i] = sum_j M[i][j] raw[plane][j] over the row's window: one 256-thread workgroup per
+// row, both channels per pass, ten loads per thread in flight
+__global__ __launch_bounds__(256) void k_fir_matvec(FirPlanView pl, const double* M, const int2* band,
+                                                    const double* raw, double* scratch) {
     __shared__ double red[2][4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const double* m = M + (size_t)row * pl.bins;
     const double* r0 = raw;
     const double* r1 = raw + pl.bins;
+    const int first = band[row].x, last = band[row].y;
     double a0 = 0.0, a1 = 0.0;
-    for (int j0 = tid; j0 < pl.bins; j0 += 256 * 10) {
+    for (int j0 = first + tid; j0 < last; j0 += 256 * 10) {
         double v[10];
 #pragma unroll
         for (int u = 0; u < 10; ++u) {
             const int j = j0 + 256 * u;
-            v[u] = j < pl.bins ? m[j] : 0.0;
+            v[u] = j < last ? m[j] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < 10; ++u) {
             const int j = j0 + 256 * u;
-            if (j < pl.bins) {
+            if (j < last) {
                 a0 = fma(v[u], r0[j], a0);
                 a1 = fma(v[u], r1[j], a1);
             }
