@@ -56,6 +56,7 @@ struct Conv2Args {
     int parts;             // filter partitions K: taps = K * N/2 (1 = plain overlap-save)
     long long npairs;      // ceil(n / N)
     float* pair_peak;      // [npairs] max(|yL|,|yR|) per pair, or nullptr
+    unsigned* queue;       // [8] pairs handed out per XCD beyond the first round, [8] workgroups done; zero between launches
 #ifdef MGX_CONV_STAMPS
     long long* stamps;     // [workgroups][8 pairs][32] s_memtime values (timing experiments)
 #endif

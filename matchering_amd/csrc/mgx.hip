@@ -74,7 +74,7 @@ struct mgx_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::map<int, float2*> twiddles;
     TrackWork track[2];
-    DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars;
+    DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars, conv_queue;
     DevBuf lim_published, lim_ctrl, lim_weights, round_ctr, band, band_info;
     std::vector<double> lim_weights_host;
     DevBuf fir_scratch;
@@ -400,6 +400,11 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
     HIP_TRY(hipGetLastError());
     MGX_TRY(ensure(h, h->block_peak, (size_t)a.npairs * sizeof(float)));
     a.pair_peak = (float*)h->block_peak.p;
+    if (!h->conv_queue.p) {                  // zero once: every launch leaves the counters at zero
+        MGX_TRY(ensure(h, h->conv_queue, 64));
+        HIP_TRY(hipMemsetAsync(h->conv_queue.p, 0, 64, h->stream));
+    }
+    a.queue = (unsigned*)h->conv_queue.p;
     // persistent grid: as many workgroups as fit the chip at once (LDS-limited), a multiple of 8
     int dev_cus = 256;
     HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device));
@@ -633,7 +638,8 @@ int mgx_destroy(mgx_handle* h) {
     hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
-                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch, &h->round_ctr, &h->band, &h->band_info};
+                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch, &h->round_ctr, &h->band, &h->band_info,
+                      &h->conv_queue};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (TrackWork& w : h->track) {

@@ -65,7 +65,7 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // ---------------------------------------------------------------------------
 template <int LOG2N, int V = 0>
 constexpr size_t conv_lds_bytes() {
-    return ((size_t)Fft2<LOG2N, V>::LDS_ELEMS + Fft2<LOG2N, V>::MID_TABLE) * sizeof(float2) + 64;
+    return ((size_t)Fft2<LOG2N, V>::LDS_ELEMS + Fft2<LOG2N, V>::MID_TABLE) * sizeof(float2) + 128;
 }
 
 // The phases of a kernel share index arithmetic (LDS addresses derived from the thread id).  Left
@@ -214,6 +214,9 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2A
 // XCD w % 8, so XCD x walks its own contiguous eighth of the track and the workgroups resident on
 // it work on neighbouring pairs: the overlap between neighbours is re-read from that XCD's L2,
 // not from HBM.  Placement only affects speed, never results.
+// After its first pair a workgroup takes the next pair of its XCD's range from a counter (asked for at
+// the start of a pair, needed at its end) instead of a fixed stride: an 8-minute track is 5.05 pairs
+// per workgroup, and with fixed strides the kernel lasted six pair-times for it.
 // Two workgroups per CU (LDS): the second launch bound is waves per SIMD, i.e. the register budget.
 // MULTI = more than one filter partition (its own instantiation: the accumulator row costs registers
 // the plain kernel should not pay for)
@@ -233,7 +236,11 @@ __global__ __launch_bounds__((Fft2<LOG2N, V>::T), (conv_waves_per_simd<LOG2N, V>
     const long long per = (a.npairs + 7) >> 3;
     const long long end = min(a.npairs, (xcd + 1) * per);
     const long long first = xcd * per + slot;
-    for (long long pair = first; pair < end; pair += slots) {
+    int* next_slot = reinterpret_cast<int*>(scratch + 16);
+    long long pair = first;
+    for (int it = 0; pair < end; ++it) {
+        unsigned ticket = 0;
+        if (tid == 0) ticket = atomicAdd(a.queue + xcd, 1u);
         // The pass-0 twiddles stay in registers across pairs, but nothing derived from them (or
         // from the thread id) should: hoisted out of this loop it would sit in VGPRs it does
         // not have.  An empty asm makes the values opaque per iteration.
@@ -241,15 +248,22 @@ __global__ __launch_bounds__((Fft2<LOG2N, V>::T), (conv_waves_per_simd<LOG2N, V>
         for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
         Stamper sm;
 #ifdef MGX_CONV_STAMPS
-        const long long it = (pair - (xcd * per + slot)) / slots;
         sm.p = a.stamps && it < 8 ? a.stamps + ((long long)blockIdx.x * 8 + it) * 32 : nullptr;
         sm.i = 0;
 #endif
         const float pk = conv_pair<LOG2N, MULTI, TSHIFT, V>(tid, pair, a, ps, lds, mid_table, sm);
         const float bp = block_max<F::T>(pk, scratch);
-        if (tid == 0 && a.pair_peak) a.pair_peak[pair] = bp;
+        if (tid == 0) {
+            if (a.pair_peak) a.pair_peak[pair] = bp;
+            *next_slot = (int)ticket;
+        }
         __syncthreads();
+        pair = xcd * per + slots + *next_slot;
         sm.mark(tid);
+    }
+    // the last workgroup to run out of pairs leaves the counters at zero for the next launch
+    if (tid == 0 && atomicAdd(a.queue + 8, 1u) == gridDim.x - 1) {
+        for (int i = 0; i < 9; ++i) a.queue[i] = 0;
     }
 }
 
