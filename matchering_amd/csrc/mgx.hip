@@ -376,11 +376,11 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     const size_t lds_taps = ((cos_in_lds ? (size_t)pl.fft : 0) + pl.bins + 1024) * sizeof(double);
     if (cos_in_lds) {
         MGX_TRY(allow_lds(k_fir_taps<true>, lds_taps));
-        hipLaunchKernelGGL(k_fir_taps<true>, dim3(pl.fft / 64, 2), dim3(1024), lds_taps, h->stream, pl,
+        hipLaunchKernelGGL(k_fir_taps<true>, dim3(pl.fft / TAPS_PER_WG, 2), dim3(1024), lds_taps, h->stream, pl,
                            (const double*)scratch, (float*)h->taps.p);
     } else {
         MGX_TRY(allow_lds(k_fir_taps<false>, lds_taps));
-        hipLaunchKernelGGL(k_fir_taps<false>, dim3(pl.fft / 64, 2), dim3(1024), lds_taps, h->stream, pl,
+        hipLaunchKernelGGL(k_fir_taps<false>, dim3(pl.fft / TAPS_PER_WG, 2), dim3(1024), lds_taps, h->stream, pl,
                            (const double*)scratch, (float*)h->taps.p);
     }
     HIP_TRY(hipGetLastError());

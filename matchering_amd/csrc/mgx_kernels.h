@@ -694,7 +694,9 @@ __global__ __launch_bounds__(1024) void k_fir_b(FirPlanView pl, double* scratch)
     FirDesign::phase_pin(tid, s);
 }
 // irfft + ifftshift + Hann (match_frequencies.py:98-99).  grid = (F/64, 2); a workgroup
-// computes 64 taps, 16 lanes each summing a slice of the bins.
+// computes TAPS_PER_WG taps, 1024 / TAPS_PER_WG lanes each summing a slice of the bins (the sum over a
+// slice is one dependent chain, so short slices matter more than few workgroups).
+constexpr int TAPS_PER_WG = 16, TAP_SLICES = 1024 / TAPS_PER_WG;
 template <bool COS_IN_LDS>
 __global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double* scratch, float* taps /* [2][F] */) {
     MGX_LDS;
@@ -707,9 +709,9 @@ __global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double*
         for (int i = threadIdx.x; i < f; i += 1024) cos_lds[i] = pl.cos_table[i];
     for (int i = threadIdx.x; i < pl.bins; i += 1024) sm[i] = s.smooth[i];
     __syncthreads();
-    const int i = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+    const int i = blockIdx.x * TAPS_PER_WG + (threadIdx.x % TAPS_PER_WG), lane = threadIdx.x / TAPS_PER_WG;
     const int mm = (i + half) & (f - 1);
-    const int per = (half - 1 + 15) / 16;                   // bins 1 .. half-1 split over 16 lanes
+    const int per = (half - 1 + TAP_SLICES - 1) / TAP_SLICES;   // bins 1 .. half-1 split over the lanes
     const int k0 = 1 + lane * per, k1 = min(half, k0 + per);
     double acc = 0.0;
     if (COS_IN_LDS) {
@@ -737,8 +739,8 @@ __global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double*
     __syncthreads();
     if (lane == 0) {
         double t = 0.0;
-#pragma unroll
-        for (int l = 0; l < 16; ++l) t += red[l * 64 + (threadIdx.x & 63)];
+#pragma unroll 8
+        for (int l = 0; l < TAP_SLICES; ++l) t += red[l * TAPS_PER_WG + threadIdx.x];
         const double v = (sm[0] + ((mm & 1) ? -sm[half] : sm[half]) + 2.0 * t) / f * pl.hann[i];
         taps[(size_t)plane * f + i] = (float)v;
     }
