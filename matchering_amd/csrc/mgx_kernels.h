@@ -278,6 +278,7 @@ __global__ __launch_bounds__((Fft2<LOG2N, V>::T)) void k_conv_prep(const float* 
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
     float2* mid_table = lds + F::LDS_ELEMS;
     const int tid = threadIdx.x, ch = blockIdx.x / parts, k = blockIdx.x % parts;
+    const double g = gain_ptr ? *gain_ptr * gain : gain;      // asked for first: nothing below should wait for it
     typename CB::Persist ps;
     CB::load_persist(tid, tw, mid_table, ps);
     CB::phase_load_taps(tid, taps + ((size_t)ch * parts + k) * CB::TAPS, ps, lds);
@@ -286,7 +287,6 @@ __global__ __launch_bounds__((Fft2<LOG2N, V>::T)) void k_conv_prep(const float* 
         CB::phase_fwd_mid(tid, lds, mid_table);
         __syncthreads();
     }
-    const double g = gain_ptr ? *gain_ptr * gain : gain;
     CB::phase_write_filter(tid, lds, (float)(g / (double)F::N), tables + ((size_t)ch * parts + k) * F::N);
 }
 
