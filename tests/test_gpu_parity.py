@@ -279,3 +279,31 @@ def test_rccl_single_rank_collectives():
         assert np.array_equal(own, got) and np.all(np.isfinite(own)) and np.abs(own).max() > 0
     finally:
         check(lib.mgx_comm_destroy(dev.handle))
+
+
+def test_thin_plan_convolution_switch():
+    """The 512-thread transform plan of k_conv (MGX_EXP_CONV_THIN, kept as an experiment switch) gives the
+    same convolution.  The switch is read once per process, hence the child process."""
+    import os
+    import subprocess
+    import sys
+
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import mastering_oracle as mo\n"
+        "from matchering_amd import kernels\n"
+        "rng = np.random.RandomState(9)\n"
+        "x = (0.3 * rng.randn(70001, 2)).astype(np.float32)\n"
+        "hm, hs = rng.randn(4096) / 64, rng.randn(4096) / 64\n"
+        "y, ymid, _ = kernels.convolve(x, hm, hs)\n"
+        "mid, side = mo.mid_side(x.astype(np.float64))\n"
+        "want, want_mid = mo.convolve_same(mid, hm, side, hs)\n"
+        "err = float(np.sqrt(np.mean((y - want) ** 2)))\n"
+        "assert err <= 1e-6, err\n"
+        "print('thin ok', err)\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+         os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    env = dict(os.environ, MGX_EXP_CONV_THIN="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "thin ok" in out.stdout, out.stderr[-2000:]
