@@ -81,7 +81,7 @@ struct Conv2Block {
     static constexpr int HALF = R0 - SKIP;           // outputs kept per pass-0 butterfly
     static constexpr int BSTEP = LOUT / S0;          // block B = block A advanced by BSTEP butterfly inputs
     static constexpr int NLOAD = R0 + BSTEP;         // frames loaded per pass-0 butterfly
-    static_assert(TAPS % S0 == 0 && LOUT % S0 == 0 || F::partial(0), "block geometry must follow the pass-0 stride");
+    static_assert((TAPS % S0 == 0 && LOUT % S0 == 0) || F::partial(0), "block geometry must follow the pass-0 stride");
 
     struct Persist {
         typename F::Tw0 tw0;

@@ -239,6 +239,7 @@ __global__ __launch_bounds__((Fft2<LOG2N, V>::T), (conv_waves_per_simd<LOG2N, V>
     int* next_slot = reinterpret_cast<int*>(scratch + 16);
     long long pair = first;
     for (int it = 0; pair < end; ++it) {
+        (void)it;                               // numbers the pair for the phase stamps only
         unsigned ticket = 0;
         if (tid == 0) ticket = atomicAdd(a.queue + xcd, 1u);
         // The pass-0 twiddles stay in registers across pairs, but nothing derived from them (or
