@@ -281,6 +281,22 @@ def test_rccl_single_rank_collectives():
         check(lib.mgx_comm_destroy(dev.handle))
 
 
+@pytest.mark.parametrize("steps", [0, 1, 7])
+def test_correction_step_counts(steps):
+    """`rms_correction_steps` other than the default 4 (stages.py:149-168): none at all (the peak and
+    early-out scalars then come from their own kernel), a single round (first and last at once), many."""
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd.synth import make_pair
+
+    t, r = make_pair(9.0, 44100, pair=4, reference_seconds=7.0)
+    kw = dict(rms_correction_steps=steps, max_piece_size=2.0)
+    got = stages.main(t, r, mg.Config(**kw), need_default=True, need_no_limiter=True, need_no_limiter_normalized=True)
+    want = mo.master(t, r, mo.params(**kw), True, True, True)
+    for mine, ref in zip(got, want):
+        assert rms_error(mine, ref) <= RMS_TOL
+
+
 def test_thin_plan_convolution_switch():
     """The 512-thread transform plan of k_conv (MGX_EXP_CONV_THIN, kept as an experiment switch) gives the
     same convolution.  The switch is read once per process, hence the child process."""
