@@ -297,6 +297,31 @@ def test_correction_step_counts(steps):
         assert rms_error(mine, ref) <= RMS_TOL
 
 
+@pytest.mark.parametrize("case", ["shortest target", "shortest reference", "silent target", "hot target"])
+def test_degenerate_inputs(case):
+    """Inputs at the edges of what core.py:69-74 lets through: a track of fft_size + 1 frames (one analysis
+    segment, one block pair), digital silence (every level clamps to min_value), a target far above
+    full scale."""
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd.synth import make_pair
+
+    t, r = make_pair(3.0, 44100, pair=2)
+    if case == "shortest target":
+        t = np.ascontiguousarray(t[:4097])
+    elif case == "shortest reference":
+        r = np.ascontiguousarray(r[:4097])
+    elif case == "silent target":
+        t = np.zeros_like(t)
+    else:
+        t = t * np.float32(8.0)
+    got = stages.main(t, r, mg.Config(), need_default=True, need_no_limiter=True, need_no_limiter_normalized=True)
+    want = mo.master(t, r, mo.params(), True, True, True)
+    for mine, ref in zip(got, want):
+        assert np.all(np.isfinite(mine))
+        assert rms_error(mine, ref) <= RMS_TOL
+
+
 def test_thin_plan_convolution_switch():
     """The 512-thread transform plan of k_conv (MGX_EXP_CONV_THIN, kept as an experiment switch) gives the
     same convolution.  The switch is read once per process, hence the child process."""
