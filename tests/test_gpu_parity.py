@@ -322,6 +322,28 @@ def test_degenerate_inputs(case):
         assert rms_error(mine, ref) <= RMS_TOL
 
 
+@pytest.mark.parametrize("rate", [8000, 22050, 48000, 88200, 192000])
+def test_other_sample_rates(rate):
+    """Window lengths, filter poles and piece sizes all follow `internal_sample_rate` (hyrax.py:35-75,
+    defaults.py:109); the limiter's chunk geometry is derived from them."""
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd._native import MgxError
+    from matchering_amd.synth import make_pair
+
+    seconds = 4.0 if rate <= 48000 else 2.0
+    t, r = make_pair(seconds, rate, pair=6, reference_seconds=seconds * 0.8)
+    kw = dict(internal_sample_rate=rate, max_piece_size=1.0)
+    want = mo.master(t, r, mo.params(**kw), True, True, False)
+    try:
+        got = stages.main(t, r, mg.Config(**kw), need_default=True, need_no_limiter=True)
+    except MgxError as exc:                        # a documented limit must say so, not miscompute
+        assert exc.code == -4, exc
+        pytest.skip(f"unsupported at {rate} Hz: {exc}")
+    for mine, ref in zip(got[:2], want[:2]):
+        assert rms_error(mine, ref) <= RMS_TOL
+
+
 def test_thin_plan_convolution_switch():
     """The 512-thread transform plan of k_conv (MGX_EXP_CONV_THIN, kept as an experiment switch) gives the
     same convolution.  The switch is read once per process, hence the child process."""
