@@ -344,6 +344,22 @@ def test_other_sample_rates(rate):
         assert rms_error(mine, ref) <= RMS_TOL
 
 
+@pytest.mark.parametrize("fft_size", [64, 256, 1024, 2048, 8192])
+def test_other_fft_sizes(fft_size):
+    """Every transform plan end to end: analysis segments of fft_size frames and convolution blocks of
+    twice that (fft2.h plans 6..14)."""
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd.synth import make_pair
+
+    t, r = make_pair(3.0, 44100, pair=8, reference_seconds=2.5)
+    kw = dict(fft_size=fft_size, max_piece_size=1.0)
+    got = stages.main(t, r, mg.Config(**kw), need_default=True, need_no_limiter=True)
+    want = mo.master(t, r, mo.params(**kw), True, True, False)
+    for mine, ref in zip(got[:2], want[:2]):
+        assert rms_error(mine, ref) <= RMS_TOL
+
+
 def test_thin_plan_convolution_switch():
     """The 512-thread transform plan of k_conv (MGX_EXP_CONV_THIN, kept as an experiment switch) gives the
     same convolution.  The switch is read once per process, hence the child process."""
