@@ -1057,12 +1057,32 @@ __global__ __launch_bounds__(256) void k_scale_outputs(const float2* y, long lon
                                                        float2* out_plain, float2* out_normalized) {
     const double g = (gain_ptr ? *gain_ptr : 1.0) * gain_mul;
     const double inv = normalize_ptr ? *normalize_ptr : 1.0;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float2 v = y[i];
-        const double l = (double)v.x * g, r = (double)v.y * g;
+    // two frames (16 bytes) per access where every buffer allows it; the odd last frame, if any, goes alone
+    const bool wide = (((size_t)y | (size_t)out_plain | (size_t)out_normalized) & 15) == 0;
+    if (!wide) {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+            const float2 v = y[i];
+            const double l = (double)v.x * g, r = (double)v.y * g;
+            if (out_plain) out_plain[i] = make_float2((float)l, (float)r);
+            if (out_normalized) out_normalized[i] = make_float2((float)(l / inv), (float)(r / inv));
+        }
+        return;
+    }
+    const long long pairs = n >> 1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (long long)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(y)[i];
+        const double a = (double)v.x * g, b = (double)v.y * g, c = (double)v.z * g, d = (double)v.w * g;
         // (plain stores: non-temporal ones measured 58 vs 54 us here)
-        if (out_plain) out_plain[i] = make_float2((float)l, (float)r);
-        if (out_normalized) out_normalized[i] = make_float2((float)(l / inv), (float)(r / inv));
+        if (out_plain) reinterpret_cast<float4*>(out_plain)[i] = make_float4((float)a, (float)b, (float)c, (float)d);
+        if (out_normalized)
+            reinterpret_cast<float4*>(out_normalized)[i] =
+                make_float4((float)(a / inv), (float)(b / inv), (float)(c / inv), (float)(d / inv));
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const float2 v = y[n - 1];
+        const double l = (double)v.x * g, r = (double)v.y * g;
+        if (out_plain) out_plain[n - 1] = make_float2((float)l, (float)r);
+        if (out_normalized) out_normalized[n - 1] = make_float2((float)(l / inv), (float)(r / inv));
     }
 }
 
