@@ -54,6 +54,48 @@ def test_wav_agrees_with_stdlib_wave(tmp_path, width):
     assert rate == 22050 and np.abs(y - np.rint(x * 32767) / 32768).max() <= 1e-12
 
 
+@pytest.mark.parametrize("subtype,tol", [("PCM_S8", 1.5 / 2 ** 7), ("PCM_16", 1.5 / 2 ** 15), ("PCM_24", 1.5 / 2 ** 23),
+                                         ("PCM_32", 1.5 / 2 ** 31), ("FLOAT", 1e-7), ("DOUBLE", 0.0)])
+def test_aiff_round_trip(tmp_path, subtype, tol):
+    x = _signal(2777)
+    path = str(tmp_path / "a.aiff")
+    audio_io.write_aiff(path, x, 96000, subtype)
+    y, rate = audio_io.read_aiff(path)
+    assert rate == 96000 and y.shape == x.shape
+    assert np.abs(y - x).max() <= tol
+
+
+def test_aiff_agrees_with_stdlib_aifc(tmp_path):
+    aifc = pytest.importorskip("aifc")                   # in the standard library up to Python 3.12
+    x = _signal(1500)
+    ours = str(tmp_path / "ours.aiff")
+    audio_io.write_aiff(ours, x, 44100, "PCM_24")
+    with aifc.open(ours, "rb") as f:                     # our writer, stdlib reader
+        assert (f.getnchannels(), f.getsampwidth(), f.getframerate(), f.getnframes()) == (2, 3, 44100, 1500)
+        raw = np.frombuffer(f.readframes(1500), dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+    v = (raw[:, 0] << 16) | (raw[:, 1] << 8) | raw[:, 2]
+    v = np.where(v & 0x800000, v - (1 << 24), v).reshape(1500, 2)
+    assert np.array_equal(v, np.rint(x * (2 ** 23 - 1)).astype(np.int64))
+    theirs = str(tmp_path / "theirs.aiff")               # stdlib writer, our reader
+    q = np.rint(x * 32767).astype(">i2")
+    with aifc.open(theirs, "wb") as f:
+        f.setnchannels(2)
+        f.setsampwidth(2)
+        f.setframerate(22050)
+        f.writeframes(q.tobytes())
+    y, rate = audio_io.read_aiff(theirs)
+    assert rate == 22050 and np.array_equal(y, q.astype(np.float64) / 32768.0)
+
+
+def test_load_and_save_pick_the_codec_by_content_and_extension(tmp_path):
+    x = _signal(900)
+    path = str(tmp_path / "result.aiff")
+    audio_io.save(path, x, 48000, "FLOAT")
+    y, rate = audio_io.load(path, "target", str(tmp_path))
+    assert rate == 48000 and np.abs(y - x).max() <= 1e-7
+    assert mg.Result(str(tmp_path / "x.aiff"), subtype="FLOAT", use_limiter=False, normalize=False).subtype == "FLOAT"
+
+
 def test_load_errors_follow_the_reference_codes(tmp_path):
     bad = tmp_path / "noise.bin"
     bad.write_bytes(b"this is not audio")
@@ -169,3 +211,39 @@ def test_preview_picks_the_loudest_window(tmp_path):
 def test_process_rejects_an_empty_result_list():
     with pytest.raises(RuntimeError, match="The result list is empty"):
         mg.process("a.wav", "b.wav", [])
+
+
+@pytest.mark.parametrize("script", ["basic.py", "several_results.py", "custom_logging.py", "custom_config.py",
+                                    "with_previews.py", "batch_of_pairs.py"])
+def test_examples_use_the_api_as_it_is(script, monkeypatch):
+    """Every script under examples/ runs up to its process() / process_batch() call with arguments that
+    call accepts (the calls themselves need a GPU and real files, so they are intercepted)."""
+    import inspect
+    import os
+    import runpy
+
+    from conftest import ROOT
+    from matchering_amd import batch, core
+
+    seen = {}
+
+    def fake_process(*args, **kwargs):
+        bound = inspect.signature(core.process).bind(*args, **kwargs)
+        seen["results"] = bound.arguments["results"]
+        assert all(isinstance(r, mg.Result) for r in seen["results"])
+        for key in ("preview_target", "preview_result"):
+            assert bound.arguments.get(key) is None or isinstance(bound.arguments[key], mg.Result)
+        cfg = bound.arguments.get("config")
+        assert cfg is None or isinstance(cfg.to_native().fft_size, int)
+
+    def fake_batch(*args, **kwargs):
+        bound = inspect.signature(batch.process_batch).bind(*args, **kwargs)
+        seen["results"] = [r for job in bound.arguments["jobs"] for r in job["results"]]
+        return list(range(len(bound.arguments["jobs"])))
+
+    monkeypatch.setattr(mg, "process", fake_process)
+    monkeypatch.setattr(mg, "process_batch", fake_batch)
+    monkeypatch.setattr("sys.argv", [script])
+    runpy.run_path(os.path.join(ROOT, "examples", script), run_name="__main__")
+    assert seen["results"]
+    mg.log()                                        # examples install handlers: put the defaults back
