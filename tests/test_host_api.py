@@ -247,3 +247,53 @@ def test_examples_use_the_api_as_it_is(script, monkeypatch):
     runpy.run_path(os.path.join(ROOT, "examples", script), run_name="__main__")
     assert seen["results"]
     mg.log()                                        # examples install handlers: put the defaults back
+
+
+def test_process_file_pipeline_on_cpu(tmp_path, monkeypatch):
+    """core.process end to end without a GPU: load -> check -> stages.main -> save -> previews, with
+    stages.main replaced by the float64 oracle (the product itself has no CPU path).  Checks which of
+    the three outputs each Result receives (core.py:99-108) and the log codes' order."""
+    import mastering_oracle as mo
+    from matchering_amd import core
+    from matchering_amd.synth import make_pair
+
+    rate = 44100
+    t, r = make_pair(8.0, rate, pair=2, reference_seconds=7.0)
+    audio_io.write_wav(str(tmp_path / "t.wav"), t, rate, "FLOAT")
+    audio_io.write_wav(str(tmp_path / "r.wav"), r, rate, "PCM_24")
+    calls = {}
+
+    def oracle_main(target, reference, config, need_default=True, need_no_limiter=False,
+                    need_no_limiter_normalized=False):
+        calls["needs"] = (need_default, need_no_limiter, need_no_limiter_normalized)
+        ocfg = mo.params(max_piece_size=config.max_piece_size / config.internal_sample_rate)
+        out = mo.master(np.asarray(target, dtype=np.float64), np.asarray(reference, dtype=np.float64), ocfg,
+                        need_default, need_no_limiter, need_no_limiter_normalized)
+        calls["out"] = out
+        return out
+
+    monkeypatch.setattr(core, "main", oracle_main)
+    codes = []
+    mg.log(info_handler=lambda text: codes.append(int(str(text).split(":")[0])), show_codes=True)
+    try:
+        mg.process(target=str(tmp_path / "t.wav"), reference=str(tmp_path / "r.wav"),
+                   results=[mg.Result(str(tmp_path / "master.wav"), "FLOAT"),
+                            mg.Result(str(tmp_path / "plain.aiff"), "FLOAT", use_limiter=False, normalize=False),
+                            mg.Result(str(tmp_path / "norm.wav"), "PCM_24", use_limiter=False)],
+                   config=mg.Config(max_piece_size=3, preview_size=6),
+                   preview_target=mg.pcm16(str(tmp_path / "pt.wav")), preview_result=mg.pcm16(str(tmp_path / "pr.wav")))
+    finally:
+        mg.log()
+    assert calls["needs"] == (True, True, True)
+    limited, plain, normalized = calls["out"]
+    got, _ = audio_io.read_wav(str(tmp_path / "master.wav"))
+    assert np.abs(got - limited).max() <= 1e-6
+    got, _ = audio_io.read_aiff(str(tmp_path / "plain.aiff"))
+    assert np.abs(got - plain).max() <= 1e-6 and np.abs(plain).max() > 1.0        # float output may exceed 0 dBFS
+    got, _ = audio_io.read_wav(str(tmp_path / "norm.wav"))
+    assert np.abs(got - normalized).max() <= 2.0 / 2 ** 23
+    for name in ("pt.wav", "pr.wav"):
+        prev, prate = audio_io.read_wav(str(tmp_path / name))
+        assert prate == rate and prev.shape == (6 * rate, 2)
+    # loading, exporting, previews, completed (log/codes.py); 2004-2007 come from stages.main, replaced here
+    assert codes == [2003, 2008, 2009, 2010]
