@@ -3,7 +3,7 @@ import sys
 
 import matchering_amd as mg
 
-# Sending all log messages to the default print function
+# every log level to stdout; drop the line for a silent run
 mg.log(print)
 
 target, reference = (sys.argv[1:3] + ["my_song.wav", "some_popular_song.wav"])[:2]
