@@ -1,5 +1,10 @@
-"""``process``: the public entry point (matchering/core.py:32-121) -- load, check, validate,
-``stages.main`` on the GPU, save, previews.  Same signature, log codes and exceptions."""
+"""``process``: the public entry point with the reference's signature, log codes and exceptions
+(matchering/core.py:32-121).  The work is split the way this package needs it: two host-side steps
+around the one call that runs on the GPU.
+
+    files --_read_pair--> float arrays at the internal rate --stages.main (MI355X)--> three renderings
+          --_write_results--> files (+ optional previews)
+"""
 
 from .audio_io import load, save
 from .checker import check, check_equality
@@ -11,47 +16,67 @@ from .stages import main
 from .utils import get_temp_folder
 
 
+def _wanted_renderings(results):
+    """Which of stages.main's three outputs the requested files need (core.py:77-86)."""
+    limited = plain = normalized = False
+    for item in results:
+        if item.use_limiter:
+            limited = True
+        elif item.normalize:
+            normalized = True
+        else:
+            plain = True
+    return limited, plain, normalized
+
+
+def _read_pair(target_path, reference_path, config, temp_folder):
+    """Load and check both tracks (core.py:52-74); raises ModuleError with the reference's codes."""
+    tracks = []
+    for path, role in ((target_path, "target"), (reference_path, "reference")):
+        audio, rate = load(path, role, temp_folder)
+        tracks.append(check(audio, rate, config, role))
+    (target, target_rate), (reference, reference_rate) = tracks
+    if not config.allow_equality:
+        check_equality(target, reference)
+    consistent = (
+        target_rate == reference_rate == config.internal_sample_rate
+        and target.shape[1] == reference.shape[1] == 2
+        and min(target.shape[0], reference.shape[0]) > config.fft_size
+    )
+    if not consistent:
+        raise ModuleError(Code.ERROR_VALIDATION)
+    return target, reference
+
+
+def _write_results(results, renderings, sample_rate):
+    """One file per Result, each from the rendering it asked for (core.py:95-108)."""
+    limited, plain, normalized = renderings
+    for item in results:
+        audio = limited if item.use_limiter else (normalized if item.normalize else plain)
+        save(item.file, audio, sample_rate, item.subtype)
+
+
 def process(target: str, reference: str, results: list, config: Config = None,
             preview_target: Result = None, preview_result: Result = None):
-    config = config if config is not None else Config()
+    config = Config() if config is None else config
     debug("Please give us a star to help the project: https://github.com/sergree/matchering")
     debug_line()
     info(Code.INFO_LOADING)
     if not results:
         raise RuntimeError("The result list is empty")
-    temp_folder = config.temp_folder if config.temp_folder else get_temp_folder(results)
+    temp_folder = config.temp_folder or get_temp_folder(results)
 
-    target, target_sample_rate = load(target, "target", temp_folder)
-    target, target_sample_rate = check(target, target_sample_rate, config, "target")
-    reference, reference_sample_rate = load(reference, "reference", temp_folder)
-    reference, reference_sample_rate = check(reference, reference_sample_rate, config, "reference")
-    if not config.allow_equality:
-        check_equality(target, reference)
-
-    if (not (target_sample_rate == reference_sample_rate == config.internal_sample_rate)
-            or not (target.shape[1] == reference.shape[1] == 2)
-            or not (target.shape[0] > config.fft_size and reference.shape[0] > config.fft_size)):
-        raise ModuleError(Code.ERROR_VALIDATION)
-
-    result, result_no_limiter, result_no_limiter_normalized = main(
-        target, reference, config,
-        need_default=any(rr.use_limiter for rr in results),
-        need_no_limiter=any(not rr.use_limiter and not rr.normalize for rr in results),
-        need_no_limiter_normalized=any(not rr.use_limiter and rr.normalize for rr in results))
-    del reference
+    target_audio, reference_audio = _read_pair(target, reference, config, temp_folder)
+    renderings = main(target_audio, reference_audio, config, *_wanted_renderings(results))
+    del reference_audio
 
     debug_line()
     info(Code.INFO_EXPORTING)
-    for wanted in results:
-        if wanted.use_limiter:
-            chosen = result
-        else:
-            chosen = result_no_limiter_normalized if wanted.normalize else result_no_limiter
-        save(wanted.file, chosen, config.internal_sample_rate, wanted.subtype)
+    _write_results(results, renderings, config.internal_sample_rate)
 
     if preview_target or preview_result:
-        shown = next(item for item in (result, result_no_limiter, result_no_limiter_normalized) if item is not None)
-        create_preview(target, shown, config, preview_target, preview_result)
+        mastered = next(audio for audio in renderings if audio is not None)
+        create_preview(target_audio, mastered, config, preview_target, preview_result)
 
     debug_line()
     info(Code.INFO_COMPLETED)

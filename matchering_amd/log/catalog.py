@@ -1,55 +1,76 @@
-"""Status codes and their English texts in one table (numbering and wording follow
-matchering/log/codes.py:24-58 and log/explanations.py:36-71 so that applications
-which parse the codes keep working)."""
+"""Status codes and what they mean.
+
+The NAMES and NUMBERS are the reference's (matchering/log/codes.py:24-58): applications built on
+matchering switch on them, so they are part of the API this package mirrors.  The English texts are
+this package's own wording; they are composed from a handful of templates because most codes exist
+once for the TARGET and once for the REFERENCE (4001/4101, 4002/4102, ...).
+"""
 
 from enum import IntEnum
 
-_T, _R = "TARGET", "REFERENCE"
-_TABLE = (
-    # name, value, text
-    ("INFO_UPLOADING", 2001, "Uploading files"),
-    ("INFO_WAITING", 2002, "Queued for processing"),
-    ("INFO_LOADING", 2003, "Loading and analysis"),
-    ("INFO_MATCHING_LEVELS", 2004, "Matching levels"),
-    ("INFO_MATCHING_FREQS", 2005, "Matching frequencies"),
-    ("INFO_CORRECTING_LEVELS", 2006, "Correcting levels"),
-    ("INFO_FINALIZING", 2007, "Final processing and saving"),
-    ("INFO_EXPORTING", 2008, "Exporting various audio formats"),
-    ("INFO_MAKING_PREVIEWS", 2009, "Making previews"),
-    ("INFO_COMPLETED", 2010, "The task is completed"),
-    ("INFO_TARGET_IS_MONO", 2101, f"The {_T} audio is mono. Converting it to stereo..."),
-    ("INFO_REFERENCE_IS_MONO", 2201, f"The {_R} audio is mono. Converting it to stereo..."),
-    ("INFO_REFERENCE_IS_RESAMPLED", 2202, f"The {_R} audio was resampled"),
-    ("INFO_REFERENCE_IS_LOSSY", 2203, f"Presumably the {_R} audio format is lossy"),
-    ("WARNING_TARGET_IS_CLIPPING", 3001,
-     f"Audio clipping is detected in the {_T} file. It is highly recommended to use the non-clipping version"),
-    ("WARNING_TARGET_LIMITER_IS_APPLIED", 3002,
-     f"The applied limiter is detected in the {_T} file. "
-     "It is highly recommended to use the version without a limiter"),
-    ("WARNING_TARGET_IS_RESAMPLED", 3003,
-     f"The {_T} audio sample rate and internal sample rate were different. The {_T} audio was resampled"),
-    ("WARNING_TARGET_IS_LOSSY", 3004,
-     f"Presumably the {_T} audio format is lossy. "
-     "It is highly recommended to use lossless audio formats (WAV, FLAC, AIFF)"),
-    ("ERROR_TARGET_LOADING", 4001, f"Audio stream error in the {_T} file"),
-    ("ERROR_TARGET_LENGTH_IS_EXCEEDED", 4002, f"Track length is exceeded in the {_T} file"),
-    ("ERROR_TARGET_LENGTH_IS_TOO_SMALL", 4003, f"The track length is too small in the {_T} file"),
-    ("ERROR_TARGET_NUM_OF_CHANNELS_IS_EXCEEDED", 4004, f"The number of channels exceeded in the {_T} file"),
-    ("ERROR_TARGET_EQUALS_REFERENCE", 4005,
-     f"The {_T} and {_R} files are the same. They must be different so that Matchering makes sense"),
-    ("ERROR_REFERENCE_LOADING", 4101, f"Audio stream error in the {_R} file"),
-    ("ERROR_REFERENCE_LENGTH_LENGTH_IS_EXCEEDED", 4102, f"Track length is exceeded in the {_R} file"),
-    ("ERROR_REFERENCE_LENGTH_LENGTH_TOO_SMALL", 4103, f"The track length is too small in the {_R} file"),
-    ("ERROR_REFERENCE_NUM_OF_CHANNELS_IS_EXCEEDED", 4104, f"The number of channels exceeded in the {_R} file"),
-    ("ERROR_UNKNOWN", 4201, "Unknown error"),
-    ("ERROR_VALIDATION", 4202, "Validation failed! Please let the developers know about this error!"),
-)
+# progress of one process() call, in the order it is reported
+_PROGRESS = {
+    2001: ("INFO_UPLOADING", "Receiving the files"),
+    2002: ("INFO_WAITING", "Waiting in the queue"),
+    2003: ("INFO_LOADING", "Reading and checking the audio"),
+    2004: ("INFO_MATCHING_LEVELS", "Matching the loudness"),
+    2005: ("INFO_MATCHING_FREQS", "Matching the spectrum"),
+    2006: ("INFO_CORRECTING_LEVELS", "Re-adjusting the loudness"),
+    2007: ("INFO_FINALIZING", "Limiting and finishing"),
+    2008: ("INFO_EXPORTING", "Writing the result files"),
+    2009: ("INFO_MAKING_PREVIEWS", "Cutting the previews"),
+    2010: ("INFO_COMPLETED", "Done"),
+}
 
-Code = IntEnum("Code", [(name, value) for name, value, _ in _TABLE])
-_TEXT = {Code[name]: text for name, _, text in _TABLE}
+# per-track conditions: offset within the track's block -> (name pattern, severity prefix, template)
+_TRACKS = {"TARGET": 0, "REFERENCE": 100}
+_FAILURES = {
+    1: ("{t}_LOADING", "the {t} file could not be decoded"),
+    2: ("{t}_LENGTH{x}_IS_EXCEEDED", "the {t} track is longer than max_length allows"),
+    3: ("{t}_LENGTH{x}_TOO_SMALL", "the {t} track is shorter than one analysis window"),
+    4: ("{t}_NUM_OF_CHANNELS_IS_EXCEEDED", "the {t} file has more than two channels"),
+}
+
+
+def _build():
+    rows = [(number, name, text) for number, (name, text) in _PROGRESS.items()]
+    rows += [
+        (2101, "INFO_TARGET_IS_MONO", "the TARGET is mono: both channels get the same signal"),
+        (2201, "INFO_REFERENCE_IS_MONO", "the REFERENCE is mono: both channels get the same signal"),
+        (2202, "INFO_REFERENCE_IS_RESAMPLED", "the REFERENCE was converted to the internal sample rate"),
+        (2203, "INFO_REFERENCE_IS_LOSSY", "the REFERENCE seems to come from a lossy codec"),
+        (3001, "WARNING_TARGET_IS_CLIPPING",
+         "the TARGET clips (runs of samples at full scale): master from an unclipped mix if you can"),
+        (3002, "WARNING_TARGET_LIMITER_IS_APPLIED",
+         "the TARGET looks limited already: master from the version without a limiter if you can"),
+        (3003, "WARNING_TARGET_IS_RESAMPLED",
+         "the TARGET was not at the internal sample rate and has been converted"),
+        (3004, "WARNING_TARGET_IS_LOSSY",
+         "the TARGET seems to come from a lossy codec: prefer WAV, FLAC or AIFF sources"),
+    ]
+    for track, base in _TRACKS.items():
+        for offset, (pattern, template) in _FAILURES.items():
+            # the reference spells the REFERENCE length errors with a doubled LENGTH and, for the second
+            # one, without IS: ERROR_REFERENCE_LENGTH_LENGTH_IS_EXCEEDED / ..._LENGTH_LENGTH_TOO_SMALL
+            extra = "_LENGTH" if track == "REFERENCE" else ""
+            name = "ERROR_" + pattern.format(t=track, x=extra)
+            if track == "TARGET" and offset == 3:
+                name = "ERROR_TARGET_LENGTH_IS_TOO_SMALL"
+            rows.append((4000 + base + offset, name, template.format(t=track)))
+    rows += [
+        (4005, "ERROR_TARGET_EQUALS_REFERENCE", "TARGET and REFERENCE are the same audio: there is nothing to match"),
+        (4201, "ERROR_UNKNOWN", "an error without a code of its own"),
+        (4202, "ERROR_VALIDATION", "the loaded audio failed the final consistency check (please report this)"),
+    ]
+    return sorted(rows)
+
+
+_ROWS = _build()
+Code = IntEnum("Code", [(name, number) for number, name, _ in _ROWS])
+_TEXT = {Code(number): text[0].upper() + text[1:] for number, _, text in _ROWS}
 
 
 def explain(code, with_code=False):
-    """Human-readable text of a code; ``with_code`` prefixes ``"<number>: "``."""
+    """Text of a code; ``with_code`` puts ``"<number>: "`` in front (log/explanations.py:28-29)."""
     text = _TEXT[Code(code)]
     return f"{int(code)}: {text}" if with_code else text
