@@ -254,7 +254,7 @@ def load(file: str, file_type: str, temp_folder: str):
     ``ModuleError(4001 | 4101)`` when the file cannot be decoded (after trying ffmpeg)."""
     file_type = file_type.upper()
     sound, sample_rate = None, None
-    debug(f"Loading the {file_type} file: '{file}'...")
+    debug(f"reading {file_type} from '{file}'")
     try:
         sound, sample_rate = _read(file)
     except (RuntimeError, OSError) as e:
@@ -263,14 +263,14 @@ def load(file: str, file_type: str, temp_folder: str):
             sound, sample_rate = _load_with_ffmpeg(file, file_type, temp_folder)
     if sound is None or sample_rate is None:
         raise ModuleError(Code.ERROR_TARGET_LOADING if file_type == "TARGET" else Code.ERROR_REFERENCE_LOADING)
-    debug(f"The {file_type} file is loaded")
+    debug(f"{file_type}: {sound.shape[0]} frames, {sound.shape[1]} channel(s) at {sample_rate} Hz")
     return sound, sample_rate
 
 
 def _load_with_ffmpeg(file, file_type, temp_folder):
     """loader.py:50-74: decode through an ``ffmpeg`` subprocess into a temporary WAV."""
     sound, sample_rate = None, None
-    debug(f"Trying to load '{file}' with ffmpeg...")
+    debug(f"no built-in decoder for '{file}': handing it to ffmpeg")
     temp_file = os.path.join(temp_folder, random_file(prefix="temp"))
     with open(os.devnull, "w") as devnull:
         try:
@@ -282,20 +282,19 @@ def _load_with_ffmpeg(file, file_type, temp_folder):
                 info(Code.INFO_REFERENCE_IS_LOSSY)
             os.remove(temp_file)
         except FileNotFoundError:
-            debug("ffmpeg is not found in the system! "
-                  "Download, install and add it to PATH: https://www.ffmpeg.org/download.html")
+            debug("ffmpeg is not on PATH, so formats beyond the built-in codecs cannot be read")
         except subprocess.CalledProcessError:
-            debug(f"ffmpeg cannot convert '{file}' to .wav!")
+            debug(f"ffmpeg could not decode '{file}' either")
     return sound, sample_rate
 
 
 def save(file: str, result: np.ndarray, sample_rate: int, subtype: str, name: str = "result") -> None:
     """saver.py:27-33."""
-    debug(f"Saving the {name.upper()} {sample_rate} Hz Stereo {subtype} to: '{file}'...")
+    debug(f"writing the {name} as {subtype} at {sample_rate} Hz to '{file}'")
     if _sf is not None:
         _sf.write(file, result, sample_rate, subtype)
     elif os.path.splitext(file)[1][1:].upper() in ("AIFF", "AIF", "AIFC"):
         write_aiff(file, result, sample_rate, subtype)
     else:
         write_wav(file, result, sample_rate, subtype)
-    debug(f"'{file}' is saved")
+    debug(f"wrote '{file}'")

@@ -41,7 +41,7 @@ def check(array: np.ndarray, sample_rate: int, config: Config, name: str):
     name = name.upper()
     target = name == "TARGET"
     length = array.shape[0]
-    debug(f"{name} audio length: {length} samples ({time_str(length, sample_rate)})")
+    debug(f"{name}: {length} frames = {time_str(length, sample_rate)}")
     if length > config.max_length * sample_rate:
         raise ModuleError(Code.ERROR_TARGET_LENGTH_IS_EXCEEDED if target
                           else Code.ERROR_REFERENCE_LENGTH_LENGTH_IS_EXCEEDED)
@@ -57,7 +57,7 @@ def check(array: np.ndarray, sample_rate: int, config: Config, name: str):
                           else Code.ERROR_REFERENCE_NUM_OF_CHANNELS_IS_EXCEEDED)
 
     if sample_rate != config.internal_sample_rate:
-        debug(f"Resampling {name} audio from {sample_rate} Hz to {config.internal_sample_rate} Hz...")
+        debug(f"{name}: converting {sample_rate} Hz -> {config.internal_sample_rate} Hz")
         array = _resample(array, sample_rate, config.internal_sample_rate)
         if target:
             warning(Code.WARNING_TARGET_IS_RESAMPLED)

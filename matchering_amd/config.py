@@ -57,8 +57,7 @@ class Config:
         sr = internal_sample_rate
         _require(isinstance(sr, int) and sr > 0, "internal_sample_rate must be a positive int")
         if sr != 44100:
-            debug("Using an internal sample rate other than 44100 has not been tested properly! "
-                  "Use it at your own risk!")
+            debug(f"internal_sample_rate {sr}: the reference only vouches for 44100; this path is tested from 8 kHz to 192 kHz")
         seconds_per_fft = fft_size / sr
         _require(max_length > 0 and max_length > seconds_per_fft, "max_length too small")
         _require(min_value < threshold < 1, "threshold must lie in (min_value, 1)")

@@ -59,7 +59,7 @@ def _write_results(results, renderings, sample_rate):
 def process(target: str, reference: str, results: list, config: Config = None,
             preview_target: Result = None, preview_result: Result = None):
     config = Config() if config is None else config
-    debug("Please give us a star to help the project: https://github.com/sergree/matchering")
+    debug("matchering_amd: the MI355X path behind the API of https://github.com/sergree/matchering")
     debug_line()
     info(Code.INFO_LOADING)
     if not results:

@@ -40,14 +40,14 @@ def create_preview(target: np.ndarray, result: np.ndarray, config: Config, previ
     info(Code.INFO_MAKING_PREVIEWS)
     target = np.clip(target, -config.threshold, config.threshold)            # dsp.py:109-110
     size, step = int(config.preview_size), int(config.preview_analysis_step)
-    debug(f"The maximum duration of the preview is {size / config.internal_sample_rate} seconds, "
-          f"with the analysis step of {step / config.internal_sample_rate} seconds")
+    debug(f"previews: up to {size / config.internal_sample_rate} s, searched in steps of "
+          f"{step / config.internal_sample_rate} s")
     index, starts, size = _loudest_window(np.asarray(result, dtype=np.float64), size, step)
     begin = int(starts[index])
     target_piece = np.array(target[begin:begin + size], dtype=np.float64)
     result_piece = np.array(result[begin:begin + size], dtype=np.float64)
-    debug(f"The best part to preview: {time_str(begin, config.internal_sample_rate)} "
-          f"- {time_str(begin + result_piece.shape[0], config.internal_sample_rate)}")
+    debug(f"loudest window of the result: {time_str(begin, config.internal_sample_rate)} to "
+          f"{time_str(begin + result_piece.shape[0], config.internal_sample_rate)}")
     if result.shape[0] != result_piece.shape[0]:
         fade_size = int(min(config.preview_fade_size, result_piece.shape[0] // config.preview_fade_coefficient))
         target_piece, result_piece = _fade(target_piece, fade_size), _fade(result_piece, fade_size)

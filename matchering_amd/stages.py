@@ -35,35 +35,33 @@ def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default
 
     debug_line()
     info(Code.INFO_MATCHING_LEVELS)
-    debug(f"The maximum size of the analyzed piece: {config.max_piece_size} samples "
-          f"or {config.max_piece_size / config.internal_sample_rate:.2f} seconds")
+    debug(f"analysis pieces: at most {config.max_piece_size} frames "
+          f"({config.max_piece_size / config.internal_sample_rate:.2f} s) each")
     t_dev = dev.upload(target)
     r_dev = dev.upload(reference)
     outs = [dev.alloc(n * 8) if need else None
             for need in (need_default, need_no_limiter, need_no_limiter_normalized)]
     try:
         report = dev.master(t_dev, n, r_dev, nr, native, *outs)
-        debug(f"The TARGET will be didived into {report.target_divisions} pieces of "
-              f"{report.target_piece} samples; the REFERENCE into {report.reference_divisions} of "
-              f"{report.reference_piece}")
+        debug(f"target: {report.target_divisions} pieces of {report.target_piece} frames, "
+              f"{report.target_loud_count} of them loud; reference: {report.reference_divisions} pieces of "
+              f"{report.reference_piece} frames, {report.reference_loud_count} loud")
         if not np.isclose(report.final_amplitude_coefficient, 1.0):
-            debug("The REFERENCE was normalized. Final amplitude coefficient for the TARGET audio is: "
-                  f"{to_db(report.final_amplitude_coefficient)}")
-        debug(f"The RMS coefficient is: {to_db(report.rms_coefficient)}")
+            debug("the reference peaks below the threshold: it was scaled up for matching and the result "
+                  f"is scaled back by {to_db(report.final_amplitude_coefficient)}")
+        debug(f"level match: {to_db(report.rms_coefficient)} on the target")
         debug_line()
         info(Code.INFO_MATCHING_FREQS)
         debug_line()
         info(Code.INFO_CORRECTING_LEVELS)
         for step in range(config.rms_correction_steps):
-            debug(f"Applying RMS correction #{step + 1}... "
-                  f"The RMS coefficient is: {to_db(report.correction_coefficients[step])}")
+            debug(f"correction round {step + 1}: {to_db(report.correction_coefficients[step])}")
         debug_line()
         info(Code.INFO_FINALIZING)
         if need_no_limiter_normalized:
-            debug("The amplitude of the normalized RESULT should be adjusted by "
-                  f"{to_db(report.normalize_coefficient)}")
+            debug(f"unlimited result normalised by {to_db(report.normalize_coefficient)} to reach the threshold")
         if need_default and not report.limiter_active:
-            debug("The limiter is not needed!")
+            debug("the result stays under the threshold: the limiter passes it through")
         results = tuple(dev.download(b, (n, 2)) if b is not None else None for b in outs)
     finally:
         for b in (t_dev, r_dev, *outs):

@@ -297,3 +297,75 @@ def test_process_file_pipeline_on_cpu(tmp_path, monkeypatch):
         assert prate == rate and prev.shape == (6 * rate, 2)
     # loading, exporting, previews, completed (log/codes.py); 2004-2007 come from stages.main, replaced here
     assert codes == [2003, 2008, 2009, 2010]
+
+
+def test_stages_main_host_glue_with_a_stand_in_device():
+    """stages.main's host side -- argument checks, uploads, which outputs are allocated, the log lines it
+    builds from the device's report, clean-up -- driven with a stand-in for the Device (the oracle does
+    the arithmetic).  The real Device is exercised by the GPU tests."""
+    import mastering_oracle as mo
+    from matchering_amd import stages
+    from matchering_amd._native import MgxReport
+    from matchering_amd.synth import make_pair
+
+    class Buf:
+        def __init__(self, array=None, nbytes=0):
+            self.array, self.nbytes, self.released = array, nbytes, False
+
+        def release(self):
+            self.released = True
+
+    class StandIn:
+        def __init__(self):
+            self.buffers = []
+
+        def upload(self, array, dtype=np.float32):
+            b = Buf(np.ascontiguousarray(array, dtype=dtype))
+            self.buffers.append(b)
+            return b
+
+        def alloc(self, nbytes):
+            b = Buf(nbytes=nbytes)
+            self.buffers.append(b)
+            return b
+
+        def master(self, t, n, r, nr, native, result=None, result_no_limiter=None, result_no_limiter_normalized=None):
+            tr = {}
+            outs = mo.master(t.array.astype(np.float64), r.array.astype(np.float64),
+                             mo.params(max_piece_size=2.0), result is not None, result_no_limiter is not None,
+                             result_no_limiter_normalized is not None, trace=tr)
+            for buf, out in zip((result, result_no_limiter, result_no_limiter_normalized), outs):
+                if buf is not None:
+                    buf.array = out.astype(np.float32)
+            rep = MgxReport()
+            rep.final_amplitude_coefficient = tr["final_amplitude_coefficient"]
+            rep.rms_coefficient = tr["rms_coefficient"]
+            rep.target_divisions, rep.reference_divisions = tr["target_divisions"], tr["reference_divisions"]
+            rep.target_piece, rep.reference_piece = tr["target_piece"], tr["reference_piece"]
+            rep.target_loud_count, rep.reference_loud_count = len(tr["target_loud_idx"]), len(tr["reference_loud_idx"])
+            for i, c in enumerate(tr["correction_coefficients"]):
+                rep.correction_coefficients[i] = c
+            rep.normalize_coefficient = tr["normalize_coefficient"] or 0.0
+            rep.limiter_active = 1
+            return rep
+
+        def download(self, buf, shape, dtype=np.float32):
+            return buf.array.reshape(shape).astype(dtype)
+
+    t, r = make_pair(6.0, 44100, pair=1, reference_gain=0.5)       # quiet reference: the amplitude branch logs too
+    lines = []
+    mg.log(print if False else lines.append, show_codes=True)
+    dev = StandIn()
+    try:
+        out = stages.main(t, r, mg.Config(max_piece_size=2), need_default=True, need_no_limiter=False,
+                          need_no_limiter_normalized=True, device=dev)
+    finally:
+        mg.log()
+    assert out[0].shape == t.shape and out[1] is None and out[2].shape == t.shape
+    assert all(b.released for b in dev.buffers) and len(dev.buffers) == 4
+    codes = [int(str(l).split(":")[0]) for l in lines if str(l)[:4].isdigit()]
+    assert codes == [2004, 2005, 2006, 2007]
+    text = "\\n".join(str(l) for l in lines)
+    assert "correction round 4" in text and "level match" in text and "scaled back" in text
+    with pytest.raises(ValueError):
+        stages.main(t[:, :1], r, mg.Config(), device=dev)
