@@ -101,9 +101,13 @@ int mgx_timer_stop(mgx_handle* h, float* milliseconds);
  * need_default, need_no_limiter, need_no_limiter_normalized)`.  target_dev /
  * reference_dev: (n,2) float32 in HBM.  Each non-null output receives (n_target,2)
  * float32 in HBM; a null output = the corresponding need_* flag False.  Inputs
- * are not modified.  Asynchronous on the handle's stream except for one host
- * round trip for the FIR design; report (host, may be null) is valid after
- * mgx_synchronize. */
+ * are not modified.  Everything, the FIR design included, is queued on the
+ * handle's stream without a host round trip: with report == NULL the call returns
+ * before the GPU has finished (mgx_synchronize to wait); with a report it waits
+ * itself and fills it.
+ * Limits (MGX_ERR_UNSUPPORTED, never a silent approximation): fft_size in
+ * [64, 16384]; limiter filter orders 1; lowess_it 0; tracks up to 536 million
+ * frames (32-bit byte offsets; 3.3 hours at 44.1 kHz). */
 int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target,
                const float* reference_dev, int64_t n_reference, const mgx_config* cfg,
                float* result_dev, float* result_no_limiter_dev,
