@@ -125,8 +125,10 @@ int mgx_analyze(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* 
                 double* piece_rms, int32_t* loud, double* avg_mid, double* avg_side);
 
 /* match_frequencies.py:78-101 get_fir from averaged spectra (host, float64).
- * avg_target must already include the level gain of stages.py:90-91.  Pure host
- * code: works without a GPU. */
+ * avg_target must already include the level gain of stages.py:90-91.  A host-side
+ * cross-check of the design (a direct float64 evaluation, no precomputed operator)
+ * for tests and tools: it needs no GPU and is NOT what mgx_master runs -- there the
+ * same design happens on the device (k_fir_raw / k_fir_matvec / k_fir_taps). */
 int mgx_design_fir(const mgx_config* cfg, const double* avg_target, const double* avg_reference,
                    double* taps, double* curve_raw, double* curve_smooth);
 
