@@ -139,13 +139,6 @@ int mgx_convolve(mgx_handle* h, const float* x_dev, int64_t n, const double* fir
                  const double* fir_side, int32_t taps, double gain, float* y_dev, float* y_mid_dev,
                  double* peak);
 
-/* Measurement aid for bench.py: the same convolution launched `iters` times back to
- * back with HIP events around the k_conv launches only (filter preparation excluded);
- * *ms_per_launch = average duration of one launch. */
-int mgx_convolve_timed(mgx_handle* h, const float* x_dev, int64_t n, const double* fir_mid,
-                       const double* fir_side, int32_t taps, double gain, float* y_dev,
-                       float* y_mid_dev, int32_t iters, float* ms_per_launch);
-
 /* One round of stages.py:149-160: piece RMS of clip(gain*mid, -1, 1) over the
  * target's piece grid.  Host output sumsq[divisions] = sum of squares per piece. */
 int mgx_clipped_piece_sumsq(mgx_handle* h, const float* mid_dev, int64_t n, int64_t piece_size,
@@ -158,6 +151,26 @@ int mgx_limit(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cf
 
 /* dsp.py:89-90 amplify on interleaved frames: out = x * gain */
 int mgx_scale(mgx_handle* h, const float* x_dev, int64_t n, double gain, float* out_dev);
+
+/* Measurement aid (bench.py): with timing enabled, mgx_master brackets each of
+ * its stages with HIP events recorded on the handle's own stream (no synchronisation is added);
+ * mgx_stage_times waits for the stream and returns the device time of every stage of the LAST
+ * mgx_master call in milliseconds, -1 for a stage that did not run.  The stages are those of
+ * stages.py:210-272 with `convolve` (match_frequencies.py:104-119) and the limiter
+ * (hyrax.py:78-99) on their own, since each is a single kernel launch. */
+enum mgx_stage {
+    MGX_STAGE_ANALYZE_TARGET = 0,   /* match_levels.py:134-161 + match_frequencies.py:30-42, target */
+    MGX_STAGE_ANALYZE_REFERENCE = 1,
+    MGX_STAGE_DESIGN_FIR = 2,       /* match_levels.py:62-71, match_frequencies.py:45-101 */
+    MGX_STAGE_FILTER_SPECTRA = 3,   /* transforms of the FIR pair the convolution multiplies by */
+    MGX_STAGE_CONVOLVE = 4,         /* match_frequencies.py:104-119: ONE launch of k_conv */
+    MGX_STAGE_CORRECT_LEVELS = 5,   /* stages.py:138-170 */
+    MGX_STAGE_SCALE_OUTPUTS = 6,    /* stages.py:185-191 */
+    MGX_STAGE_LIMIT = 7,            /* hyrax.py:78-99: ONE launch of the limiter kernel */
+    MGX_STAGE_COUNT = 8
+};
+int mgx_stage_timing(mgx_handle* h, int32_t enable);
+int mgx_stage_times(mgx_handle* h, float* ms /* [MGX_STAGE_COUNT] */);
 
 /* Device address of the FIR pair ([2][fft_size] float32: mid taps then side taps, level gain
  * not included) designed by the last mgx_master / uploaded by the last mgx_convolve on this

@@ -90,8 +90,8 @@ SYMBOLS = {
                                       c_double_p, c_double_p]),
     "mgx_convolve": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, c_double_p, c_double_p, ctypes.c_int32,
                                     ctypes.c_double, _VP, _VP, c_double_p]),
-    "mgx_convolve_timed": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, c_double_p, c_double_p, ctypes.c_int32,
-                                          ctypes.c_double, _VP, _VP, ctypes.c_int32, c_float_p]),
+    "mgx_stage_timing": (ctypes.c_int, [_VP, ctypes.c_int32]),
+    "mgx_stage_times": (ctypes.c_int, [_VP, c_float_p]),
     "mgx_clipped_piece_sumsq": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                                ctypes.c_double, c_double_p]),
     "mgx_limit": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.POINTER(MgxConfig), ctypes.c_double,
@@ -104,6 +104,11 @@ SYMBOLS = {
     "mgx_comm_allgather_f32": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_int64]),
     "mgx_comm_destroy": (ctypes.c_int, [_VP]),
 }
+
+
+# enum mgx_stage (include/mgx.h), in order
+STAGES = ("analyze_target", "analyze_reference", "design_fir", "filter_spectra", "convolve", "correct_levels",
+          "scale_outputs", "limit")
 
 
 class MgxError(RuntimeError):
@@ -122,7 +127,9 @@ def library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if not os.environ.get("MGX_LIB"):
+        # build() compares a digest of csrc/ and include/mgx.h with the one the binary was made from
+        # and returns at once when they agree: an edited kernel or struct never meets a stale binary
         from . import build as _build
 
         _build.build()

@@ -1,4 +1,5 @@
 """Build matchering_amd/libmgx.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -15,23 +16,52 @@ def _deps():
     return deps
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
+         "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def source_hash(extra_flags=()):
+    """Digest of everything the binary is made from.  A content hash, not mtimes: the snapshot that
+    carries the tree to a GPU box does not preserve modification order."""
+    h = hashlib.sha256(" ".join([*FLAGS, *extra_flags]).encode())
+    for path in sorted(_deps()):
+        if os.path.isfile(path):
+            h.update(os.path.basename(path).encode())
+            with open(path, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+def _stamp(out):
+    return out + ".srchash"
+
+
+def up_to_date(out=None, extra_flags=()):
+    out = out or OUT
+    try:
+        with open(_stamp(out)) as fh:
+            return os.path.exists(out) and fh.read().strip() == source_hash(extra_flags)
+    except OSError:
+        return False
+
+
 def build(force=False, verbose=False, out=None, extra_flags=()):
     """Compile the HIP library in-tree.  Returns the path of the shared object.
 
     ``out`` / ``extra_flags`` build an experimental variant next to the product (A/B runs of
     compiler options on the GPU box: ``MGX_LIB=<path>`` makes ``_native`` load it)."""
     out = out or OUT
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in _deps()):
+    if not force and up_to_date(out, extra_flags):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fno-slp-vectorize: packing the butterflies' float pairs into v_pk_* costs more v_mov shuffles
     # than it saves on gfx950 (k_conv 233 -> 196 us, k_analyze 108 -> 65 us, profiles/r01_d_*)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
-           "-fno-slp-vectorize", "-Wno-unused-result", "-Wno-unused-value", *extra_flags, "-o", out] + SOURCES + [
-               "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = [hipcc, *FLAGS, *extra_flags, "-o", out] + SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
+    with open(_stamp(out), "w") as fh:
+        fh.write(source_hash(extra_flags))
     return out
 
 

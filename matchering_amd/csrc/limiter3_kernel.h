@@ -1,0 +1,478 @@
+// Hyrax brick-wall limiter (matchering/limiter/hyrax.py:78-99) in ONE streaming pass -- third
+// generation of the chunk kernel.  Same mathematics and the same chunk geometry / look-back words
+// as limiter2_kernel.h (read its header first); what changed is everything that decided how many
+// workgroups a CU holds and how long each of them waits:
+//
+//  * ONE LDS plane.  The raw hard-clip gains g0 stay in the plane; a thread forms its 2 x 16 window
+//    maxima from them directly (a suffix run on the left edge, a prefix run on the right edge, whole
+//    block maxima in between) instead of from precomputed prefix / suffix planes.  18.8 KB per
+//    workgroup instead of 36 KB, one barrier less, and the block maxima come out of the load phase
+//    (eight neighbouring lanes hold one block: three DPP steps).
+//  * The attack path (sl -> forward smoother -> backward smoother) runs to completion before the
+//    hold / release path starts, so at most three 16-frame arrays are live at any time: the kernel
+//    is compiled for six workgroups per CU (80 VGPRs) instead of four.
+//  * Look-back words are asked for as soon as the chunk's own aggregates are published and consumed
+//    as late as possible.  The forward attack carry enters linearly, so the whole attack path runs
+//    on a zero carry while the words are in flight and the carry is added at the end:
+//        gA[n] += carry * kappa * rho^(n - n0),   kappa = b0 + beta*rho / (1 - rho^2)
+//    (the backward smoother's response to the decaying state, summed to infinity: the right halo is
+//    >= 9 time constants long).  Only the chunk that holds the last frame of the track -- filtfilt's
+//    odd extension makes its backward start depend on the forward end state -- waits for its carry
+//    first.
+#pragma once
+
+#include "limiter2_kernel.h"
+
+namespace mgx {
+
+struct Limiter3Block {
+    static constexpr int T = 256;
+    static constexpr int E = 16;
+    static constexpr int STRIDE = E + 1;               // LDS row stride (floats): conflict-free columns
+    static constexpr int WAVES = T / 64;
+    static constexpr int FRAMES = T * E;
+    static constexpr int PLANE = T * STRIDE;
+    static constexpr int MAX_SPINS = 1 << 20;
+    static constexpr int POLL_SLOTS = 4;               // look-back words a lane keeps in flight (x64 lanes)
+
+    // LDS carve (floats): [0, PLANE) g0, later the gain | [PLANE, +T) block maxima | misc
+    static constexpr int BM_OFF = PLANE;
+    static constexpr int MISC_OFF = BM_OFF + T;
+    static constexpr int TOTALS_FLOATS = 4 * WAVES * 4;                 // four scans x WAVES Affine
+    static constexpr int MISC_FLOATS = 16 + TOTALS_FLOATS + 16;        // edge sl[14] | totals | scalars
+    static constexpr size_t LDS_BYTES = (size_t)(MISC_OFF + MISC_FLOATS) * 4 + 16;
+
+    static MGX_HD float* plane(float* lds) { return lds; }
+    static MGX_HD float* block_max(float* lds) { return lds + BM_OFF; }
+    static MGX_HD float* edge_sl(float* lds) { return lds + MISC_OFF; }
+    // scan 0 = forward attack, 1 = hold, 2 = backward attack, 3 = release
+    static MGX_HD Affine* wave_totals(float* lds, int scan) {
+        return reinterpret_cast<Affine*>(lds + MISC_OFF + 16) + scan * WAVES;
+    }
+    //   scalars: [0] hold carry, [1] release carry, [2] attack carry, [4] ticket
+    static MGX_HD double* scalars(float* lds) { return reinterpret_cast<double*>(lds + MISC_OFF + 16 + TOTALS_FLOATS); }
+    static MGX_HD int gidx(int i) { return (i >> 4) * STRIDE + (i & 15); }
+
+    using Geometry = Limiter2Block::Geometry;
+    static MGX_HD Geometry geometry(int hw, int hb, int ha) { return Limiter2Block::geometry(hw, hb, ha); }
+    static MGX_HD long long region_start(long long chunk, const Limiter2Args& a) {
+        return Limiter2Block::region_start(chunk, a);
+    }
+    // the chunk whose region reaches the end of the track: its attack carry is taken up front
+    static MGX_HD bool tail_chunk(long long chunk, const Limiter2Args& a) {
+        return region_start(chunk, a) + FRAMES >= a.n;
+    }
+
+    // a chunk whose region lies strictly inside the track: every block has 16 frames, no filtfilt edge,
+    // plain loads.  All but the first and the last one or two chunks of a track: the phases are compiled
+    // twice, FULL = true without any of the per-frame validity tests.
+    static MGX_HD bool full_chunk(long long chunk, const Limiter2Args& a) {
+        const long long r0 = region_start(chunk, a);
+        return r0 >= 0 && r0 + FRAMES < a.n;
+    }
+
+    struct Thread {
+        long long base;
+        int valid;
+        bool core, has_sl;
+        bool inject_left, inject_right;
+        double edge_state;
+        double att_decay;                 // decay of the forward attack state from the chunk's first sl frame to this block
+        Affine hold_pre;                  // composition of the hold maps of the blocks before this one
+        float inner;                      // max g0 over the part of the attack window every frame of the block shares
+        float sl[E], sh[E], yf[E], yb[E], x2[E], mx[E];
+    };
+
+    // ---- hard-clip gain (dsp.py:117-121, hyrax.py:87): 1 - thr/amax above the threshold -----------
+    // amax - thr is exact for amax < 2 thr (Sterbenz); the reciprocal is good to 1 ulp.
+    static MGX_HD float gain_of(float2 v, float thr) {
+        const float amax = fmaxf(fabsf(v.x), fabsf(v.y));
+        return amax > thr ? (amax - thr) * fast_rcp(amax) : 0.f;
+    }
+    static MGX_HD float2 scaled(float2 y, float g) { return make_float2(y.x * g, y.y * g); }
+    static MGX_HD float own_gain(float2 v, float k, bool with_gain, float thr) {
+        return with_gain ? fminf(k, 1.0f - gain_of(v, thr)) : 1.f;
+    }
+
+    // ---- P1: coalesced load, g0 -> plane; pm[j] = max of this lane's two frames of iteration j ----
+    // (lanes 8q .. 8q+7 of iteration j hold block q + 32 j: the kernel folds them into the block maxima)
+    template <bool FULL = false>
+    static MGX_HD void phase_load(int tid, long long chunk, const Limiter2Args& a, float* lds, float (&pm)[E / 2]) {
+        const long long r0 = region_start(chunk, a);
+        const bool interior = FULL || (r0 >= 0 && r0 + FRAMES <= a.n);
+        const float g = (float)*a.gain;
+        float* gp = plane(lds);
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) {
+            const int i = 2 * tid + 2 * T * j;
+            float2 v0 = make_float2(0.f, 0.f), v1 = v0;
+            if (interior) {
+                const float4 q = *reinterpret_cast<const float4*>(a.y + (r0 + i));
+                v0 = make_float2(q.x, q.y);
+                v1 = make_float2(q.z, q.w);
+            } else {
+                const long long f = r0 + i;
+                if (f >= 0 && f < a.n) v0 = a.y[f];
+                if (f + 1 >= 0 && f + 1 < a.n) v1 = a.y[f + 1];
+            }
+            const float g0 = gain_of(scaled(v0, g), a.threshold), g1 = gain_of(scaled(v1, g), a.threshold);
+            gp[gidx(i)] = g0;
+            gp[gidx(i + 1)] = g1;
+            pm[j] = fmaxf(g0, g1);
+        }
+    }
+    static MGX_HD int block_of(int tid, int j) { return (tid >> 3) + (T / 8) * j; }
+
+    // ---- window maxima from the raw plane -----------------------------------------------------------
+    // value at frame 16*tid + d of the region, d uniform
+    static MGX_HD int rel(int d) { return (d >> 4) * STRIDE + (d & 15); }
+    // max over frames 16*tid + [a, b] (uniform, may be empty): ragged ends frame by frame (at most 15
+    // each, masked reads), whole blocks from the block maxima
+    static MGX_HD float range_max(int tid, int a, int b, const float* lds) {
+        const float* row = plane(const_cast<float*>(lds)) + tid * STRIDE;
+        const float* bm = block_max(const_cast<float*>(lds)) + tid;
+        const int len = b - a + 1;
+        if (len <= 0) return 0.f;
+        const int to_edge = (16 - (a & 15)) & 15;                 // frames up to the next block boundary
+        const int nl = to_edge < len ? to_edge : len;
+        const int a2 = a + nl, rest = len - nl;
+        const int nb = rest >> 4, nr = rest & 15;
+        float m = 0.f;
+        const float* pl = row + rel(a);                           // nl <= 15 frames inside one row
+        MGX_UNROLL
+        for (int k = 0; k < 15; ++k) {
+            const float v = pl[k < nl ? k : 0];
+            m = fmaxf(m, k < nl ? v : 0.f);
+        }
+        for (int k = 0; k < nb; ++k) m = fmaxf(m, bm[(a2 >> 4) + k]);
+        const float* pr = row + rel(a2 + 16 * nb);                // a block boundary: nr <= 15 frames of one row
+        MGX_UNROLL
+        for (int k = 0; k < 15; ++k) {
+            const float v = pr[k < nr ? k : 0];
+            m = fmaxf(m, k < nr ? v : 0.f);
+        }
+        // (with nl == 0 and nr == 0 the two rows above are read at offset 0 only: rel(a), rel(a2) lie inside the region)
+        return m;
+    }
+    // 15 consecutive frames starting at 16*tid + d0 (they cross at most one row boundary)
+    static MGX_HD void run15(int tid, int d0, const float* lds, float (&v)[15]) {
+        const float* row = plane(const_cast<float*>(lds)) + tid * STRIDE;
+        const float* p = row + rel(d0);
+        const int cross = 16 - (d0 & 15);                          // frames before the pad slot
+        MGX_UNROLL
+        for (int k = 0; k < 15; ++k) {
+            const float* q = k < cross ? p : p + 1;
+            v[k] = q[k];
+        }
+    }
+    // sl[j] = max g0[c - hw .. c + hw], sh[j] = max g0[c - hw - hb .. c + hw] for c = 16 tid + j:
+    //   window = [j - lw, 14 - lw] (suffix run)  u  [15 - lw, hw] (always inside)  u  [hw + 1, hw + j] (prefix run)
+    // One 15-frame run is in registers at a time (the register budget is the point of this kernel): the
+    // left run right-to-left into the output, then the right run left-to-right.  `inner` = the maximum
+    // over the always-inside part.
+    static MGX_HD void window16(int tid, int lw, int hw, float inner, const float* lds, float (&out)[E]) {
+        float r[15];
+        run15(tid, -lw, lds, r);
+        float s = 0.f;
+        out[15] = inner;
+        MGX_UNROLL
+        for (int j = 14; j >= 0; --j) {
+            s = fmaxf(s, r[j]);
+            out[j] = fmaxf(inner, s);
+        }
+        run15(tid, hw + 1, lds, r);
+        s = 0.f;
+        MGX_UNROLL
+        for (int j = 1; j < E; ++j) {
+            s = fmaxf(s, r[j - 1]);
+            out[j] = fmaxf(out[j], s);
+        }
+    }
+
+    // ---- first-order recurrences, filtfilt edges: shared with the second generation --------------
+    using L2 = Limiter2Block;
+
+    // ---- P2: block geometry; sh; block map of the hold filter ----------------------------------------
+    // The hold path goes first: its aggregate is what successors wait for longest.
+    template <bool FULL = false>
+    static MGX_HD Affine phase_hold_window(int tid, long long chunk, const Limiter2Args& a, Thread& th, const float* lds) {
+        th.base = region_start(chunk, a) + (long long)tid * E;
+        th.core = tid >= a.gl && tid < T - a.gr;
+        th.has_sl = tid >= a.gl && tid < T - a.gw;
+        const long long left = a.n - th.base;
+        th.valid = FULL ? E : (th.base < 0 ? 0 : (left >= E ? E : (left > 0 ? (int)left : 0)));
+        const int valid = FULL ? E : th.valid;
+        th.inject_left = false;
+        th.inject_right = false;
+        th.edge_state = 0.0;
+        th.inner = 0.f;
+        Affine r = affine_identity();
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) th.sh[j] = 0.f;
+        if (th.has_sl) th.inner = range_max(tid, 15 - a.hw, a.hw, lds);
+        if (th.core) {
+            const int lw = a.hw + a.hb;
+            window16(tid, lw, a.hw, fmaxf(th.inner, range_max(tid, 15 - lw, 14 - a.hw, lds)), lds, th.sh);
+            if (!FULL) {
+                MGX_UNROLL
+                for (int j = 0; j < E; ++j)
+                    if (j >= valid) th.sh[j] = 0.f;                           // windows are truncated at the array ends
+            }
+            if (valid > 0)
+                r = Affine{L2::block_decay(a.ph16, a.hold.alpha, valid), (double)L2::run_forward(a.holdf, th.sh, valid, 0.f)};
+        }
+        return r;
+    }
+    // ---- P3: sl; block map of the forward attack smoother ------------------------------------------
+    template <bool FULL = false>
+    static MGX_HD Affine phase_attack_window(int tid, const Limiter2Args& a, Thread& th, float* lds) {
+        const int valid = FULL ? E : th.valid;
+        Affine r = affine_identity();
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) th.sl[j] = 0.f;
+        if (th.has_sl) {
+            window16(tid, a.hw, a.hw, th.inner, lds, th.sl);
+            if (!FULL) {
+                MGX_UNROLL
+                for (int j = 0; j < E; ++j)
+                    if (j >= valid) th.sl[j] = 0.f;
+                MGX_UNROLL
+                for (int j = 0; j < E; ++j) {
+                    const long long f = th.base + j;
+                    if (j < valid && f >= a.n - 7) edge_sl(lds)[7 + (int)(f - (a.n - 7))] = th.sl[j];
+                }
+                th.inject_left = th.base == 0;
+                th.inject_right = valid > 0 && th.base + valid == a.n;
+            }
+            if (valid > 0) {
+                const double decay = L2::block_decay(a.pa16, a.att.alpha, valid);
+                const double zend = (double)L2::run_forward(a.attf, th.sl, valid, 0.f);
+                r = Affine{decay, zend};
+                if (!FULL && th.inject_left) {
+                    th.edge_state = L2::filtfilt_left_state(a.att, th.sl);
+                    r = Affine{0.0, fma(decay, th.edge_state, zend)};
+                }
+            }
+        }
+        return r;
+    }
+
+    // ---- look-back words, split into "ask" and "take" ----------------------------------------------
+    struct Polls {
+        unsigned long long v[POLL_SLOTS];
+    };
+    static MGX_HD void lookback_publish(long long chunk, int slot, const Limiter2Args& a, double b) {
+        publish_word(a.published + (size_t)slot * a.nchunks + chunk, double_bits(b));
+    }
+    static MGX_HD void lookback_ask(int lane, long long chunk, int slot, const Limiter2Args& a, Polls& p) {
+        const int count = slot == 0 ? a.n_hold : (slot == 1 ? a.n_rel : a.n_att);
+        MGX_UNROLL
+        for (int k = 0; k < POLL_SLOTS; ++k) {
+            const int m = lane + 64 * k;
+            const long long c = chunk - 1 - m;
+            p.v[k] = 0ull;                                          // +0.0: a word that does not exist adds nothing
+            if (m < count && c >= 0) p.v[k] = poll_word(a.published + (size_t)slot * a.nchunks + c);
+        }
+    }
+    // this lane's share of sum_m w[m] * published[chunk-1-m] (the caller adds the 64 shares)
+    static MGX_HD double lookback_take(int lane, long long chunk, int slot, const Limiter2Args& a, Polls& p) {
+        const double* w = slot == 0 ? a.w_hold : (slot == 1 ? a.w_rel : a.w_att);
+        const int count = slot == 0 ? a.n_hold : (slot == 1 ? a.n_rel : a.n_att);
+        double acc = 0.0;
+        MGX_UNROLL
+        for (int k = 0; k < POLL_SLOTS; ++k) {
+            const int m = lane + 64 * k;
+            const long long c = chunk - 1 - m;
+            if (m < count && c >= 0) {
+                unsigned long long* q = a.published + (size_t)slot * a.nchunks + c;
+                unsigned long long v = p.v[k];
+                int spins = 0;
+                while (v == LIMITER_UNPUBLISHED && spins < MAX_SPINS) {
+                    backoff(spins);
+                    v = poll_word(q);
+                    ++spins;
+                }
+                if (v == LIMITER_UNPUBLISHED) {
+                    *a.error = 1;
+                    v = 0;
+                }
+                acc = fma(w[m], bits_double(v), acc);
+            }
+        }
+        // filters with a longer memory than POLL_SLOTS * 64 chunks: the remaining words, one at a time
+        for (int m = lane + 64 * POLL_SLOTS; m < count; m += 64) {
+            const long long c = chunk - 1 - m;
+            if (c < 0) break;
+            unsigned long long* q = a.published + (size_t)slot * a.nchunks + c;
+            unsigned long long v = poll_word(q);
+            int spins = 0;
+            while (v == LIMITER_UNPUBLISHED && spins < MAX_SPINS) {
+                backoff(spins);
+                v = poll_word(q);
+                ++spins;
+            }
+            if (v == LIMITER_UNPUBLISHED) {
+                *a.error = 1;
+                v = 0;
+            }
+            acc = fma(w[m], bits_double(v), acc);
+        }
+        return acc;
+    }
+
+    // ---- P3: forward attack output from carry `att_now` (zero unless tail chunk); block map of the
+    //          backward smoother (right-to-left scan).  `p0` = forward attack prefix of this thread.
+    template <bool FULL = false>
+    static MGX_HD Affine phase_attack_forward(int tid, const Limiter2Args& a, Thread& th, Affine p0, double att_now,
+                                              const float* lds) {
+        Affine r = affine_identity();
+        const int valid = FULL ? E : th.valid;
+        th.att_decay = p0.a;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) th.yf[j] = 0.f;
+        if (th.has_sl) {
+            double c = affine_apply(p0, att_now);
+            if (!FULL && th.inject_left) c = th.edge_state;
+            const float zend = L2::out_forward(a.attf, th.sl, valid, (float)c, th.yf);
+            if (valid > 0) {
+                const double decay = L2::block_decay(a.pa16, a.att.alpha, valid);
+                const double zb = (double)L2::run_backward(a.attf, th.yf, valid, 0.f);
+                r = Affine{decay, zb};
+                if (!FULL && th.inject_right) {
+                    th.edge_state = L2::filtfilt_right_state(a.att, edge_sl(const_cast<float*>(lds)) + 7, (double)zend);
+                    r = Affine{0.0, fma(decay, th.edge_state, zb)};
+                }
+            }
+        }
+        return r;
+    }
+    // ---- P4: backward attack output (carry-free part).  `pb` = composition of the blocks to the right
+    template <bool FULL = false>
+    static MGX_HD void phase_attack_backward(int tid, const Limiter2Args& a, Thread& th, Affine pb) {
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) th.yb[j] = 0.f;
+        if (!th.core) return;
+        double cb = affine_apply(pb, 0.0);
+        if (!FULL && th.inject_right) cb = th.edge_state;
+        L2::out_backward(a.attf, th.yf, FULL ? E : th.valid, (float)cb, th.yb);
+    }
+    // kappa of the file header
+    static MGX_HD double attack_kappa(const Iir1& f) { return f.b0 + f.beta * f.alpha / (1.0 - f.alpha * f.alpha); }
+
+    // ---- P5: carries have arrived.  Exact hold output, attack carry term, max(sh, ho) -> block map of
+    //          the release filter.  att_deferred = the attack carry not yet applied (0 in a tail chunk)
+    template <bool FULL = false>
+    static MGX_HD Affine phase_hold(int tid, const Limiter2Args& a, Thread& th, double hold_carry, double att_deferred) {
+        Affine r = affine_identity();
+        const int valid = FULL ? E : th.valid;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) { th.x2[j] = 0.f; th.mx[j] = 0.f; }
+        if (!th.core) return r;
+        float pw = (float)(att_deferred * attack_kappa(a.att) * th.att_decay);
+        // hold output (L2::out_forward inlined so that sh[j], yb[j] die as x2[j], mx[j] are born)
+        float z = (float)affine_apply(th.hold_pre, hold_carry);
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) {
+            const bool in = j < valid;
+            const float ho = in ? fmaf(a.holdf.b0, th.sh[j], z) : 0.f;
+            if (in) z = fmaf(a.holdf.alpha, z, a.holdf.beta * th.sh[j]);
+            const float ga = in ? th.yb[j] + pw : 0.f;
+            pw *= a.attf.alpha;
+            th.x2[j] = fmaxf(th.sh[j], ho);                      // hyrax.py:73
+            th.mx[j] = fmaxf(ho, ga);
+        }
+        if (valid > 0)
+            r = Affine{L2::block_decay(a.pr16, a.rel.alpha, valid), (double)L2::run_forward(a.relf, th.x2, valid, 0.f)};
+        return r;
+    }
+
+    // ---- P6: release output -> gain -> plane ---------------------------------------------------------
+    template <bool FULL = false>
+    static MGX_HD void phase_gain(int tid, const Limiter2Args& a, Thread& th, Affine pr, double rel_carry, float* lds) {
+        if (!th.core) return;
+        const int valid = FULL ? E : th.valid;
+        float z = (float)affine_apply(pr, rel_carry);
+        float* gn = plane(lds) + tid * STRIDE;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) {
+            const bool in = j < valid;
+            const float ro = in ? fmaf(a.relf.b0, th.x2[j], z) : 0.f;
+            if (in) z = fmaf(a.relf.alpha, z, a.relf.beta * th.x2[j]);
+            gn[j] = 1.0f - fmaxf(th.mx[j], ro);                  // hyrax.py:75,97 without g0 (phase_store)
+        }
+    }
+
+    // ---- P7 split in two (experiment): the frames of the store phase are asked for before the release
+    //      look-back is waited for, so that the two latencies overlap; interior chunks only.
+    struct Frames {
+        float4 q[E / 2];
+    };
+    static MGX_HD bool interior_chunk(long long chunk, const Limiter2Args& a) {
+        const long long r0 = region_start(chunk, a);
+        return r0 >= 0 && r0 + FRAMES <= a.n;
+    }
+    static MGX_HD void fetch_frames(int tid, long long chunk, const Limiter2Args& a, Frames& fr) {
+        const long long r0 = region_start(chunk, a);
+        const long long c0 = r0 + (long long)a.gl * E, c1 = r0 + (long long)(T - a.gr) * E;
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) {
+            const long long f = r0 + 2 * tid + 2 * T * j;
+            fr.q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f >= c0 && f < c1) fr.q[j] = *reinterpret_cast<const float4*>(a.y + f);
+        }
+    }
+    static MGX_HD void phase_store_held(int tid, long long chunk, const Limiter2Args& a, const Frames& fr, const float* lds) {
+        const long long r0 = region_start(chunk, a);
+        const long long c0 = r0 + (long long)a.gl * E, c1 = r0 + (long long)(T - a.gr) * E;
+        const float g = (float)*a.gain, post = (float)*a.post_gain;
+        const float* gn = plane(const_cast<float*>(lds));
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) {
+            const int i = 2 * tid + 2 * T * j;
+            const long long f = r0 + i;
+            if (f < c0 || f >= c1) continue;
+            const float4 q = fr.q[j];
+            const float2 v0 = scaled(make_float2(q.x, q.y), g), v1 = scaled(make_float2(q.z, q.w), g);
+            const float s0 = own_gain(v0, gn[gidx(i)], true, a.threshold) * post;
+            const float s1 = own_gain(v1, gn[gidx(i + 1)], true, a.threshold) * post;
+            st_stream(reinterpret_cast<float4*>(a.out + f), make_float4(v0.x * s0, v0.y * s0, v1.x * s1, v1.y * s1));
+        }
+    }
+
+    // ---- P7: coalesced reload, apply gain, store ---------------------------------------------------
+    template <bool FULL = false>
+    static MGX_HD void phase_store(int tid, long long chunk, const Limiter2Args& a, bool with_gain, const float* lds) {
+        const long long r0 = region_start(chunk, a);
+        const long long c0 = r0 + (long long)a.gl * E, c1 = r0 + (long long)(T - a.gr) * E;
+        const bool interior = FULL || (r0 >= 0 && r0 + FRAMES <= a.n);
+        const float g = (float)*a.gain, post = (float)*a.post_gain;
+        const float* gn = plane(const_cast<float*>(lds));
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) {
+            const int i = 2 * tid + 2 * T * j;
+            const long long f = r0 + i;
+            if (f < c0 || f >= c1) continue;
+            const float k0 = with_gain ? gn[gidx(i)] : 1.f, k1 = with_gain ? gn[gidx(i + 1)] : 1.f;
+            if (interior) {
+                const float4 q = *reinterpret_cast<const float4*>(a.y + f);
+                const float2 v0 = scaled(make_float2(q.x, q.y), g), v1 = scaled(make_float2(q.z, q.w), g);
+                const float s0 = own_gain(v0, k0, with_gain, a.threshold) * post;
+                const float s1 = own_gain(v1, k1, with_gain, a.threshold) * post;
+                st_stream(reinterpret_cast<float4*>(a.out + f), make_float4(v0.x * s0, v0.y * s0, v1.x * s1, v1.y * s1));
+            } else {
+                if (f < a.n) {
+                    const float2 v = scaled(a.y[f], g);
+                    const float s = own_gain(v, k0, with_gain, a.threshold) * post;
+                    a.out[f] = make_float2(v.x * s, v.y * s);
+                }
+                if (f + 1 < a.n) {
+                    const float2 v = scaled(a.y[f + 1], g);
+                    const float s = own_gain(v, k1, with_gain, a.threshold) * post;
+                    a.out[f + 1] = make_float2(v.x * s, v.y * s);
+                }
+            }
+        }
+    }
+};
+
+}  // namespace mgx

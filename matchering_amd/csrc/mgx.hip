@@ -72,6 +72,9 @@ struct mgx_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool stage_timing = false;                                    // mgx_stage_timing
+    hipEvent_t stage_ev[MGX_STAGE_COUNT][2] = {};
+    bool stage_used[MGX_STAGE_COUNT] = {};
     std::map<int, float2*> twiddles;
     TrackWork track[2];
     DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars, conv_queue;
@@ -112,6 +115,24 @@ static int ensure_pinned(mgx_handle* h, size_t bytes) {
     h->pinned_bytes = bytes;
     return 0;
 }
+
+// HIP-event brackets around the stages of mgx_master (mgx_stage_timing / mgx_stage_times): events on
+// the handle's stream, so they cost no synchronisation; off by default.
+static void stage_mark(mgx_handle* h, int stage, int end) {
+    if (!h->stage_timing) return;
+    if (!h->stage_ev[stage][0]) {
+        hipEventCreate(&h->stage_ev[stage][0]);
+        hipEventCreate(&h->stage_ev[stage][1]);
+    }
+    hipEventRecord(h->stage_ev[stage][end], h->stream);
+    if (end) h->stage_used[stage] = true;
+}
+struct StageScope {
+    mgx_handle* h;
+    int stage;
+    StageScope(mgx_handle* h_, int s) : h(h_), stage(s) { stage_mark(h, stage, 0); }
+    ~StageScope() { stage_mark(h, stage, 1); }
+};
 
 // control words shared by the kernels that count arrivals: [0] limiter ticket, [1] limiter error flag,
 // [4] correction-round arrivals.  Zeroed when allocated; every user leaves its word at zero.
@@ -389,14 +410,16 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
 }
 
 template <int LOG2N, bool MULTI, int TSHIFT = 1, int V = 0>
-static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr,
-                       int repeat) {
+static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr) {
     using F = Fft2<LOG2N, V>;
     const size_t lds = conv_lds_bytes<LOG2N, V>();
     MGX_TRY((allow_lds(k_conv_prep<LOG2N, TSHIFT, V>, lds)));
     MGX_TRY((allow_lds(k_conv<LOG2N, MULTI, TSHIFT, V>, lds)));
-    hipLaunchKernelGGL((k_conv_prep<LOG2N, TSHIFT, V>), dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev, a.tw,
-                       (float2*)h->filt.p, a.parts, gain_ptr, gain);
+    {
+        StageScope scope(h, MGX_STAGE_FILTER_SPECTRA);
+        hipLaunchKernelGGL((k_conv_prep<LOG2N, TSHIFT, V>), dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev,
+                           a.tw, (float2*)h->filt.p, a.parts, gain_ptr, gain);
+    }
     HIP_TRY(hipGetLastError());
     MGX_TRY(ensure(h, h->block_peak, (size_t)a.npairs * sizeof(float)));
     a.pair_peak = (float*)h->block_peak.p;
@@ -418,9 +441,10 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
     HIP_TRY(hipMemsetAsync(stamps_dev, 0, stamp_words * sizeof(long long), h->stream));
     a.stamps = stamps_dev;
 #endif
-    if (repeat > 1) HIP_TRY(hipEventRecord(h->ev0, h->stream));
-    for (int r = 0; r < repeat; ++r)
+    {
+        StageScope scope(h, MGX_STAGE_CONVOLVE);
         hipLaunchKernelGGL((k_conv<LOG2N, MULTI, TSHIFT, V>), dim3(grid), dim3(F::T), lds, h->stream, a);
+    }
 #ifdef MGX_CONV_STAMPS
     if (const char* path = std::getenv("MGX_STAMPS_OUT")) {
         std::vector<long long> host(stamp_words);
@@ -432,7 +456,6 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
         }
     }
 #endif
-    if (repeat > 1) HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -442,8 +465,7 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
 // partitions on N = 8192 blocks (uniformly partitioned overlap-save), because N = 2F no longer fits
 // a CU's LDS.  MGX_CONV_BLOCK_LOG2=<l> forces N = 2^l with K = 2F/N partitions (tests).
 static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const float* taps_dev, double gain,
-                    float* y, float* ymid, long long* npairs_out, int repeat = 1,
-                    const double* gain_ptr = nullptr) {
+                    float* y, float* ymid, long long* npairs_out, const double* gain_ptr = nullptr) {
     const int l = ilog2_exact(taps);
     if (l < 0) return fail(MGX_ERR_ARGUMENT, "FIR length must be a power of two");
     MGX_TRY(check_length(n));
@@ -469,15 +491,13 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     a.pair_peak = nullptr;
     MGX_TRY(get_twiddles(h, log2b, &a.tw));
     if (npairs_out) *npairs_out = a.npairs;
-    static const bool thin = std::getenv("MGX_EXP_CONV_THIN") != nullptr;
-    if (thin && parts == 1 && log2b == 13) return launch_conv<13, false, 1, 1>(h, a, taps_dev, gain, gain_ptr, repeat);
     if (parts > 1) {
-        if (log2b == 13) return launch_conv<13, true>(h, a, taps_dev, gain, gain_ptr, repeat);
-        if (log2b == 10) return launch_conv<10, true>(h, a, taps_dev, gain, gain_ptr, repeat);
+        if (log2b == 13) return launch_conv<13, true>(h, a, taps_dev, gain, gain_ptr);
+        if (log2b == 10) return launch_conv<10, true>(h, a, taps_dev, gain, gain_ptr);
         return fail(MGX_ERR_UNSUPPORTED, "partitioned convolution is built for 1024- and 8192-frame blocks only");
     }
     switch (log2b) {
-#define CASE(L) case L: return launch_conv<L, false>(h, a, taps_dev, gain, gain_ptr, repeat);
+#define CASE(L) case L: return launch_conv<L, false>(h, a, taps_dev, gain, gain_ptr);
         CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return fail(MGX_ERR_UNSUPPORTED, "FIR length not supported by the convolution kernel");
@@ -512,14 +532,52 @@ static int limiter_state(mgx_handle* h, long long n, const mgx_config* cfg, unsi
     return 0;
 }
 
-// preset_done: the caller's previous kernel has already preset the look-back words and the ticket
-static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_config* cfg, const double* gain_dev,
-                       const double* post_dev, const int* active_dev, float* out, bool preset_done = false) {
+// which limiter kernel a launch uses: the third-generation kernel compiled for 6 workgroups per CU;
+// MGX_LIMITER = 2 | 3w4 | 3w5 | 3w6 selects another build for A/B timing (tools/bench_limiter.py)
+static int launch_limiter(mgx_handle* h, const Limiter2Args& a) {
+    const char* which = std::getenv("MGX_LIMITER");
+    const std::string w = which ? which : "3w4";
+    if (w == "2") {
+        const size_t lds = Limiter2Block::LDS_BYTES;
+        MGX_TRY(allow_lds(k_limit, lds));
+        hipLaunchKernelGGL(k_limit, dim3((unsigned)a.nchunks), dim3(Limiter2Block::T), lds, h->stream, a);
+    } else {
+        size_t lds = Limiter3Block::LDS_BYTES;
+        if (const char* pad = std::getenv("MGX_LIM_LDS_PAD")) lds += (size_t)std::atoi(pad);   // occupancy experiments
+        const dim3 grid((unsigned)a.nchunks), block(Limiter3Block::T);
+        if (w == "3w5") hipLaunchKernelGGL((k_limit3<5, false>), grid, block, lds, h->stream, a);
+        else if (w == "3w4p") hipLaunchKernelGGL((k_limit3<4, true>), grid, block, lds, h->stream, a);
+        else if (w == "3w5p") hipLaunchKernelGGL((k_limit3<5, true>), grid, block, lds, h->stream, a);
+        else if (w == "3w6p") hipLaunchKernelGGL((k_limit3<6, true>), grid, block, lds, h->stream, a);
+        else if (w[1] == 'p') {          // persistent: as many workgroups as the chip holds
+            int cus = 256;
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+            const int per = w == "3p3" ? 3 : (w == "3p5" ? 5 : 4);
+            const dim3 pg((unsigned)std::min<long long>(a.nchunks, (long long)cus * per));
+            if (w == "3p3") { MGX_TRY((allow_lds(k_limit3p<3>, lds))); hipLaunchKernelGGL((k_limit3p<3>), pg, block, lds, h->stream, a); }
+            else if (w == "3p5") hipLaunchKernelGGL((k_limit3p<5>), pg, block, lds, h->stream, a);
+            else if (w == "3p4p") hipLaunchKernelGGL((k_limit3p<4, true>), pg, block, lds, h->stream, a);
+            else if (w == "3p4a1") hipLaunchKernelGGL((k_limit3p<4, false, 1>), pg, block, lds, h->stream, a);
+            else if (w == "3p4a2") hipLaunchKernelGGL((k_limit3p<4, false, 2>), pg, block, lds, h->stream, a);
+            else hipLaunchKernelGGL((k_limit3p<4>), pg, block, lds, h->stream, a);
+        }
+        else if (w == "3w4a1") hipLaunchKernelGGL((k_limit3<4, false, 1>), grid, block, lds, h->stream, a);
+        else if (w == "3w4a2") hipLaunchKernelGGL((k_limit3<4, false, 2>), grid, block, lds, h->stream, a);
+        else if (w == "3w8a2") hipLaunchKernelGGL((k_limit3<8, false, 2>), grid, block, lds, h->stream, a);
+        else if (w == "3w6") hipLaunchKernelGGL((k_limit3<6, false>), grid, block, lds, h->stream, a);
+        else hipLaunchKernelGGL((k_limit3<4, false>), grid, block, lds, h->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// everything of a limiter launch but the look-back words, ticket and error flag
+static int limiter_args(mgx_handle* h, const float* y, long long n, const mgx_config* cfg, const double* gain_dev,
+                        const double* post_dev, const int* active_dev, float* out, Limiter2Args& a) {
     LimiterParams lp;
     const std::string err = limiter_params(*cfg, lp);
     if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
     if (n < 8) return fail(MGX_ERR_ARGUMENT, "limiter input too short");
-    Limiter2Args a;
     limiter_fill(lp, (float)cfg->threshold, a);
     a.y = reinterpret_cast<const float2*>(y);
     a.n = n;
@@ -542,6 +600,14 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     a.w_hold = (const double*)h->lim_weights.p;
     a.w_rel = a.w_hold + lp.w_hold.size();
     a.w_att = a.w_rel + lp.w_rel.size();
+    return 0;
+}
+
+// preset_done: the caller's previous kernel has already preset the look-back words and the ticket
+static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_config* cfg, const double* gain_dev,
+                       const double* post_dev, const int* active_dev, float* out, bool preset_done = false) {
+    Limiter2Args a;
+    MGX_TRY(limiter_args(h, y, n, cfg, gain_dev, post_dev, active_dev, out, a));
     // published words preset to "unpublished", ticket and error zeroed, every launch
     const size_t pub_bytes = (size_t)3 * a.nchunks * sizeof(unsigned long long);
     MGX_TRY(ensure(h, h->lim_published, pub_bytes));
@@ -553,11 +619,7 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
         HIP_TRY(hipMemsetAsync(h->lim_published.p, 0xff, pub_bytes, h->stream));
         HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 4, h->stream));   // ticket only: a raised error sticks
     }
-    const size_t lds = Limiter2Block::LDS_BYTES;
-    MGX_TRY(allow_lds(k_limit, lds));
-    hipLaunchKernelGGL(k_limit, dim3((unsigned)a.nchunks), dim3(Limiter2Block::T), lds, h->stream, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return launch_limiter(h, a);
 }
 
 // a look-back wait expired (never seen; the spin is bounded so that a lost chunk cannot hang the GPU)
@@ -656,6 +718,9 @@ int mgx_destroy(mgx_handle* h) {
     if (h->pinned) hipHostFree(h->pinned);
     hipEventDestroy(h->ev0);
     hipEventDestroy(h->ev1);
+    for (auto& pair : h->stage_ev)
+        for (hipEvent_t e : pair)
+            if (e) hipEventDestroy(e);
     hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -781,21 +846,6 @@ int mgx_convolve(mgx_handle* h, const float* x_dev, int64_t n, const double* fir
     return 0;
 }
 
-int mgx_convolve_timed(mgx_handle* h, const float* x_dev, int64_t n, const double* fir_mid, const double* fir_side,
-                       int32_t taps, double gain, float* y_dev, float* y_mid_dev, int32_t iters,
-                       float* ms_per_launch) {
-    if (!h || !x_dev || !fir_mid || !fir_side || !y_dev || !ms_per_launch || iters < 2)
-        return fail(MGX_ERR_ARGUMENT, "bad argument");
-    HIP_TRY(hipSetDevice(h->device));
-    MGX_TRY(upload_taps(h, fir_mid, fir_side, taps));
-    MGX_TRY(run_conv(h, x_dev, n, taps, (const float*)h->taps.p, gain, y_dev, y_mid_dev, nullptr, iters));
-    HIP_TRY(hipEventSynchronize(h->ev1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    *ms_per_launch = ms / iters;
-    return 0;
-}
-
 int mgx_clipped_piece_sumsq(mgx_handle* h, const float* mid_dev, int64_t n, int64_t piece_size, int32_t divisions,
                             double gain, double* sumsq) {
     if (!h || !mid_dev || !sumsq) return fail(MGX_ERR_ARGUMENT, "null argument");
@@ -873,22 +923,32 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     TrackWork& rw = h->track[1];
     // (analysing the reference first, so that the target is the fresher track in the Infinity Cache when
     // the convolution reads it, was measured: no difference)
-    MGX_TRY(run_analysis(h, target_dev, n_target, cfg, 0, tw));
-    MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
-    MGX_TRY(run_levels(h, cfg, &tw, &rw));
+    {
+        StageScope scope(h, MGX_STAGE_ANALYZE_TARGET);
+        MGX_TRY(run_analysis(h, target_dev, n_target, cfg, 0, tw));
+    }
+    {
+        StageScope scope(h, MGX_STAGE_ANALYZE_REFERENCE);
+        MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
+    }
     // stage 2 (stages.py:107-135): FIR design on the device, then the overlap-save convolution with
     // the level gain of stages.py:80-88 (a device scalar) folded into the filter spectra
-    MGX_TRY(run_fir_design(h, cfg, tw, rw));
+    {
+        StageScope scope(h, MGX_STAGE_DESIGN_FIR);
+        MGX_TRY(run_levels(h, cfg, &tw, &rw));
+        MGX_TRY(run_fir_design(h, cfg, tw, rw));
+    }
     MGX_TRY(ensure(h, h->y, (size_t)n_target * sizeof(float2)));
     MGX_TRY(ensure(h, h->mid, (size_t)n_target * sizeof(float)));
     long long nblocks = 0;
     MGX_TRY(run_conv(h, target_dev, n_target, f, (const float*)h->taps.p, 1.0, (float*)h->y.p, (float*)h->mid.p,
-                     &nblocks, 1, (const double*)h->scalars.p));
+                     &nblocks, (const double*)h->scalars.p));
     // stage 3 (stages.py:138-170): scalar feedback stays on the device; one launch per round, the last
     // round also derives the peak / early-out / normalisation scalars (the state was reset by k_fir_raw)
     CorrectionState* cs = (CorrectionState*)h->cstate.p;
     bool limiter_preset = false;
     {
+        StageScope scope(h, MGX_STAGE_CORRECT_LEVELS);
         RoundArgs ra;
         ra.mid = (const float*)h->mid.p;
         ra.piece = tw.piece;
@@ -933,6 +993,7 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     }
     // stage 4 (stages.py:173-207)
     if (result_no_limiter_dev || result_no_limiter_normalized_dev) {
+        StageScope scope(h, MGX_STAGE_SCALE_OUTPUTS);
         const unsigned grid = (unsigned)std::min<long long>((n_target + 255) / 256, 8192);
         hipLaunchKernelGGL(k_scale_outputs, dim3(grid), dim3(256), 0, h->stream, (const float2*)h->y.p,
                            (long long)n_target, (const double*)&cs->gain, 1.0, (const double*)&cs->normalize_c,
@@ -940,6 +1001,7 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         HIP_TRY(hipGetLastError());
     }
     if (result_dev) {
+        StageScope scope(h, MGX_STAGE_LIMIT);
         const double* post = &((const TrackStats*)rw.stats.p)->amplitude_c;
         MGX_TRY(run_limiter(h, (const float*)h->y.p, n_target, cfg, &cs->gain, post, &cs->limiter_active, result_dev,
                             limiter_preset));
@@ -972,6 +1034,24 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         report->target_loud_count = st_t->loud_count;
         report->reference_loud_count = st_r->loud_count;
         report->limiter_active = hc->limiter_active;
+    }
+    return 0;
+}
+
+int mgx_stage_timing(mgx_handle* h, int32_t enable) {
+    if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
+    h->stage_timing = enable != 0;
+    for (bool& u : h->stage_used) u = false;
+    return 0;
+}
+int mgx_stage_times(mgx_handle* h, float* ms) {
+    if (!h || !ms) return fail(MGX_ERR_ARGUMENT, "null argument");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int s = 0; s < MGX_STAGE_COUNT; ++s) {
+        ms[s] = -1.f;
+        if (!h->stage_used[s]) continue;
+        HIP_TRY(hipEventElapsedTime(&ms[s], h->stage_ev[s][0], h->stage_ev[s][1]));
+        h->stage_used[s] = false;
     }
     return 0;
 }

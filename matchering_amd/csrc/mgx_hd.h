@@ -198,6 +198,15 @@ MGX_HD float fast_sqrt(float x) {
 #endif
 }
 
+// 1/x to 1 ulp (v_rcp_f32); the division operator expands to a ~10-instruction IEEE sequence
+MGX_HD float fast_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_HOST_EMU)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 constexpr int bitrev(int v, int bits) {
     int r = 0;

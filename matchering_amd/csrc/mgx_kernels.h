@@ -10,6 +10,7 @@
 #include "conv2_kernel.h"
 #include "fir_plan.h"
 #include "limiter2_kernel.h"
+#include "limiter3_kernel.h"
 
 namespace mgx {
 
@@ -1207,6 +1208,170 @@ __global__ __launch_bounds__(Limiter2Block::T, 4) void k_limit(Limiter2Args a) {
     LB::phase_gain(opaque(tid), a, th, pre, LB::scalars(lds)[1], lds);
     __syncthreads();
     LB::phase_store(opaque(tid), chunk, a, true, lds);
+}
+
+// ---- third generation (limiter3_kernel.h): one LDS plane, six workgroups per CU ----------------
+// maximum over the eight lanes that share lane >> 3 (non-negative values): three DPP steps
+__device__ __forceinline__ float dpp_max8(float v) {
+    int x = __float_as_int(v);
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true))));   // quad_perm [1,0,3,2]
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true))));   // quad_perm [2,3,0,1]
+    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true))));  // row_half_mirror
+    return __int_as_float(x);
+}
+
+// one chunk, from the load phase to the store; FULL = the chunk lies strictly inside the track
+// ABL (timing experiments only, results are wrong): 1 = carries taken as zero, nothing waited for;
+// 2 = load, plane and store phases only
+template <bool FULL, bool PF, int ABL = 0>
+__device__ __forceinline__ void limit3_chunk(const Limiter2Args& a, long long chunk, float* lds) {
+    using LB = Limiter3Block;
+    // (opaque: nothing derived from the thread id may be hoisted out of a persistent caller's loop)
+    const int tid = opaque((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
+    {
+        float pm[LB::E / 2];
+        LB::phase_load<FULL>(opaque(tid), chunk, a, lds, pm);
+#pragma unroll
+        for (int j = 0; j < LB::E / 2; ++j) {
+            const float m = dpp_max8(pm[j]);
+            if ((tid & 7) == 0) LB::block_max(lds)[LB::block_of(tid, j)] = m;
+        }
+    }
+    __syncthreads();
+    if (ABL == 2) {
+        LB::phase_store<FULL>(opaque(tid), chunk, a, true, lds);
+        return;
+    }
+
+    // hold filter first (scan 1): its aggregate is published as early as possible
+    LB::Thread th;
+    Affine whole;
+    {
+        const Affine m1 = LB::phase_hold_window<FULL>(opaque(tid), chunk, a, th, lds);
+        const Affine i1 = wave_inclusive<false>(m1);
+        if (lane == 63) LB::wave_totals(lds, 1)[wave] = i1;
+        const Affine e1 = wave_exclusive<false>(i1);
+        __syncthreads();
+        th.hold_pre = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 1), e1, &whole);
+    }
+    if (tid == 0) LB::lookback_publish(chunk, 0, a, whole.b);
+    // ask for the predecessors' words now, take them after the attack path (wave 0: hold, wave 1: attack)
+    LB::Polls polls;
+    if (ABL == 0 && wave == 0) LB::lookback_ask(lane, chunk, 0, a, polls);
+    // forward attack smoother (scan 0)
+    Affine p0;
+    {
+        const Affine m0 = LB::phase_attack_window<FULL>(opaque(tid), a, th, lds);
+        const Affine i0 = wave_inclusive<false>(m0);
+        if (lane == 63) LB::wave_totals(lds, 0)[wave] = i0;
+        const Affine e0 = wave_exclusive<false>(i0);
+        __syncthreads();
+        p0 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 0), e0, nullptr);
+    }
+    if (tid == LB::T - a.gr) LB::lookback_publish(chunk, 2, a, p0.b);          // attack state at the end of the core
+    if (ABL == 0 && wave == 1) LB::lookback_ask(lane, chunk, 2, a, polls);
+    const bool tail = !FULL && LB::tail_chunk(chunk, a);                        // uniform
+    double att_now = 0.0;
+    if (ABL == 0 && tail) {
+        if (wave == 1) {
+            const double s = wave_sum(LB::lookback_take(lane, chunk, 2, a, polls));
+            if (lane == 0) LB::scalars(lds)[2] = s;
+        }
+        __syncthreads();
+        att_now = LB::scalars(lds)[2];
+    }
+
+    // backward attack smoother, right to left (scan 2)
+    const Affine mb = LB::phase_attack_forward<FULL>(opaque(tid), a, th, p0, att_now, lds);
+    const Affine ib = wave_inclusive<true>(mb);
+    if (lane == 0) LB::wave_totals(lds, 2)[wave] = ib;
+    const Affine eb = wave_exclusive<true>(ib);
+    __syncthreads();
+    const Affine pb = compose_waves<true, LB::WAVES>(LB::wave_totals(lds, 2), eb, nullptr);
+    LB::phase_attack_backward<FULL>(opaque(tid), a, th, pb);
+    if (ABL != 0 && tid == 0) { LB::scalars(lds)[0] = 0.0; LB::scalars(lds)[1] = 0.0; LB::scalars(lds)[2] = 0.0; }
+    if (ABL == 0 && wave == 0) {
+        const double s = wave_sum(LB::lookback_take(lane, chunk, 0, a, polls));
+        if (lane == 0) LB::scalars(lds)[0] = s;
+    }
+    if (ABL == 0 && wave == 1 && !tail) {
+        const double s = wave_sum(LB::lookback_take(lane, chunk, 2, a, polls));
+        if (lane == 0) LB::scalars(lds)[2] = s;
+    }
+    __syncthreads();
+
+    // hold output, release filter (scan 3)
+    const Affine mr = LB::phase_hold<FULL>(opaque(tid), a, th, LB::scalars(lds)[0], tail ? 0.0 : LB::scalars(lds)[2]);
+    const Affine ir = wave_inclusive<false>(mr);
+    if (lane == 63) LB::wave_totals(lds, 3)[wave] = ir;
+    const Affine er = wave_exclusive<false>(ir);
+    __syncthreads();
+    const Affine pr = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 3), er, &whole);
+    if (tid == 0) LB::lookback_publish(chunk, 1, a, whole.b);
+    if (ABL == 0 && wave == 0) LB::lookback_ask(lane, chunk, 1, a, polls);
+    LB::Frames fr;
+    constexpr bool held = PF && FULL;
+    if (held) LB::fetch_frames(opaque(tid), chunk, a, fr);
+    if (ABL == 0 && wave == 0) {
+        const double s = wave_sum(LB::lookback_take(lane, chunk, 1, a, polls));
+        if (lane == 0) LB::scalars(lds)[1] = s;
+    }
+    __syncthreads();
+    LB::phase_gain<FULL>(opaque(tid), a, th, pr, LB::scalars(lds)[1], lds);
+    __syncthreads();
+    if (held) LB::phase_store_held(opaque(tid), chunk, a, fr, lds);
+    else LB::phase_store<FULL>(opaque(tid), chunk, a, true, lds);
+}
+
+// WGS = workgroups per CU the kernel is compiled for (register budget 512 / WGS per lane)
+// PF (experiment) = ask for the store phase's frames before waiting for the release look-back
+template <int WGS, bool PF = false, int ABL = 0>
+__global__ __launch_bounds__(Limiter3Block::T, WGS) void k_limit3(Limiter2Args a) {
+    using LB = Limiter3Block;
+    MGX_LDS;
+    float* lds = reinterpret_cast<float*>(mgx_smem);
+    int& ticket = *reinterpret_cast<int*>(LB::scalars(lds) + 4);
+    const int tid = threadIdx.x;
+    const bool active = a.active ? (*a.active != 0) : true;
+    if (!active) {                       // hyrax.py:83-85: the array passes through, then stages.py:203
+        LB::phase_store(tid, blockIdx.x, a, false, lds);
+        return;
+    }
+    if (tid == 0) ticket = atomicAdd(a.ticket, 1);
+    __syncthreads();
+    const long long chunk = ticket;
+    if (LB::full_chunk(chunk, a)) limit3_chunk<true, PF, ABL>(a, chunk, lds);
+    else limit3_chunk<false, PF, ABL>(a, chunk, lds);
+}
+
+// Persistent form: as many workgroups as the chip holds, each drawing chunk after chunk from the
+// ticket counter.  The next ticket is asked for when a chunk starts and read when it ends, so its
+// round trip to the L2 (1-3 us under load) no longer stands in front of every chunk's loads.
+template <int WGS, bool PF = false, int ABL = 0>
+__global__ __launch_bounds__(Limiter3Block::T, WGS) void k_limit3p(Limiter2Args a) {
+    using LB = Limiter3Block;
+    MGX_LDS;
+    float* lds = reinterpret_cast<float*>(mgx_smem);
+    int& ticket = *reinterpret_cast<int*>(LB::scalars(lds) + 4);
+    const int tid = threadIdx.x;
+    const bool active = a.active ? (*a.active != 0) : true;
+    if (!active) {
+        for (long long c = blockIdx.x; c < a.nchunks; c += gridDim.x) LB::phase_store(tid, c, a, false, lds);
+        return;
+    }
+    if (tid == 0) ticket = atomicAdd(a.ticket, 1);
+    __syncthreads();
+    long long chunk = ticket;
+    while (chunk < a.nchunks) {
+        int next = 0;
+        if (tid == 0) next = atomicAdd(a.ticket, 1);
+        if (LB::full_chunk(chunk, a)) limit3_chunk<true, PF, ABL>(a, chunk, lds);
+        else limit3_chunk<false, PF, ABL>(a, chunk, lds);
+        __syncthreads();                 // the store phase has read the gain plane; the ticket slot is free
+        if (tid == 0) ticket = next;
+        __syncthreads();
+        chunk = ticket;
+    }
 }
 
 }  // namespace mgx

@@ -5,6 +5,7 @@ integer pointers; numpy arrays cross the PCIe boundary only in ``upload`` /
 """
 
 import ctypes
+import threading
 
 import numpy as np
 
@@ -40,6 +41,11 @@ class Device:
     def __init__(self, index=0):
         self.index = index
         self.handle = None
+        # include/mgx.h: calls on one handle are serialised by the caller.  ctypes drops the GIL while a
+        # call blocks, so two threads sharing a Device (the process-wide default one, typically) would
+        # otherwise interleave inside the same stream and workspaces.  Every upload -> kernels ->
+        # download sequence of this package runs under this lock.
+        self.lock = threading.RLock()
         h = ctypes.c_void_p()
         check(library().mgx_create(index, ctypes.byref(h)))
         self.handle = h
@@ -84,6 +90,16 @@ class Device:
         ms = ctypes.c_float()
         check(library().mgx_timer_stop(self.handle, ctypes.byref(ms)))
         return ms.value
+
+    # ---- per-stage device times of mgx_master (bench.py) ---------------------------
+    def stage_timing(self, enable=True):
+        check(library().mgx_stage_timing(self.handle, int(bool(enable))))
+
+    def stage_times(self):
+        """Milliseconds per stage of the last ``master`` call, keyed by stage name (``None`` = not run)."""
+        ms = (ctypes.c_float * len(_native.STAGES))()
+        check(library().mgx_stage_times(self.handle, ms))
+        return {name: (float(v) if v >= 0 else None) for name, v in zip(_native.STAGES, ms)}
 
     # ---- the boundary ------------------------------------------------------------
     def master(self, target, n_target, reference, n_reference, native_config, result=None,

@@ -1,9 +1,11 @@
 """Stage-level entry points of libmgx on numpy arrays (upload -> kernel -> download).
 
 These are the finer boundaries of SURVEY.md section 8(b): each wraps one C-ABI call so
-that a stage can be used, and parity-tested, on its own.  ``stage_helpers`` and
-``limiter`` build the reference-named functions on top of them.
+that a stage can be used, and parity-tested, on its own.  Every wrapper holds the
+device's lock from its upload to its download (include/mgx.h: one caller per handle).
 """
+
+import functools
 
 import ctypes
 from collections import namedtuple
@@ -21,6 +23,19 @@ def _dp(a):
     return a.ctypes.data_as(c_double_p)
 
 
+def _exclusive(fn):
+    """Run ``fn`` under the lock of the device it will use (``device=`` keyword or the default one)."""
+
+    @functools.wraps(fn)
+    def locked(*args, device=None, **kwargs):
+        dev = device or default_device()
+        with dev.lock:
+            return fn(*args, device=dev, **kwargs)
+
+    return locked
+
+
+@_exclusive
 def analyze(array, config, is_reference=False, device=None):
     """match_levels.py:134-161 + match_frequencies.py:30-42 in one pass (``mgx_analyze``)."""
     dev = device or default_device()
@@ -60,6 +75,7 @@ def design_fir(avg_target, avg_reference, config):
     return taps, raw, smooth
 
 
+@_exclusive
 def convolve(array, mid_fir, side_fir, gain=1.0, device=None):
     """match_frequencies.py:104-119 on interleaved L/R frames (``mgx_convolve``).
     Returns (result (n,2) float32, result_mid (n,) float32, peak)."""
@@ -81,6 +97,7 @@ def convolve(array, mid_fir, side_fir, gain=1.0, device=None):
             b.release()
 
 
+@_exclusive
 def clipped_piece_sumsq(mid, piece_size, divisions, gain=1.0, device=None):
     """Sum of squares per piece of clip(gain*mid, -1, 1) (stages.py:149-160, ``mgx_clipped_piece_sumsq``)."""
     dev = device or default_device()
@@ -95,6 +112,7 @@ def clipped_piece_sumsq(mid, piece_size, divisions, gain=1.0, device=None):
     return out
 
 
+@_exclusive
 def limit(array, config, gain=1.0, post_gain=1.0, device=None):
     """limiter/hyrax.py:78-99 on (array*gain), times post_gain (``mgx_limit``).
     Returns (limited (n,2) float32, active flag)."""
@@ -113,6 +131,7 @@ def limit(array, config, gain=1.0, post_gain=1.0, device=None):
         ob.release()
 
 
+@_exclusive
 def scale(array, gain, device=None):
     """dsp.py:89-90 ``amplify`` on the device (``mgx_scale``)."""
     dev = device or default_device()

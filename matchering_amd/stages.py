@@ -37,34 +37,35 @@ def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default
     info(Code.INFO_MATCHING_LEVELS)
     debug(f"analysis pieces: at most {config.max_piece_size} frames "
           f"({config.max_piece_size / config.internal_sample_rate:.2f} s) each")
-    t_dev = dev.upload(target)
-    r_dev = dev.upload(reference)
-    outs = [dev.alloc(n * 8) if need else None
-            for need in (need_default, need_no_limiter, need_no_limiter_normalized)]
-    try:
-        report = dev.master(t_dev, n, r_dev, nr, native, *outs)
-        debug(f"target: {report.target_divisions} pieces of {report.target_piece} frames, "
-              f"{report.target_loud_count} of them loud; reference: {report.reference_divisions} pieces of "
-              f"{report.reference_piece} frames, {report.reference_loud_count} loud")
-        if not np.isclose(report.final_amplitude_coefficient, 1.0):
-            debug("the reference peaks below the threshold: it was scaled up for matching and the result "
-                  f"is scaled back by {to_db(report.final_amplitude_coefficient)}")
-        debug(f"level match: {to_db(report.rms_coefficient)} on the target")
-        debug_line()
-        info(Code.INFO_MATCHING_FREQS)
-        debug_line()
-        info(Code.INFO_CORRECTING_LEVELS)
-        for step in range(config.rms_correction_steps):
-            debug(f"correction round {step + 1}: {to_db(report.correction_coefficients[step])}")
-        debug_line()
-        info(Code.INFO_FINALIZING)
-        if need_no_limiter_normalized:
-            debug(f"unlimited result normalised by {to_db(report.normalize_coefficient)} to reach the threshold")
-        if need_default and not report.limiter_active:
-            debug("the result stays under the threshold: the limiter passes it through")
-        results = tuple(dev.download(b, (n, 2)) if b is not None else None for b in outs)
-    finally:
-        for b in (t_dev, r_dev, *outs):
-            if b is not None:
-                b.release()
+    with dev.lock:
+        t_dev = dev.upload(target)
+        r_dev = dev.upload(reference)
+        outs = [dev.alloc(n * 8) if need else None
+                for need in (need_default, need_no_limiter, need_no_limiter_normalized)]
+        try:
+            report = dev.master(t_dev, n, r_dev, nr, native, *outs)
+            debug(f"target: {report.target_divisions} pieces of {report.target_piece} frames, "
+                  f"{report.target_loud_count} of them loud; reference: {report.reference_divisions} pieces of "
+                  f"{report.reference_piece} frames, {report.reference_loud_count} loud")
+            if not np.isclose(report.final_amplitude_coefficient, 1.0):
+                debug("the reference peaks below the threshold: it was scaled up for matching and the result "
+                      f"is scaled back by {to_db(report.final_amplitude_coefficient)}")
+            debug(f"level match: {to_db(report.rms_coefficient)} on the target")
+            debug_line()
+            info(Code.INFO_MATCHING_FREQS)
+            debug_line()
+            info(Code.INFO_CORRECTING_LEVELS)
+            for step in range(config.rms_correction_steps):
+                debug(f"correction round {step + 1}: {to_db(report.correction_coefficients[step])}")
+            debug_line()
+            info(Code.INFO_FINALIZING)
+            if need_no_limiter_normalized:
+                debug(f"unlimited result normalised by {to_db(report.normalize_coefficient)} to reach the threshold")
+            if need_default and not report.limiter_active:
+                debug("the result stays under the threshold: the limiter passes it through")
+            results = tuple(dev.download(b, (n, 2)) if b is not None else None for b in outs)
+        finally:
+            for b in (t_dev, r_dev, *outs):
+                if b is not None:
+                    b.release()
     return results

@@ -15,6 +15,7 @@
 #include "../../matchering_amd/csrc/conv2_kernel.h"
 #include "../../matchering_amd/csrc/fir_design.h"
 #include "../../matchering_amd/csrc/host_params.h"
+#include "../../matchering_amd/csrc/limiter3_kernel.h"
 
 using namespace mgx;
 
@@ -265,7 +266,7 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
                          float* out, float* dbg_sl, float* dbg_sh) {
     LimiterParams lp;
     if (!limiter_params(*cfg, lp).empty()) return -1;
-    using LB = Limiter2Block;
+    using LB = Limiter3Block;
     Limiter2Args a;
     limiter_fill(lp, (float)cfg->threshold, a);
     a.y = reinterpret_cast<const float2*>(x);
@@ -285,30 +286,42 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
     a.error = &ctrl[1];
     std::vector<float> lds(LB::LDS_BYTES / 4 + 8);
     std::vector<LB::Thread> th(LB::T);
-    std::vector<LB::ScanIn> in(LB::T);
-    std::vector<LB::ScanOut> pre(LB::T);
-    // the workgroup scans of the device kernel (wave shuffles there), as plain ordered loops:
-    // scan 1 always left to right, scan 0 left to right or (reverse0) right to left
-    auto scan = [&](bool reverse0, Affine& whole1) {
+    std::vector<Affine> in0(LB::T), in1(LB::T), pre0(LB::T), pre1(LB::T);
+    // the workgroup scans of the device kernel (wave shuffles there), as plain ordered loops
+    auto scan = [&](const std::vector<Affine>& in, std::vector<Affine>& pre, bool reverse) {
         Affine run = affine_identity();
-        for (int t = 0; t < LB::T; ++t) { pre[t].p1 = run; run = affine_then(run, in[t].m1); }
-        whole1 = run;
-        run = affine_identity();
         for (int i = 0; i < LB::T; ++i) {
-            const int t = reverse0 ? LB::T - 1 - i : i;
-            pre[t].p0 = run;
-            run = affine_then(run, in[t].m0);
+            const int t = reverse ? LB::T - 1 - i : i;
+            pre[t] = run;
+            run = affine_then(run, in[t]);
         }
+        return run;
     };
     auto carry = [&](long long chunk, int slot) {
         double s = 0.0;
-        for (int lane = 0; lane < 64; ++lane) s += LB::lookback_share(lane, chunk, slot, a);
+        for (int lane = 0; lane < 64; ++lane) {
+            LB::Polls p;
+            LB::lookback_ask(lane, chunk, slot, a, p);
+            s += LB::lookback_take(lane, chunk, slot, a, p);
+        }
         return s;
     };
     for (long long chunk = 0; chunk < a.nchunks; ++chunk) {
-        FOR_THREADS(LB::T) LB::phase_load(tid, chunk, a, lds.data());
-        FOR_THREADS(LB::T) LB::phase_planes(tid, chunk, a, th[tid], lds.data());
-        FOR_THREADS(LB::T) in[tid] = LB::phase_windows(tid, a, th[tid], lds.data());
+        FOR_THREADS(LB::T) {
+            float pm[LB::E / 2];
+            LB::phase_load(tid, chunk, a, lds.data(), pm);
+        }
+        // block maxima: the device folds eight lanes with DPP steps
+        for (int b = 0; b < LB::T; ++b) {
+            float m = 0.f;
+            for (int j = 0; j < LB::E; ++j) m = std::fmax(m, LB::plane(lds.data())[b * LB::STRIDE + j]);
+            LB::block_max(lds.data())[b] = m;
+        }
+        FOR_THREADS(LB::T) in1[tid] = LB::phase_hold_window(tid, chunk, a, th[tid], lds.data());
+        const Affine whole_hold = scan(in1, pre1, false);
+        FOR_THREADS(LB::T) th[tid].hold_pre = pre1[tid];
+        LB::lookback_publish(chunk, 0, a, whole_hold.b);
+        FOR_THREADS(LB::T) in0[tid] = LB::phase_attack_window(tid, a, th[tid], lds.data());
         if (dbg_sl || dbg_sh) {
             FOR_THREADS(LB::T) {
                 if (!th[tid].core) continue;
@@ -318,16 +331,19 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
                 }
             }
         }
-        Affine whole;
-        scan(false, whole);
-        LB::lookback_publish(chunk, 2, a, pre[LB::T - a.gr].p0.b);
-        LB::lookback_publish(chunk, 0, a, whole.b);
-        const double hold_carry = carry(chunk, 0), att_carry = carry(chunk, 2);
-        FOR_THREADS(LB::T) in[tid] = LB::phase_exact_first(tid, a, th[tid], pre[tid], att_carry, hold_carry, lds.data());
-        scan(true, whole);
-        LB::lookback_publish(chunk, 1, a, whole.b);
+        scan(in0, pre0, false);
+        LB::lookback_publish(chunk, 2, a, pre0[LB::T - a.gr].b);
+        const bool tail = LB::tail_chunk(chunk, a);
+        const double att_carry = carry(chunk, 2), hold_carry = carry(chunk, 0);
+        FOR_THREADS(LB::T)
+            in0[tid] = LB::phase_attack_forward(tid, a, th[tid], pre0[tid], tail ? att_carry : 0.0, lds.data());
+        scan(in0, pre0, true);
+        FOR_THREADS(LB::T) LB::phase_attack_backward(tid, a, th[tid], pre0[tid]);
+        FOR_THREADS(LB::T) in1[tid] = LB::phase_hold(tid, a, th[tid], hold_carry, tail ? 0.0 : att_carry);
+        const Affine whole_rel = scan(in1, pre1, false);
+        LB::lookback_publish(chunk, 1, a, whole_rel.b);
         const double rel_carry = carry(chunk, 1);
-        FOR_THREADS(LB::T) LB::phase_gain(tid, a, th[tid], pre[tid], rel_carry, lds.data());
+        FOR_THREADS(LB::T) LB::phase_gain(tid, a, th[tid], pre1[tid], rel_carry, lds.data());
         FOR_THREADS(LB::T) LB::phase_store(tid, chunk, a, true, lds.data());
     }
     return ctrl[1] ? -2 : 0;

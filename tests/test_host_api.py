@@ -317,7 +317,10 @@ def test_stages_main_host_glue_with_a_stand_in_device():
 
     class StandIn:
         def __init__(self):
+            import threading
+
             self.buffers = []
+            self.lock = threading.RLock()        # stages.main serialises callers of one device
 
         def upload(self, array, dtype=np.float32):
             b = Buf(np.ascontiguousarray(array, dtype=dtype))
