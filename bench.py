@@ -1,28 +1,33 @@
 #!/usr/bin/env python
 """bench.py -- stereo Msamples/s mastered on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the whole hot path (``mgx_master`` = matchering
-``stages.main``: level analysis of target and reference, FIR design, overlap-save
-convolution, 4-round level correction, output) over one synthetic 8-minute
-44.1 kHz stereo pair that is already resident in HBM.  Default workload =
-BASELINE.json configs[1] ("single 8-minute pair, matching-EQ FIR only, limiter
-bypassed" -> ``need_no_limiter`` output); configs[2] (full pipeline incl. the
-Hyrax limiter) is timed next to it and reported under "full_pipeline".  With N
-ranks every rank masters its own pair (pairs are independent: no data-path
-collective, weak scaling); the FIR tables are all-gathered over RCCL after the
-timed region, which is the only traffic that crosses xGMI.
+One "step" = one pass of the whole hot path (``mgx_master`` = matchering ``stages.main``: level
+analysis of target and reference, FIR design, overlap-save convolution, 4-round level correction,
+Hyrax limiter) over synthetic stereo pairs that are already resident in HBM.
 
-torch is used for rendezvous/barrier/max-reduce only (gloo, CPU tensors); device
-memory, streams and timing go through libmgx.  Prints ONE JSON line on rank 0.
+Workloads (BASELINE.json configs):
+  8min_full       configs[2]  one 8-minute 44.1 kHz pair, full pipeline incl. limiter -- the N=1 default,
+                              the configuration the 40 %-of-roofline target is stated on
+  8min_fir_only   configs[1]  the same pair, limiter bypassed (``result_no_limiter`` only)
+  4min_x8_full    configs[3]  one GPU's share of "64 four-minute pairs over 8 GPUs": eight pairs per step,
+                              submitted to two device handles (two HIP streams) -- the default for N > 1
+  96k_16k_full    configs[4]  one 4-minute 96 kHz pair with a 16384-tap FIR (partitioned overlap-save)
+With N ranks every rank masters its own pairs (pairs are independent: no data-path collective, weak
+scaling); the FIR tables are all-gathered over RCCL after the timed region, the only traffic that
+crosses xGMI.
+
+torch is used for rendezvous/barrier/max-reduce only (gloo, CPU tensors); device memory, streams and
+timing go through libmgx.  Prints ONE JSON line on rank 0.
 """
 
 import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,9 +36,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290
-CONV_BYTES_PER_FRAME = 16      # read 8 + write 8 (the mid plane's 4 B are booked to S4)
-MODEL_BYTES = {"8min_fir_only": 64, "8min_full": 72}     # SURVEY.md 8(d) whole-pipeline byte models
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md)
+HBM_COPY_GBS = 6290.0          # measured float4 copy ceiling, same guide
+# SURVEY.md 8(d) byte models, bytes per target frame
+PIPELINE_BYTES = {"8min_full": 72, "8min_fir_only": 64, "4min_x8_full": 72, "96k_16k_full": 72}
+KERNEL_BYTES = {"convolve": 16,    # S3: read 8 + write 8 (the mid plane's 4 B are booked to S4)
+                "limit": 16}       # read 8 + write 8 per launch of the one-pass limiter (S5's 24 B model
+                                   # counts a second read that this kernel takes from the L2 / Infinity Cache)
+KERNEL_NAMES = {"convolve": "k_conv (overlap-save FIR)", "limit": "k_limit3 (Hyrax limiter, one pass)"}
+WORKLOADS = sorted(PIPELINE_BYTES)
 
 
 def parse():
@@ -41,11 +52,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="8min_fir_only", choices=sorted(MODEL_BYTES))
-    ap.add_argument("--seconds", type=float, default=480.0)
-    ap.add_argument("--sample-rate", type=int, default=44100)
+    ap.add_argument("--workload", default="auto", choices=["auto"] + WORKLOADS,
+                    help="auto = 8min_full on one GPU, 4min_x8_full per rank on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the second workload and PCIe figure")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the side workloads and the PCIe figure")
     return ap.parse_args()
 
 
@@ -94,71 +104,138 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def timed_steps(ranks, dev, step, steps, warmup):
+def timed_steps(ranks, sync, step, steps, warmup):
     for _ in range(warmup):
         step()
-    dev.synchronize()
+    sync()
     ranks.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    dev.synchronize()
+    sync()
     ranks.barrier()
     return ranks.max(time.perf_counter() - t0)
+
+
+class Workload:
+    """Resident inputs/outputs of one named workload on this rank and the function that runs one step."""
+
+    def __init__(self, name, rank, local, mg, Device, device_count, make_pair):
+        self.name = name
+        index = local % max(1, device_count())          # one rank per GPU; wraps only when ranks outnumber GPUs
+        self.dev = Device(index)
+        self.lanes = [self.dev]
+        self.sample_rate, self.fft, self.seconds, self.pairs = 44100, 4096, 480.0, 1
+        if name == "4min_x8_full":
+            self.seconds, self.pairs = 240.0, 8
+            self.lanes.append(Device(index))
+        elif name == "96k_16k_full":
+            self.sample_rate, self.fft, self.seconds = 96000, 16384, 240.0
+        self.cfg = mg.Config(internal_sample_rate=self.sample_rate, fft_size=self.fft)
+        self.native = self.cfg.to_native()
+        self.want_limiter = name != "8min_fir_only"
+        self.jobs = []
+        self.host_pair = None
+        for k in range(self.pairs):
+            target, reference = make_pair(self.seconds, self.sample_rate, pair=rank * self.pairs + k)
+            if k == 0:
+                self.host_pair = (target, reference)
+            d = self.lanes[k % len(self.lanes)]
+            self.jobs.append((d, d.upload(target), target.shape[0], d.upload(reference), reference.shape[0],
+                              d.alloc(target.shape[0] * 8)))
+        self.frames = sum(j[2] for j in self.jobs)
+
+    def step(self):
+        for d, t, n, r, nr, out in self.jobs:
+            if self.want_limiter:
+                d.master(t, n, r, nr, self.native, result=out, want_report=False)
+            else:
+                d.master(t, n, r, nr, self.native, result=None, result_no_limiter=out, want_report=False)
+
+    def sync(self):
+        for d in self.lanes:
+            d.synchronize()
+
+    def describe(self):
+        if self.name == "4min_x8_full":
+            what = "8 x 240 s stereo 44100 Hz pairs per GPU (config #4's per-GPU share), two device handles"
+        else:
+            what = f"{self.seconds:.0f} s stereo {self.sample_rate} Hz pair per GPU"
+        tail = "full pipeline incl. Hyrax limiter" if self.want_limiter else "matching-EQ FIR only (limiter bypassed)"
+        return f"{self.name}: {what}, fft_size {self.fft}, {tail}, inputs resident in HBM"
+
+    def stage_profile(self, steps):
+        """Device time per stage (HIP events on the handle's stream, inside mgx_master), median over steps."""
+        d, t, n, r, nr, out = self.jobs[0]
+        d.stage_timing(True)
+        rows = []
+        for _ in range(steps):
+            if self.want_limiter:
+                d.master(t, n, r, nr, self.native, result=out, want_report=False)
+            else:
+                d.master(t, n, r, nr, self.native, result=None, result_no_limiter=out, want_report=False)
+            rows.append(d.stage_times())
+        d.stage_timing(False)
+        return {k: statistics.median(row[k] for row in rows) for k in rows[0] if rows[0][k] is not None}, n
+
+    def release(self):
+        for d, t, n, r, nr, out in self.jobs:
+            for b in (t, r, out):
+                b.release()
+        for d in self.lanes[1:]:
+            d.close()
+
+
+def roofline_of(kernel, ms, frames, traffic):
+    alg = KERNEL_BYTES[kernel] * frames
+    achieved = alg / (ms * 1e-3) / 1e9
+    return {"kernel": KERNEL_NAMES[kernel], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4), "traffic": traffic,
+            "kernel_ms": round(ms, 4), "algorithmic_bytes_per_launch": alg,
+            "timing": "HIP events around the launch inside mgx_master, on the stream it runs on, median of the "
+                      "profiled steps (cold inputs: the whole pipeline runs between two launches)"}
 
 
 def main():
     args = parse()
     ranks = Ranks()
-    if args.gpus != ranks.world:
-        if ranks.world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.gpus != ranks.world and ranks.world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import matchering_amd as mg
     from matchering_amd._native import check, library
-    from matchering_amd.device import Device
+    from matchering_amd.device import Device, device_count
     from matchering_amd.synth import make_pair
 
     lib = library()
-    from matchering_amd.device import device_count
-
-    dev = Device(ranks.local % max(1, device_count()))      # one rank per GPU; wraps only when ranks outnumber GPUs
-    cfg = mg.Config(internal_sample_rate=args.sample_rate)
-    native = cfg.to_native()
-    target, reference = make_pair(args.seconds, args.sample_rate, pair=ranks.rank)
-    n, nr = target.shape[0], reference.shape[0]
-    t_dev, r_dev = dev.upload(target), dev.upload(reference)
-    out_a, out_b = dev.alloc(n * 8), dev.alloc(n * 8)
-
-    def step_fir_only():
-        dev.master(t_dev, n, r_dev, nr, native, result=None, result_no_limiter=out_a, want_report=False)
-
-    def step_full():
-        dev.master(t_dev, n, r_dev, nr, native, result=out_b, want_report=False)
-
-    steps = {"8min_fir_only": step_fir_only, "8min_full": step_full}
-    elapsed = timed_steps(ranks, dev, steps[args.workload], args.steps, args.warmup)
-    frames_total = n * args.steps * ranks.world
+    name = args.workload
+    if name == "auto":
+        name = "8min_full" if ranks.world == 1 else "4min_x8_full"
+    wl = Workload(name, ranks.rank, ranks.local, mg, Device, device_count, make_pair)
+    elapsed = timed_steps(ranks, wl.sync, wl.step, args.steps, args.warmup)
+    frames_total = wl.frames * args.steps * ranks.world
     value = frames_total / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
+    model = PIPELINE_BYTES[name]
+    pipeline_gbs = model * wl.frames / (elapsed / args.steps) / 1e9
 
     line = {
         "metric": "stereo Msamples/s mastered (44.1 kHz pairs); % HBM roofline @1/2/4/8 GPU",
         "value": round(value, 2), "unit": "Msamples/s", "n_gpus": ranks.world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {args.seconds:.0f} s stereo {args.sample_rate} Hz pair per GPU, "
-                               f"fft_size {cfg.fft_size}, inputs resident in HBM",
-                   "frames_per_pair": n, "pairs_per_step": ranks.world, "parallelism": f"pairs x{ranks.world}"},
-        "pipeline_hbm_model": {"bytes_per_frame": MODEL_BYTES[args.workload],
-                               "achieved_GBs": round(MODEL_BYTES[args.workload] * n / (elapsed / args.steps) / 1e9, 1),
-                               "frac_of_8TBs": round(MODEL_BYTES[args.workload] * n / (elapsed / args.steps) / 1e9
-                                                     / HBM_PEAK_GBS, 4)},
+        "config": {"workload": wl.describe(), "frames_per_gpu_per_step": wl.frames,
+                   "pairs_per_gpu_per_step": wl.pairs, "parallelism": f"pairs x{ranks.world * wl.pairs}"},
+        "pipeline_hbm_model": {"bytes_per_frame": model, "achieved_GBs": round(pipeline_gbs, 1),
+                               "frac_of_8TBs": round(pipeline_gbs / HBM_PEAK_GBS, 4),
+                               "frac_of_6p29TBs": round(pipeline_gbs / HBM_COPY_GBS, 4)},
     }
 
     # ---- multi-GPU: all-gather the FIR tables over RCCL (off the timed path) ---------------
     if ranks.world > 1:
-        # (never on the timed path; a failing collective is reported in the line, it does not lose the measurement)
+        # (a failing collective is reported in the line, it does not lose the measurement)
         try:
+            dev = wl.dev
             id_buf = ctypes.create_string_buffer(128)
             if ranks.rank == 0:
                 check(lib.mgx_comm_unique_id(id_buf))
@@ -175,107 +252,115 @@ def main():
             ok = bool(np.array_equal(firs[ranks.rank], own)) and bool(np.all(np.isfinite(firs)))
             line["rccl_fir_allgather"] = {"bytes_per_rank": count * 4, "ok": ok}
             check(lib.mgx_comm_destroy(dev.handle))
-
         except Exception as exc:       # noqa: BLE001
             line["rccl_fir_allgather"] = {"ok": False, "error": str(exc)[:200]}
 
     if ranks.rank == 0:
-        # ---- roofline of the dominant kernel (k_conv), HIP events on the kernel's stream ----
-        rng = np.random.RandomState(0)
-        f = cfg.fft_size
-        hm = rng.randn(f) / np.sqrt(f)
-        hs = rng.randn(f) / np.sqrt(f)
-        dp = ctypes.POINTER(ctypes.c_double)
-        ms = ctypes.c_float()
-        mid_plane = dev.alloc(n * 4)
-        for _ in range(2):
-            check(lib.mgx_convolve_timed(dev.handle, ctypes.c_void_p(t_dev.ptr), n, hm.ctypes.data_as(dp),
-                                         hs.ctypes.data_as(dp), f, 1.0, ctypes.c_void_p(out_a.ptr),
-                                         ctypes.c_void_p(mid_plane.ptr), 20, ctypes.byref(ms)))
-        achieved = CONV_BYTES_PER_FRAME * n / (ms.value * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC passes of tools/gpu_pmc.sh (FETCH_SIZE x2 on gfx950 +
-        # WRITE_SIZE), valid for this workload only; rocprofv3 cannot wrap the process it runs in
-        traffic = None
+        # ---- rooflines of the two streaming kernels, timed where they run: inside the pipeline ----
+        stage_ms, n0 = wl.stage_profile(max(5, min(args.steps, 20)))
+        line["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
+        pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path) and args.seconds == 480.0 and args.sample_rate == 44100:
+        if os.path.exists(pmc_path) and name in ("8min_full", "8min_fir_only"):
             with open(pmc_path) as fh:
-                traffic = json.load(fh)["kernels"].get("k_conv<13>", {}).get("hbm_bytes_per_launch")
-        line["roofline"] = {"kernel": "k_conv<13> (overlap-save FIR, B=8192)", "bound": "hbm",
-                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                            "kernel_ms": round(ms.value, 4),
-                            "algorithmic_bytes_per_launch": CONV_BYTES_PER_FRAME * n}
+                pmc = json.load(fh)["stages"]
+        kernels = [k for k in ("convolve", "limit") if k in stage_ms]
+        per = {k: roofline_of(k, stage_ms[k], n0, pmc.get(k, {}).get("hbm_bytes_per_launch")) for k in kernels}
+        # (profiles/pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE of the same workload, one rocprofv3 pass per
+        # counter -- tools/gpu_pmc.sh; rocprofv3 cannot wrap the process it runs in)
+        dominant = max(kernels, key=lambda k: stage_ms[k])
+        line["roofline"] = per[dominant]
+        line["roofline_other"] = [per[k] for k in kernels if k != dominant]
+
         if not args.no_secondary and ranks.world == 1:
-            other = "8min_full" if args.workload == "8min_fir_only" else "8min_fir_only"
-            e2 = timed_steps(ranks, dev, steps[other], args.steps, 1)
-            line["full_pipeline" if other == "8min_full" else "fir_only"] = {
-                "workload": other, "value": round(n * args.steps / e2 / 1e6, 2), "unit": "Msamples/s",
-                "ms_per_step": round(e2 / args.steps * 1e3, 4),
-                "frac_of_8TBs": round(MODEL_BYTES[other] * n / (e2 / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+            side = {}
+            for other in WORKLOADS:
+                if other == name:
+                    continue
+                w2 = Workload(other, 0, ranks.local, mg, Device, device_count, make_pair)
+                e2 = timed_steps(ranks, w2.sync, w2.step, max(3, args.steps // 2), 1)
+                per_step = e2 / max(3, args.steps // 2)
+                side[other] = {"value": round(w2.frames / per_step / 1e6, 2), "unit": "Msamples/s",
+                               "ms_per_step": round(per_step * 1e3, 4),
+                               "frac_of_8TBs": round(PIPELINE_BYTES[other] * w2.frames / per_step / 1e9 / HBM_PEAK_GBS, 4),
+                               "workload": w2.describe()}
+                w2.release()
+            line["other_workloads"] = side
             # host buffers in, host buffers out (PCIe inclusive) -- never the headline value
             from matchering_amd import stages
 
+            target, reference = wl.host_pair
             t0 = time.perf_counter()
-            stages.main(target, reference, cfg, need_default=False, need_no_limiter=True, device=dev)
-            line["pcie_inclusive"] = {"value": round(n / (time.perf_counter() - t0) / 1e6, 2), "unit": "Msamples/s",
-                                      "note": "pageable numpy in/out through stages.main, one pair"}
-            # config #4's share of one GPU: eight four-minute pairs, resident in HBM, submitted round-robin
-            # to two device handles (two HIP streams) so that one pair's short serial kernels overlap
-            # the other's streaming ones -- the batch front end's lanes (matchering_amd/batch.py)
-            if args.seconds == 480.0:
-                lanes = [dev, Device(ranks.local)]
-                half_t, half_r = make_pair(args.seconds / 2, args.sample_rate, pair=100)
-                nb, nrb = half_t.shape[0], half_r.shape[0]
-                bufs = []
-                for k in range(8):
-                    d = lanes[k % 2]
-                    bufs.append((d, d.upload(half_t), d.upload(half_r), d.alloc(nb * 8)))
-
-                def batch_pass(only=None):
-                    for d, tb, rb, ob in bufs:
-                        (only or d).master(tb, nb, rb, nrb, native, result=ob, want_report=False)
-                    for d in lanes:
-                        d.synchronize()
-
-                times = {}
-                for name, only in (("one_lane", dev), ("two_lanes", None)):
-                    batch_pass(only)
-                    t0 = time.perf_counter()
-                    for _ in range(3):
-                        batch_pass(only)
-                    times[name] = (time.perf_counter() - t0) / 3
-                line["batch_8x4min_full"] = {
-                    "value": round(8 * nb / times["two_lanes"] / 1e6, 2), "unit": "Msamples/s",
-                    "ms_per_batch": round(times["two_lanes"] * 1e3, 3),
-                    "one_lane_ms_per_batch": round(times["one_lane"] * 1e3, 3),
-                    "note": "8 four-minute pairs per GPU (config #4's share), full pipeline, two handles"}
-                for d, tb, rb, ob in bufs:
-                    for b in (tb, rb, ob):
-                        b.release()
-                lanes[1].close()
+            stages.main(target, reference, wl.cfg, need_default=wl.want_limiter, need_no_limiter=not wl.want_limiter,
+                        device=wl.dev)
+            line["pcie_inclusive"] = {"value": round(target.shape[0] / (time.perf_counter() - t0) / 1e6, 2),
+                                      "unit": "Msamples/s", "note": "numpy in/out through stages.main, one pair"}
         if not args.no_cpu_baseline and ranks.world == 1:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import mastering_oracle as mo
-
-            ocfg = mo.params(internal_sample_rate=args.sample_rate)
-            need = (False, True, False) if args.workload == "8min_fir_only" else (True, False, False)
-            runs = []
-            t_all = time.perf_counter()
-            while len(runs) < 3 or (time.perf_counter() - t_all < 10.0 and len(runs) < 8):
-                t0 = time.perf_counter()
-                mo.master(target, reference, ocfg, *need)
-                runs.append(time.perf_counter() - t0)
-            cpu_s = min(runs)
-            line["cpu_baseline"] = {"value": round(n / cpu_s / 1e6, 3), "unit": "Msamples/s", "cores": 1,
-                                    "kind": "port", "seconds": round(cpu_s, 2), "runs": len(runs),
-                                    "sample": f"the same {args.seconds:.0f} s pair, best of {len(runs)} runs of "
-                                              f"oracle/mastering_oracle.py (numpy/scipy float64 restatement of "
-                                              f"stages.main, single thread; {sum(runs):.0f} s of CPU work), "
-                                              f"host has {os.cpu_count()} logical cores"}
+            line["cpu_baseline"] = cpu_baseline(wl, name)
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
     if ranks.rank == 0:
         print(json.dumps(line))
     ranks.finish()
+
+
+def _oracle_worker(seconds, sample_rate, fft, need, pair):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mastering_oracle as mo
+    from matchering_amd.synth import make_pair
+
+    target, reference = make_pair(seconds, sample_rate, pair=pair)
+    cfg = mo.params(internal_sample_rate=sample_rate, fft_size=fft)
+    t0 = time.perf_counter()
+    mo.master(target, reference, cfg, *need)
+    return time.perf_counter() - t0, target.shape[0]
+
+
+def cpu_baseline(wl, name):
+    """The numpy/scipy restatement of stages.main (oracle/, test infrastructure) timed on this box's
+    host cores: (i) one process on the workload's own first pair, what a matchering user gets; (ii)
+    BASELINE.md section 3's all-host-cores figure, P concurrent processes of one pair each, on a bounded
+    sample.  ``port_vs_reference`` is the wall-time ratio oracle / unmodified reference measured on the
+    build container (profiles/cpu_port_vs_reference.json; the reference tree does not exist here)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mastering_oracle as mo
+
+    target, reference = wl.host_pair
+    ocfg = mo.params(internal_sample_rate=wl.sample_rate, fft_size=wl.fft)
+    need = (True, False, False) if wl.want_limiter else (False, True, False)
+    runs = []
+    t_all = time.perf_counter()
+    while len(runs) < 2 or (time.perf_counter() - t_all < 12.0 and len(runs) < 6):
+        t0 = time.perf_counter()
+        mo.master(target, reference, ocfg, *need)
+        runs.append(time.perf_counter() - t0)
+    cpu_s = min(runs)
+    n = target.shape[0]
+    out = {"value": round(n / cpu_s / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+           "seconds": round(cpu_s, 2), "runs": len(runs),
+           "sample": f"the workload's first pair ({n} frames), best of {len(runs)} runs of "
+                     f"oracle/mastering_oracle.py (numpy/scipy float64 restatement of stages.main, one thread; "
+                     f"{sum(runs):.0f} s of CPU work); host has {os.cpu_count()} logical cores"}
+    ratio_path = os.path.join(ROOT, "profiles", "cpu_port_vs_reference.json")
+    if os.path.exists(ratio_path):
+        with open(ratio_path) as fh:
+            out["port_vs_reference"] = json.load(fh)
+    try:
+        import concurrent.futures as cf
+
+        procs = max(1, min(os.cpu_count() or 1, 32))
+        sample_seconds = 60.0
+        with cf.ProcessPoolExecutor(max_workers=procs) as pool:
+            done = list(pool.map(_oracle_worker, [sample_seconds] * procs, [wl.sample_rate] * procs, [wl.fft] * procs,
+                                 [need] * procs, range(procs)))
+        slowest = max(d[0] for d in done)
+        out["all_cores"] = {"value": round(sum(d[1] for d in done) / slowest / 1e6, 3), "unit": "Msamples/s",
+                            "processes": procs,
+                            "sample": f"{procs} concurrent processes (of {os.cpu_count()} logical cores), one "
+                                      f"{sample_seconds:.0f} s pair each, frames of all / time of the slowest "
+                                      f"({slowest:.1f} s; each process times its own call of the oracle)"}
+    except Exception as exc:           # noqa: BLE001
+        out["all_cores"] = {"error": str(exc)[:200]}
+    return out
 
 
 if __name__ == "__main__":

@@ -240,7 +240,9 @@ def convolve_same(mid, mid_fir, side, side_fir):
     side, then dsp.py:67-68 ``ms_to_lr``.  Returns (result (N,2), result_mid)."""
     ym = signal.fftconvolve(mid, mid_fir, "same")
     ys = signal.fftconvolve(side, side_fir, "same")
-    return np.stack((ym + ys, ym - ys), axis=1), ym
+    # the reference's memory layout too (np.vstack(...).T: planar, i.e. an F-ordered (N,2) view) -- it is
+    # what the later per-channel reductions of the reference run on, and so what their CPU time depends on
+    return np.vstack((ym + ys, ym - ys)).T, ym
 
 
 # --------------------------------------------------------------------------
@@ -274,7 +276,7 @@ def limiter_envelopes(y, cfg):
                            lim.release_filter_coefficient / lim.release, fs=sr)
     ro = signal.lfilter(b2, a2, np.maximum(sh, ho))          # hyrax.py:68-73
     g_rel = np.maximum(ho, ro)                               # hyrax.py:75
-    gain = 1.0 - np.maximum.reduce((g0, g_att, g_rel))       # hyrax.py:97
+    gain = 1.0 - np.maximum(np.maximum(g0, g_att), g_rel)    # hyrax.py:97 (dsp.py:124-125 max_mix; max is exact in any order)
     return SimpleNamespace(g0=g0, slided=slided, g_att=g_att, held=sh, hold_out=ho,
                            release_out=ro, g_rel=g_rel, gain=gain)
 

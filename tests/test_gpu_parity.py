@@ -68,6 +68,52 @@ def test_master_matches_reference_golden(name, golden, oracle_runs):
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
+def test_fir_and_stage_scalars_match_reference_golden(name, golden):
+    """What flows BETWEEN the stages of stages.main, device values against the values frozen from the
+    unmodified reference: the matching FIR pair (match_frequencies.py:78-101, read back through
+    mgx_last_fir) and every scalar of mgx_report (stages.py:80-91, 149-168, 186-191;
+    match_levels.py:29-44).  An end-to-end comparison alone would let a FIR level error hide
+    behind a compensating gain."""
+    import ctypes
+
+    from matchering_amd._native import check, library
+    from matchering_amd.device import default_device
+
+    g = golden(name)
+    t, r = build_inputs(CASES[name])
+    cfg = make_config(CASES[name]["config"])
+    dev = default_device()
+    with dev.lock:
+        td, rd = dev.upload(t), dev.upload(r)
+        outs = [dev.alloc(t.shape[0] * 8) for _ in range(3)]
+        try:
+            rep = dev.master(td, t.shape[0], rd, r.shape[0], cfg.to_native(), *outs)
+            taps_dev, taps = ctypes.c_void_p(), ctypes.c_int32()
+            check(library().mgx_last_fir(dev.handle, ctypes.byref(taps_dev), ctypes.byref(taps)))
+            assert taps.value == cfg.fft_size
+            fir = dev.download(int(taps_dev.value), (2, taps.value))
+        finally:
+            for b in (td, rd, *outs):
+                b.release()
+    for mine, want in ((fir[0], g["fir_mid"]), (fir[1], g["fir_side"])):
+        assert np.abs(mine - want).max() <= 1e-6 * np.abs(want).max()          # float32 taps: 6e-8 of the peak tap each
+    rel = lambda a, b: abs(a / b - 1.0)                                          # noqa: E731
+    assert rel(rep.rms_coefficient, float(g["rms_coefficient"])) <= 1e-6
+    assert rel(rep.final_amplitude_coefficient, float(g["final_amplitude_coefficient"])) <= 1e-6
+    assert rel(rep.target_match_rms, float(g["target_match_rms"])) <= 1e-6
+    assert rel(rep.reference_match_rms, float(g["reference_match_rms"])) <= 1e-6
+    steps = cfg.rms_correction_steps
+    got = np.array(rep.correction_coefficients[:steps])
+    assert got.shape == g["correction_coefficients"].shape
+    assert np.abs(got / g["correction_coefficients"] - 1.0).max() <= 1e-6
+    assert rel(rep.normalize_coefficient, float(g["normalize_coefficient"])) <= 1e-6
+    assert (rep.target_divisions, rep.reference_divisions) == (int(g["target_divisions"]), int(g["reference_divisions"]))
+    assert (rep.target_piece, rep.reference_piece) == (int(g["target_piece"]), int(g["reference_piece"]))
+    assert (rep.target_loud_count, rep.reference_loud_count) == (int(g["target_loud_count"]), int(g["reference_loud_count"]))
+    assert bool(rep.limiter_active) == bool(g["limiter_active"])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
 def test_analysis_stage(name, oracle_runs):
     from matchering_amd import kernels
 

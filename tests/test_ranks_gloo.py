@@ -33,13 +33,9 @@ def _worker(rank, world, port, queue):
     try:
         assert ranks.rank == rank and ranks.world == world
 
-        class FakeDevice:                       # stands in for the HIP stream synchronisation
-            def synchronize(self):
-                pass
-
-        calls = []
-        elapsed = bench.timed_steps(ranks, FakeDevice(), lambda: calls.append(1), steps=3, warmup=2)
-        assert len(calls) == 5 and elapsed >= 0.0
+        calls, syncs = [], []                   # the second argument stands in for the HIP stream synchronisation
+        elapsed = bench.timed_steps(ranks, lambda: syncs.append(1), lambda: calls.append(1), steps=3, warmup=2)
+        assert len(calls) == 5 and len(syncs) == 2 and elapsed >= 0.0
         slow = ranks.max(10.0 + rank)           # the job's time is the slowest rank's
         payload = bytes(range(128)) if rank == 0 else bytes(128)
         uid = ranks.broadcast_bytes(payload, 128)
