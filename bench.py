@@ -263,7 +263,7 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path) and name in ("8min_full", "8min_fir_only"):
             with open(pmc_path) as fh:
-                pmc = json.load(fh)["stages"]
+                pmc = json.load(fh).get("stages", {})
         kernels = [k for k in ("convolve", "limit") if k in stage_ms]
         per = {k: roofline_of(k, stage_ms[k], n0, pmc.get(k, {}).get("hbm_bytes_per_launch")) for k in kernels}
         # (profiles/pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE of the same workload, one rocprofv3 pass per

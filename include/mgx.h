@@ -159,15 +159,15 @@ int mgx_scale(mgx_handle* h, const float* x_dev, int64_t n, double gain, float* 
  * stages.py:210-272 with `convolve` (match_frequencies.py:104-119) and the limiter
  * (hyrax.py:78-99) on their own, since each is a single kernel launch. */
 enum mgx_stage {
-    MGX_STAGE_ANALYZE_TARGET = 0,   /* match_levels.py:134-161 + match_frequencies.py:30-42, target */
-    MGX_STAGE_ANALYZE_REFERENCE = 1,
-    MGX_STAGE_DESIGN_FIR = 2,       /* match_levels.py:62-71, match_frequencies.py:45-101 */
-    MGX_STAGE_FILTER_SPECTRA = 3,   /* transforms of the FIR pair the convolution multiplies by */
-    MGX_STAGE_CONVOLVE = 4,         /* match_frequencies.py:104-119: ONE launch of k_conv */
-    MGX_STAGE_CORRECT_LEVELS = 5,   /* stages.py:138-170 */
-    MGX_STAGE_SCALE_OUTPUTS = 6,    /* stages.py:185-191 */
-    MGX_STAGE_LIMIT = 7,            /* hyrax.py:78-99: ONE launch of the limiter kernel */
-    MGX_STAGE_COUNT = 8
+    MGX_STAGE_ANALYZE = 0,          /* match_levels.py:134-161 + match_frequencies.py:30-42, target AND
+                                       reference: ONE launch of k_analyze */
+    MGX_STAGE_DESIGN_FIR = 1,       /* match_levels.py:62-71, match_frequencies.py:45-101 */
+    MGX_STAGE_FILTER_SPECTRA = 2,   /* transforms of the FIR pair the convolution multiplies by */
+    MGX_STAGE_CONVOLVE = 3,         /* match_frequencies.py:104-119: ONE launch of k_conv */
+    MGX_STAGE_CORRECT_LEVELS = 4,   /* stages.py:138-170 */
+    MGX_STAGE_SCALE_OUTPUTS = 5,    /* stages.py:185-191 */
+    MGX_STAGE_LIMIT = 6,            /* hyrax.py:78-99: ONE launch of the limiter kernel */
+    MGX_STAGE_COUNT = 7
 };
 int mgx_stage_timing(mgx_handle* h, int32_t enable);
 int mgx_stage_times(mgx_handle* h, float* ms /* [MGX_STAGE_COUNT] */);

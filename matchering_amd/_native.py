@@ -107,8 +107,7 @@ SYMBOLS = {
 
 
 # enum mgx_stage (include/mgx.h), in order
-STAGES = ("analyze_target", "analyze_reference", "design_fir", "filter_spectra", "convolve", "correct_levels",
-          "scale_outputs", "limit")
+STAGES = ("analyze", "design_fir", "filter_spectra", "convolve", "correct_levels", "scale_outputs", "limit")
 
 
 class MgxError(RuntimeError):

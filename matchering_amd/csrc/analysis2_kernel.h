@@ -37,8 +37,7 @@ struct AnalysisArgs {
     long long piece;        // p
     int divisions;          // D
     int segs_per_piece;     // q = p // F
-    int segs_per_wg;        // SEGS
-    int chunks_per_piece;   // ceil(q / SEGS)
+    int chunks_per_piece;   // workgroups per piece: chunk c takes segments [c*q/C, (c+1)*q/C)
     // outputs, one slot per workgroup
     double* wg_sumsq;       // sum of mid^2 over the frames this workgroup owns
     float* wg_peak;         // max(|L|,|R|) over the frames this workgroup owns
@@ -67,6 +66,12 @@ struct Analysis2Block {
     };
 
     static MGX_HD bool active0(int tid) { return !F::partial(0) || tid < F::NB(0); }
+
+    // segments of chunk `ch` of a piece: the q segments are dealt out as evenly as integers allow
+    static MGX_HD void chunk_segments(const AnalysisArgs& a, int ch, int& s0, int& s1) {
+        s0 = (int)((long long)ch * a.segs_per_piece / a.chunks_per_piece);
+        s1 = (int)((long long)(ch + 1) * a.segs_per_piece / a.chunks_per_piece);
+    }
 
     static MGX_HD void load_persist(int tid, const float2* tw, float2* mid_table, Persist& ps) {
         F::load_tw0(tid, tw, ps.tw0);

@@ -78,7 +78,7 @@ struct mgx_handle {
     std::map<int, float2*> twiddles;
     TrackWork track[2];
     DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars, conv_queue;
-    DevBuf lim_published, lim_ctrl, lim_weights, round_ctr, band, band_info;
+    DevBuf lim_published, lim_ctrl, lim_weights, round_ctr, tail_gains, band, band_info;
     std::vector<double> lim_weights_host;
     DevBuf fir_scratch;
     std::map<const FirPlanHost*, PlanDev> plan_dev;               // uploaded plan blobs + dense operators
@@ -179,7 +179,7 @@ static int check_config(const mgx_config* c) {
     if (c->fft_size < 64 || c->fft_size > 16384)
         return fail(MGX_ERR_UNSUPPORTED, "fft_size outside [64, 16384] is not implemented "
                                          "(one analysis segment must fit one CU's LDS)");
-    if (c->rms_correction_steps < 0 || c->rms_correction_steps > 16)
+    if (c->rms_correction_steps < 0 || c->rms_correction_steps > 16)   /* CorrectionState::coeffs, the gain words */
         return fail(MGX_ERR_UNSUPPORTED, "rms_correction_steps outside [0, 16]");
     if (c->lowess_it != 0) return fail(MGX_ERR_UNSUPPORTED, "lowess_it != 0 is not implemented");
     if (!(c->threshold > c->min_value && c->threshold < 1.0 && c->min_value > 0.0))
@@ -215,75 +215,101 @@ static int analysis_workgroups_per_cu(int log2f) {
 }
 
 template <int LOG2N>
-static int launch_analysis(mgx_handle* h, const AnalysisArgs& a, int nwg) {
+static int launch_analysis(mgx_handle* h, const AnalysisArgs& a0, const AnalysisArgs& a1, int nwg0, int nwg) {
     const size_t lds = analysis_lds_bytes<LOG2N>();
     MGX_TRY(allow_lds(k_analyze<LOG2N>, lds));
-    hipLaunchKernelGGL(k_analyze<LOG2N>, dim3(nwg), dim3(Fft2<LOG2N>::T), lds, h->stream, a);
+    hipLaunchKernelGGL(k_analyze<LOG2N>, dim3(nwg), dim3(Fft2<LOG2N>::T), lds, h->stream, a0, a1, nwg0);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-static int run_analysis(mgx_handle* h, const float* x, long long n, const mgx_config* cfg, int is_reference,
-                        TrackWork& w) {
-    const int f = cfg->fft_size, half = f / 2;
+// geometry of a track's analysis (match_levels.py:47-59) and the workspace it fills; chunks per piece
+// are chosen by the caller (they depend on what shares the launch)
+static int plan_analysis(mgx_handle* h, long long n, const mgx_config* cfg, int is_reference, TrackWork& w) {
+    const int f = cfg->fft_size;
     if (n <= f) return fail(MGX_ERR_ARGUMENT, "track must be longer than fft_size frames (core.py:69-74)");
     MGX_TRY(check_length(n));
     piece_geometry(n, cfg->max_piece_size, w.divisions, w.piece);
     w.segs_per_piece = (int)(w.piece / f);
     if (w.segs_per_piece < 1)
         return fail(MGX_ERR_UNSUPPORTED, "analysis pieces shorter than fft_size are not implemented");
-    // One workgroup per resident slot at most: a second dispatch wave of a few stragglers would double
-    // the kernel's duration (every workgroup runs segs_per_wg segments back to back).
+    w.is_reference = is_reference;
+    return 0;
+}
+
+// Every workgroup runs its segments back to back and a CU's residents share its throughput, so the
+// kernel lasts about as long as the busiest CU has segments: ceil(workgroups / CUs) * segments per
+// workgroup.  Pick the segments per workgroup that minimise it over ALL tracks of the launch (ties:
+// more workgroups); a second dispatch wave of a few stragglers would double the kernel's duration.
+static int choose_chunks(mgx_handle* h, const mgx_config* cfg, TrackWork* const* tracks, int count) {
     int dev_cus = 256;
     HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device));
-    // Every workgroup runs segs_per_wg segments back to back and a CU's residents share its
-    // throughput, so the kernel lasts about as long as the busiest CU has segments: ceil(workgroups /
-    // CUs) * segs_per_wg.  Pick the segments per workgroup that minimise it (ties: more workgroups).
-    const int per_cu = analysis_workgroups_per_cu(ilog2_exact(f));
+    const int per_cu = analysis_workgroups_per_cu(ilog2_exact(cfg->fft_size));
+    int longest = 1;
+    for (int t = 0; t < count; ++t) longest = std::max(longest, tracks[t]->segs_per_piece);
     long long best_cost = -1;
-    for (int s = 1; s <= w.segs_per_piece; ++s) {
-        const int chunks = (w.segs_per_piece + s - 1) / s;
-        const long long wgs = (long long)w.divisions * chunks;
+    int best_s = longest;
+    for (int s = 1; s <= longest; ++s) {
+        long long wgs = 0;
+        for (int t = 0; t < count; ++t)
+            wgs += (long long)tracks[t]->divisions * ((tracks[t]->segs_per_piece + s - 1) / s);
         const long long deep = (wgs + dev_cus - 1) / dev_cus;
         if (deep > per_cu) continue;
         const long long cost = deep * s;
         if (best_cost < 0 || cost < best_cost) {
             best_cost = cost;
-            w.segs_per_wg = s;
+            best_s = s;
         }
     }
-    if (best_cost < 0) w.segs_per_wg = w.segs_per_piece;     // more pieces than resident slots
-    w.chunks = (w.segs_per_piece + w.segs_per_wg - 1) / w.segs_per_wg;
-    const int nwg = w.divisions * w.chunks;
-    MGX_TRY(ensure(h, w.wg_sumsq, (size_t)nwg * sizeof(double)));
-    MGX_TRY(ensure(h, w.wg_peak, (size_t)nwg * sizeof(float)));
-    MGX_TRY(ensure(h, w.wg_spec, (size_t)nwg * 2 * (half + 1) * sizeof(float)));
-    MGX_TRY(ensure(h, w.stats, sizeof(TrackStats)));
-    MGX_TRY(ensure(h, w.rms, (size_t)w.divisions * sizeof(double)));
-    MGX_TRY(ensure(h, w.loud, (size_t)w.divisions * sizeof(int)));
-    MGX_TRY(ensure(h, w.avg, (size_t)2 * (half + 1) * sizeof(double)));
-    AnalysisArgs a;
+    for (int t = 0; t < count; ++t) {
+        TrackWork& w = *tracks[t];
+        w.chunks = (w.segs_per_piece + best_s - 1) / best_s;
+        w.nwg = w.divisions * w.chunks;
+        const int half = cfg->fft_size / 2;
+        MGX_TRY(ensure(h, w.wg_sumsq, (size_t)w.nwg * sizeof(double)));
+        MGX_TRY(ensure(h, w.wg_peak, (size_t)w.nwg * sizeof(float)));
+        MGX_TRY(ensure(h, w.wg_spec, (size_t)w.nwg * 2 * (half + 1) * sizeof(float)));
+        MGX_TRY(ensure(h, w.stats, sizeof(TrackStats)));
+        MGX_TRY(ensure(h, w.rms, (size_t)w.divisions * sizeof(double)));
+        MGX_TRY(ensure(h, w.loud, (size_t)w.divisions * sizeof(int)));
+        MGX_TRY(ensure(h, w.avg, (size_t)2 * (half + 1) * sizeof(double)));
+    }
+    return 0;
+}
+
+static int analysis_args(mgx_handle* h, const float* x, long long n, const mgx_config* cfg, const TrackWork& w,
+                         AnalysisArgs& a) {
     a.x = reinterpret_cast<const float2*>(x);
     a.n = n;
-    a.fft = f;
+    a.fft = cfg->fft_size;
     a.piece = w.piece;
     a.divisions = w.divisions;
     a.segs_per_piece = w.segs_per_piece;
-    a.segs_per_wg = w.segs_per_wg;
     a.chunks_per_piece = w.chunks;
     a.wg_sumsq = (double*)w.wg_sumsq.p;
     a.wg_peak = (float*)w.wg_peak.p;
     a.wg_spec = (float*)w.wg_spec.p;
-    const int l = ilog2_exact(f);
-    MGX_TRY(get_twiddles(h, l, &a.tw));
-    switch (l) {
-#define CASE(L) case L: MGX_TRY(launch_analysis<L>(h, a, nwg)); break;
+    return get_twiddles(h, ilog2_exact(cfg->fft_size), &a.tw);
+}
+
+// one launch for one track (second == nullptr) or for the target and the reference of a pair
+static int run_analysis(mgx_handle* h, const mgx_config* cfg, const float* x0, long long n0, TrackWork& w0,
+                        const float* x1 = nullptr, long long n1 = 0, TrackWork* w1 = nullptr) {
+    MGX_TRY(plan_analysis(h, n0, cfg, w0.is_reference, w0));
+    if (w1) MGX_TRY(plan_analysis(h, n1, cfg, w1->is_reference, *w1));
+    TrackWork* tracks[2] = {&w0, w1};
+    MGX_TRY(choose_chunks(h, cfg, tracks, w1 ? 2 : 1));
+    AnalysisArgs a0, a1;
+    MGX_TRY(analysis_args(h, x0, n0, cfg, w0, a0));
+    a1 = a0;
+    if (w1) MGX_TRY(analysis_args(h, x1, n1, cfg, *w1, a1));
+    const int nwg = w0.nwg + (w1 ? w1->nwg : 0);
+    switch (ilog2_exact(cfg->fft_size)) {
+#define CASE(L) case L: MGX_TRY(launch_analysis<L>(h, a0, a1, w0.nwg, nwg)); break;
         CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return fail(MGX_ERR_UNSUPPORTED, "fft_size not supported by the analysis kernel");
     }
-    w.nwg = nwg;
-    w.is_reference = is_reference;
     return 0;
 }
 
@@ -388,22 +414,33 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     double* scratch = (double*)h->fir_scratch.p;
     double* raw = scratch + 2 * per;
     MGX_TRY(ensure(h, h->cstate, sizeof(CorrectionState)));
-    hipLaunchKernelGGL(k_fir_raw, dim3((pl.bins + 255) / 256, 2), dim3(256), 0, h->stream, pl, in, raw,
-                       (double*)h->scalars.p, (CorrectionState*)h->cstate.p);
+    // piece decisions of both tracks, loud-piece spectra and the raw curve: one launch while the piece
+    // tables fit a workgroup's LDS (always, short of thousands of pieces), three otherwise
+    const int max_div = std::max(tw.divisions, rw.divisions);
+    const size_t lds_curve = match_curve_lds_bytes(max_div, tw.nwg + rw.nwg);
+    if (lds_curve <= (size_t)150 * 1024) {
+        CurveTrack ct{levels_args(tw), (const float*)tw.wg_spec.p, tw.nwg, tw.segs_per_piece};
+        CurveTrack cr{levels_args(rw), (const float*)rw.wg_spec.p, rw.nwg, rw.segs_per_piece};
+        MGX_TRY(allow_lds(k_match_curve, lds_curve));
+        hipLaunchKernelGGL(k_match_curve, dim3((pl.bins + 31) / 32, 2), dim3(1024), lds_curve, h->stream, ct, cr, pl.bins,
+                           pl.fft, max_div, cfg->threshold, cfg->min_value, pl.min_value, raw, (double*)h->scalars.p,
+                           (CorrectionState*)h->cstate.p);
+    } else {
+        TrackWork& t = const_cast<TrackWork&>(tw);
+        TrackWork& r = const_cast<TrackWork&>(rw);
+        MGX_TRY(run_levels(h, cfg, &t, &r));
+        in.part_t = (const double*)tw.part.p;
+        in.part_r = (const double*)rw.part.p;
+        hipLaunchKernelGGL(k_fir_raw, dim3((pl.bins + 255) / 256, 2), dim3(256), 0, h->stream, pl, in, raw,
+                           (double*)h->scalars.p, (CorrectionState*)h->cstate.p);
+    }
     hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
                        (const int2*)pd.band, (const double*)raw, scratch);
-    // the cosine table rides in LDS when it fits (F <= 8192), otherwise it is read through L2
-    const bool cos_in_lds = ((size_t)pl.fft + pl.bins + 1024) * sizeof(double) <= (size_t)150 * 1024;
-    const size_t lds_taps = ((cos_in_lds ? (size_t)pl.fft : 0) + pl.bins + 1024) * sizeof(double);
-    if (cos_in_lds) {
-        MGX_TRY(allow_lds(k_fir_taps<true>, lds_taps));
-        hipLaunchKernelGGL(k_fir_taps<true>, dim3(pl.fft / TAPS_PER_WG, 2), dim3(1024), lds_taps, h->stream, pl,
-                           (const double*)scratch, (float*)h->taps.p);
-    } else {
-        MGX_TRY(allow_lds(k_fir_taps<false>, lds_taps));
-        hipLaunchKernelGGL(k_fir_taps<false>, dim3(pl.fft / TAPS_PER_WG, 2), dim3(1024), lds_taps, h->stream, pl,
-                           (const double*)scratch, (float*)h->taps.p);
-    }
+    const size_t lds_taps = ((size_t)pl.bins + 1024) * sizeof(double);
+    if (pl.fft < TAPS_PER_WG) return fail(MGX_ERR_UNSUPPORTED, "fft_size below 64 is not implemented");
+    MGX_TRY(allow_lds(k_fir_taps, lds_taps));
+    hipLaunchKernelGGL(k_fir_taps, dim3(pl.fft / TAPS_PER_WG, 2), dim3(1024), lds_taps, h->stream, pl,
+                       (const double*)scratch, (float*)h->taps.p);
     HIP_TRY(hipGetLastError());
     h->last_taps = cfg->fft_size;
     return 0;
@@ -629,7 +666,7 @@ static int check_limiter_error(mgx_handle* h) {
     HIP_TRY(hipMemcpy(flags, h->lim_ctrl.p, sizeof(flags), hipMemcpyDeviceToHost));
     if (flags[1] != 0) {
         HIP_TRY(hipMemset((int*)h->lim_ctrl.p + 1, 0, 4));
-        return fail(MGX_ERR_HIP, "limiter look-back timed out waiting for a predecessor chunk");
+        return fail(MGX_ERR_HIP, "a bounded device-side wait expired (limiter look-back or level-correction round)");
     }
     return 0;
 }
@@ -700,7 +737,7 @@ int mgx_destroy(mgx_handle* h) {
     hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
-                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch, &h->round_ctr, &h->band, &h->band_info,
+                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info,
                       &h->conv_queue};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -777,7 +814,8 @@ int mgx_analyze(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* 
     MGX_TRY(check_config(cfg));
     HIP_TRY(hipSetDevice(h->device));
     TrackWork& w = h->track[is_reference ? 1 : 0];
-    MGX_TRY(run_analysis(h, x_dev, n, cfg, is_reference, w));
+    w.is_reference = is_reference;
+    MGX_TRY(run_analysis(h, cfg, x_dev, n, w));
     MGX_TRY(run_levels(h, cfg, &w, nullptr));
     {
         const int total = 2 * (cfg->fft_size / 2 + 1);
@@ -924,18 +962,15 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     // (analysing the reference first, so that the target is the fresher track in the Infinity Cache when
     // the convolution reads it, was measured: no difference)
     {
-        StageScope scope(h, MGX_STAGE_ANALYZE_TARGET);
-        MGX_TRY(run_analysis(h, target_dev, n_target, cfg, 0, tw));
-    }
-    {
-        StageScope scope(h, MGX_STAGE_ANALYZE_REFERENCE);
-        MGX_TRY(run_analysis(h, reference_dev, n_reference, cfg, 1, rw));
+        StageScope scope(h, MGX_STAGE_ANALYZE);
+        tw.is_reference = 0;
+        rw.is_reference = 1;
+        MGX_TRY(run_analysis(h, cfg, target_dev, n_target, tw, reference_dev, n_reference, &rw));
     }
     // stage 2 (stages.py:107-135): FIR design on the device, then the overlap-save convolution with
     // the level gain of stages.py:80-88 (a device scalar) folded into the filter spectra
     {
         StageScope scope(h, MGX_STAGE_DESIGN_FIR);
-        MGX_TRY(run_levels(h, cfg, &tw, &rw));
         MGX_TRY(run_fir_design(h, cfg, tw, rw));
     }
     MGX_TRY(ensure(h, h->y, (size_t)n_target * sizeof(float2)));
@@ -956,7 +991,11 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         ra.chunks = std::max(1, 1024 / tw.divisions);        // ~1000 workgroups: each pays one publish + ticket
         MGX_TRY(ensure(h, h->partial, (size_t)ra.divisions * ra.chunks * sizeof(double)));
         ra.partial = (double*)h->partial.p;
+        // arrival counters [1 + divisions], zero between launches; the 16 gain words of k_correction_tail
+        // live in their own buffer (a layout that moved with `divisions` would leave one call's preset
+        // gain words where the next call counts arrivals)
         const size_t ctr_bytes = (size_t)(1 + ra.divisions) * sizeof(unsigned);
+        MGX_TRY(ensure(h, h->tail_gains, 16 * sizeof(unsigned long long)));
         if (h->round_ctr.bytes < ctr_bytes) {                 // zeroed when (re)allocated, reset by each launch
             MGX_TRY(ensure(h, h->round_ctr, std::max(ctr_bytes, (size_t)4096)));
             HIP_TRY(hipMemsetAsync(h->round_ctr.p, 0, h->round_ctr.bytes, h->stream));
@@ -972,19 +1011,46 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         ra.threshold = cfg->threshold;
         ra.cs = cs;
         ra.npeaks = nblocks;
+        MGX_TRY(ensure_ctrl(h));
+        ra.error = (int*)h->lim_ctrl.p + 1;
         const size_t lds_step = (size_t)(64 + tw.divisions + (size_t)ra.divisions * ra.chunks) * sizeof(double);
+        if (lds_step > (size_t)150 * 1024)
+            return fail(MGX_ERR_UNSUPPORTED, "too many analysis pieces for the level-correction kernel's LDS");
+        MGX_TRY(allow_lds(k_correction_round, lds_step));
         const int rounds = cfg->rms_correction_steps;
         ra.lim_published = nullptr;
         ra.lim_words = 0;
         ra.lim_ticket = nullptr;
-        for (int step = 0; step < rounds; ++step) {
-            ra.final_peaks = step == rounds - 1 ? (const float*)h->block_peak.p : nullptr;
-            if (result_dev && step == rounds - 1) {
-                MGX_TRY(limiter_state(h, n_target, cfg, &ra.lim_published, &ra.lim_words, &ra.lim_ticket));
+        ra.tail_gains = rounds > 1 ? (unsigned long long*)h->tail_gains.p : nullptr;
+        auto with_final = [&](RoundArgs& r) -> int {          // the launch that runs the last round
+            r.final_peaks = (const float*)h->block_peak.p;
+            if (result_dev) {
+                MGX_TRY(limiter_state(h, n_target, cfg, &r.lim_published, &r.lim_words, &r.lim_ticket));
                 limiter_preset = true;
             }
-            ra.build_band = step == 0 ? 1 : 0;
-            hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, ra);
+            return 0;
+        };
+        if (rounds >= 1) {                                    // round 0 streams the mid plane and builds the band lists
+            RoundArgs r0 = ra;
+            r0.final_peaks = nullptr;
+            r0.build_band = 1;
+            r0.step = 0;
+            if (rounds == 1) MGX_TRY(with_final(r0));
+            hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, r0);
+        }
+        if (rounds > 1) {                                     // every further round inside one small resident grid
+            RoundArgs rt = ra;
+            rt.build_band = 0;
+            rt.step = 1;
+            MGX_TRY(with_final(rt));
+            // at most ~128 workgroups, at most 64 chunks (the lanes of a wave) per workgroup
+            const int groups = std::max((ra.chunks + 63) / 64, std::max(1, std::min(ra.chunks, 128 / ra.divisions)));
+            const size_t lds_tail = correction_tail_lds_bytes(ra.divisions, groups);
+            if (lds_tail > (size_t)150 * 1024)
+                return fail(MGX_ERR_UNSUPPORTED, "too many analysis pieces for the level-correction kernel's LDS");
+            MGX_TRY(allow_lds(k_correction_tail, lds_tail));
+            hipLaunchKernelGGL(k_correction_tail, dim3(ra.divisions * groups), dim3(256), lds_tail, h->stream, rt, groups,
+                               rounds - 1);
         }
         if (rounds == 0)
             hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, h->stream, (const float*)h->block_peak.p,
@@ -1018,7 +1084,7 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         HIP_TRY(hipMemcpyAsync(hc, cs, sizeof(CorrectionState), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(c0, h->scalars.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (result_dev) MGX_TRY(check_limiter_error(h));
+        MGX_TRY(check_limiter_error(h));
         std::memset(report, 0, sizeof(*report));
         report->final_amplitude_coefficient = st_r->amplitude_c;
         report->target_match_rms = st_t->match_rms;

@@ -304,9 +304,6 @@ constexpr size_t analysis_lds_bytes() {
 #ifndef MGX_ANALYZE_MAX_WGS
 #define MGX_ANALYZE_MAX_WGS 8          // experiments: cap the workgroups per CU (more registers each)
 #endif
-#ifndef MGX_ANALYZE_PREFETCH
-#define MGX_ANALYZE_PREFETCH 0
-#endif
 template <int LOG2N>
 constexpr int analysis_waves_per_simd() {
     constexpr int by_lds = (int)((size_t)160 * 1024 / analysis_lds_bytes<LOG2N>());
@@ -315,8 +312,11 @@ constexpr int analysis_waves_per_simd() {
     return w < 1 ? 1 : (w > 8 ? 8 : w);
 }
 
+// One grid for one or two tracks: workgroups [0, nwg0) belong to `a0`, the rest to `a1` (target and
+// reference of a pair in ONE launch: no boundary and no half-empty chip between the two passes).
 template <int LOG2N>
-__global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) void k_analyze(AnalysisArgs a) {
+__global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) void k_analyze(AnalysisArgs a0, AnalysisArgs a1,
+                                                                                             int nwg0) {
     using AB = Analysis2Block<LOG2N>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
@@ -324,29 +324,22 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
     float2* mid_table = lds + F::LDS_ELEMS;
     double* dscratch = reinterpret_cast<double*>(mid_table + F::MID_TABLE);
     float* fscratch = reinterpret_cast<float*>(dscratch + 8);
-    const int tid = threadIdx.x, wg = blockIdx.x;
+    const bool second = (int)blockIdx.x >= nwg0;                 // uniform
+    const AnalysisArgs& a = second ? a1 : a0;
+    const int tid = threadIdx.x, wg = second ? blockIdx.x - nwg0 : blockIdx.x;
     const int d = wg / a.chunks_per_piece, ch = wg % a.chunks_per_piece;
     typename AB::Thread th;
     AB::init(th);
     typename AB::Persist ps;
     AB::load_persist(tid, a.tw, mid_table, ps);
     __syncthreads();
-    const int s0 = ch * a.segs_per_wg;
-    const int s1 = min(a.segs_per_piece, s0 + a.segs_per_wg);
-#if MGX_ANALYZE_PREFETCH
-    typename AB::Raw ahead;
-    if (s0 < s1) AB::fetch(tid, (long long)d * a.piece + (long long)s0 * F::N, a, ahead);
-#endif
+    int s0, s1;
+    AB::chunk_segments(a, ch, s0, s1);
     for (int s = s0; s < s1; ++s) {
         // (a software prefetch of the next segment was tried: at 128 VGPRs the 32 registers it pins
         // spill, which stalls on the very loads it was meant to hide)
         typename AB::Raw raw;
-#if MGX_ANALYZE_PREFETCH
-        raw = ahead;
-        if (s + 1 < s1) AB::fetch(tid, (long long)d * a.piece + (long long)(s + 1) * F::N, a, ahead);
-#else
         AB::fetch(tid, (long long)d * a.piece + (long long)s * F::N, a, raw);
-#endif
         AB::phase_load(tid, raw, ps, th, lds);
         lds_barrier();
         if (F::P == 3) {
@@ -604,6 +597,171 @@ __global__ __launch_bounds__(256) void k_fir_raw(FirPlanView pl, FirInputs in, d
     const double ar = spectrum_at(in.part_r, plane, pl.bins, k) * sc_r;
     raw[(size_t)plane * pl.bins + k] = ar / fmax(pl.min_value, at);
 }
+// The piece decisions of match_levels.py:62-71,93-103 by ONE wave, without a barrier: sums[d] = sum of
+// mid^2 of piece d (LDS); every lane returns the same average rms, match rms and loud count, and the loud
+// flags go to `loud_out` (LDS).  Lane-strided loops and butterfly sums: a fixed order.
+__device__ __forceinline__ void wave_decide(const double* sums, int divisions, long long piece, double inv_c,
+                                            double* rms_out, int* loud_out, double& avg, double& match, int& count) {
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int d = lane; d < divisions; d += 64) {
+        const double r = sqrt(sums[d] / (double)piece) * inv_c;
+        acc += r * r;
+    }
+    avg = sqrt(wave_sum(acc) / divisions);
+    double lacc = 0.0, lcnt = 0.0;
+    for (int d = lane; d < divisions; d += 64) {
+        const double r = sqrt(sums[d] / (double)piece) * inv_c;
+        const bool l = r >= avg;
+        if (l) { lacc += r * r; lcnt += 1.0; }
+        if (rms_out) rms_out[d] = r;
+        if (loud_out) loud_out[d] = l ? 1 : 0;
+    }
+    const double cnt = wave_sum(lcnt);
+    count = (int)cnt;
+    match = sqrt(wave_sum(lacc) / cnt);
+}
+
+// ---- levels + loud-piece spectra + raw matching curve in ONE launch --------------------------------
+// k_levels -> k_average_spectra -> k_fir_raw are three dependent launches of a few microseconds of
+// work each; here every workgroup re-derives the (tiny) piece decisions of both tracks in its own LDS
+// (one batch of loads, the two tracks decided side by side by one wave each), sums its tile of bins
+// over the loud workgroup rows of both tracks and writes the raw curve (match_frequencies.py:93-94)
+// directly.  Grid (bin tiles of 32, 2 planes) x 1024 threads = 32 bins x 32 row lanes; every sum runs in
+// a fixed order.  Workgroup (0, 0) also leaves the TrackStats, the piece tables, the level gain c0
+// (stages.py:80-88) and the reset correction state.
+struct CurveTrack {
+    LevelsArgs lv;
+    const float* wg_spec;        // [nwg][2][bins]
+    int nwg, segs_per_piece;
+};
+// LDS carve, in doubles: acc[1024] | scal[16] | sums[2][max_div] | ss[nwg_t + nwg_r] ; then ints loud[2][max_div]
+// and floats pk[nwg_t + nwg_r]
+__host__ __device__ inline size_t match_curve_lds_bytes(int max_div, int rows) {
+    return ((size_t)1024 + 16 + 2 * (size_t)max_div + rows) * 8 + (2 * (size_t)max_div + rows + 4) * 4;
+}
+__global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack tr, int bins, int fft, int max_div,
+                                                      double threshold, double eps, double curve_floor,
+                                                      double* raw /* [2][bins] */, double* c0_out,
+                                                      CorrectionState* cs_init) {
+    MGX_LDS;
+    const int rows = tt.nwg + tr.nwg;
+    double* acc = reinterpret_cast<double*>(mgx_smem);
+    double* scal = acc + 1024;                                  // [k*4 + {amplitude_c, match, count, -}]
+    double* sums = scal + 16;                                   // [2][max_div]
+    double* ss = sums + 2 * max_div;                            // [rows] piece-chunk sums of mid^2, target rows first
+    int* loud = reinterpret_cast<int*>(ss + rows);              // [2][max_div]
+    float* pk = reinterpret_cast<float*>(loud + 2 * max_div);   // [rows]
+    const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int w = threadIdx.x; w < rows; w += 1024) {
+        const bool second = w >= tt.nwg;
+        const LevelsArgs& t = second ? tr.lv : tt.lv;
+        const int i = second ? w - tt.nwg : w;
+        ss[w] = t.wg_sumsq[i];
+        pk[w] = t.wg_peak[i];
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < tt.lv.divisions + tr.lv.divisions; p += 1024) {
+        const bool second = p >= tt.lv.divisions;
+        const LevelsArgs& t = second ? tr.lv : tt.lv;
+        const int d = second ? p - tt.lv.divisions : p;
+        const double* src = ss + (second ? tt.nwg : 0) + (size_t)d * t.chunks_per_piece;
+        double sum = 0.0;
+        for (int ch = 0; ch < t.chunks_per_piece; ++ch) sum += src[ch];
+        sums[(second ? max_div : 0) + d] = sum;
+    }
+    __syncthreads();
+    if (wave < 2) {                                             // wave 0: target, wave 1: reference
+        const int k = wave;
+        const LevelsArgs& t = k == 0 ? tt.lv : tr.lv;
+        const float* p = pk + (k == 0 ? 0 : tt.nwg);
+        float m = 0.f;
+        for (int w = lane; w < (k == 0 ? tt.nwg : tr.nwg); w += 64) m = fmaxf(m, p[w]);
+        const double peak = (double)wave_max(m);
+        double c = 1.0;
+        if (t.is_reference && peak < threshold) c = fmax(eps, peak / threshold);     // dsp.py:98-99
+        double avg, match;
+        int count;
+        wave_decide(sums + k * max_div, t.divisions, t.piece, 1.0 / c, writer ? t.rms : nullptr, loud + k * max_div, avg,
+                    match, count);
+        if (lane == 0) {
+            scal[k * 4 + 0] = c;
+            scal[k * 4 + 1] = match;
+            scal[k * 4 + 2] = (double)count;
+        }
+        if (writer) {
+            for (int d = lane; d < t.divisions; d += 64) t.loud[d] = loud[k * max_div + d];
+            if (lane == 0) {
+                TrackStats st;
+                st.peak = peak;
+                st.amplitude_c = c;
+                st.average_rms = avg;
+                st.match_rms = match;
+                st.divisions = t.divisions;
+                st.loud_count = count;
+                st.piece = t.piece;
+                *t.st = st;
+            }
+        }
+    }
+    __syncthreads();
+    const double c0 = scal[4 + 1] / fmax(eps, scal[1]);         // match_levels.py:106-111
+    if (writer && threadIdx.x == 0) {
+        *c0_out = c0;
+        if (cs_init) correction_reset(cs_init, 1.0);            // stages.py:138-170 starts from gain 1
+    }
+    const int b = threadIdx.x & 31, row_lane = threadIdx.x >> 5, plane = blockIdx.y;
+    const int bin = blockIdx.x * 32 + b;
+    // sixteen rows of EACH track in flight per thread: one round trip for a pair of 8-minute tracks
+    double sacc[2] = {0.0, 0.0};
+    if (bin < bins) {
+        // buffer views: ONE lane offset per track, the row step is a scalar displacement, and rows past
+        // the end of a track read as zero through the range check
+        const MemView vt = mem_view(tt.wg_spec, (long long)tt.nwg * 2 * bins * 4);
+        const MemView vr = mem_view(tr.wg_spec, (long long)tr.nwg * 2 * bins * 4);
+        const unsigned lane_off = (unsigned)((((size_t)row_lane * 2 + plane) * bins + bin) * 4);
+        const unsigned row_step = (unsigned)((size_t)32 * 2 * bins * 4);
+        const int longest = max(tt.nwg, tr.nwg);
+        for (int w0 = 0; w0 < longest; w0 += 32 * 16) {
+            float v[2][16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const unsigned disp = (unsigned)(w0 / 32 + u) * row_step;
+                v[0][u] = ld_f1(vt, lane_off, disp);
+                v[1][u] = ld_f1(vr, lane_off, disp);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const CurveTrack& t = k == 0 ? tt : tr;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int w = w0 + row_lane + 32 * u;
+                    const bool on = w < t.nwg && loud[k * max_div + (w < t.nwg ? w : 0) / t.lv.chunks_per_piece] != 0;
+                    sacc[k] += on ? (double)v[k][u] : 0.0;
+                }
+            }
+        }
+    }
+    double level[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const CurveTrack& t = k == 0 ? tt : tr;
+        acc[threadIdx.x] = sacc[k];
+        __syncthreads();
+        double total = 0.0;
+        if (row_lane == 0) {
+#pragma unroll 8
+            for (int l = 0; l < 32; ++l) total += acc[l * 32 + b];
+        }
+        // mean over loud pieces and segments of |rfft|/F of the normalised track (match_frequencies.py:42)
+        level[k] = total / (scal[k * 4 + 2] * (double)t.segs_per_piece * (double)fft * scal[k * 4 + 0]);
+        __syncthreads();
+    }
+    if (row_lane == 0 && bin < bins)
+        raw[(size_t)plane * bins + bin] = level[1] / fmax(curve_floor, level[0] * c0);   // stages.py:90-91 on the target
+}
+
 // The operator is numerically banded: LOWESS looks at 3.75 % of the log-frequency grid and the
 // splines' influence decays geometrically, so outside a window around the diagonal (about a third of
 // the bin index wide) every entry is below 1e-18 of the row's largest.  k_fir_band records that
@@ -695,55 +853,44 @@ __global__ __launch_bounds__(1024) void k_fir_b(FirPlanView pl, double* scratch)
     __syncthreads();
     FirDesign::phase_pin(tid, s);
 }
-// irfft + ifftshift + Hann (match_frequencies.py:98-99).  grid = (F/64, 2); a workgroup
-// computes TAPS_PER_WG taps, 1024 / TAPS_PER_WG lanes each summing a slice of the bins (the sum over a
-// slice is one dependent chain, so short slices matter more than few workgroups).
-constexpr int TAPS_PER_WG = 16, TAP_SLICES = 1024 / TAPS_PER_WG;
-template <bool COS_IN_LDS>
+// irfft + ifftshift + Hann (match_frequencies.py:98-99) as a direct cosine sum in float64.  grid =
+// (F / TAPS_PER_WG, 2); a workgroup computes TAPS_PER_WG taps (the lanes of a wave), its TAP_SLICES
+// waves each summing a slice of the bins.  cos(2 pi k m / F) for the consecutive k of a slice comes from
+// a rotation: start and step are exact table values, the steps in between cost four float64
+// operations each and add ~1e-14 of error over a slice -- no cosine table in LDS (filling 32 KB of
+// it per workgroup was most of this kernel's time) and no gather through the L2.
+constexpr int TAPS_PER_WG = 64, TAP_SLICES = 1024 / TAPS_PER_WG;
 __global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double* scratch, float* taps /* [2][F] */) {
     MGX_LDS;
     double* sm = reinterpret_cast<double*>(mgx_smem);       // [bins]
     double* red = sm + pl.bins;                             // [1024]
-    double* cos_lds = red + 1024;                           // [F] when it fits
     const int plane = blockIdx.y, f = pl.fft, half = f / 2;
     const FirScratch s = fir_scratch(const_cast<double*>(scratch), pl, plane);
-    if (COS_IN_LDS)
-        for (int i = threadIdx.x; i < f; i += 1024) cos_lds[i] = pl.cos_table[i];
-    for (int i = threadIdx.x; i < pl.bins; i += 1024) sm[i] = s.smooth[i];
-    __syncthreads();
-    const int i = blockIdx.x * TAPS_PER_WG + (threadIdx.x % TAPS_PER_WG), lane = threadIdx.x / TAPS_PER_WG;
+    const int i = blockIdx.x * TAPS_PER_WG + (threadIdx.x % TAPS_PER_WG), slice = threadIdx.x / TAPS_PER_WG;
     const int mm = (i + half) & (f - 1);
-    const int per = (half - 1 + TAP_SLICES - 1) / TAP_SLICES;   // bins 1 .. half-1 split over the lanes
-    const int k0 = 1 + lane * per, k1 = min(half, k0 + per);
+    const int per = (half - 1 + TAP_SLICES - 1) / TAP_SLICES;   // bins 1 .. half-1 split over the slices
+    const int k0 = 1 + slice * per, k1 = min(half, k0 + per);
+    // asked for before the barrier: four table look-ups per thread
+    const int i0 = (int)(((long long)k0 * mm) & (f - 1));
+    double c = pl.cos_table[i0], sn = pl.cos_table[(i0 - f / 4) & (f - 1)];        // sin x = cos(x - pi/2)
+    const double dc = pl.cos_table[mm], ds = pl.cos_table[(mm - f / 4) & (f - 1)];
+    const double window = pl.hann[i];
+    for (int k = threadIdx.x; k < pl.bins; k += 1024) sm[k] = s.smooth[k];
+    __syncthreads();
     double acc = 0.0;
-    if (COS_IN_LDS) {
-        int idx = (int)(((long long)k0 * mm) & (f - 1));
-        for (int k = k0; k < k1; ++k) {
-            acc = fma(sm[k], cos_lds[idx], acc);
-            idx = (idx + mm) & (f - 1);
-        }
-    } else {
-        // The table does not fit the LDS (F = 16384): a look-up per term would be a gather through the
-        // L2 (measured 780 us per pair).  cos(2 pi k mm / F) for the slice's consecutive k by rotation
-        // instead: start and step come from the table (exact), the steps in between cost four
-        // float64 operations each and add ~1e-13 of error over a slice.
-        const int i0 = (int)(((long long)k0 * mm) & (f - 1));
-        double c = pl.cos_table[i0], sn = pl.cos_table[(i0 - f / 4) & (f - 1)];        // sin x = cos(x - pi/2)
-        const double dc = pl.cos_table[mm], ds = pl.cos_table[(mm - f / 4) & (f - 1)];
-        for (int k = k0; k < k1; ++k) {
-            acc = fma(sm[k], c, acc);
-            const double cn = fma(c, dc, -sn * ds);
-            sn = fma(sn, dc, c * ds);
-            c = cn;
-        }
+    for (int k = k0; k < k1; ++k) {
+        acc = fma(sm[k], c, acc);
+        const double cn = fma(c, dc, -sn * ds);
+        sn = fma(sn, dc, c * ds);
+        c = cn;
     }
     red[threadIdx.x] = acc;
     __syncthreads();
-    if (lane == 0) {
+    if (slice == 0) {
         double t = 0.0;
-#pragma unroll 8
+#pragma unroll
         for (int l = 0; l < TAP_SLICES; ++l) t += red[l * TAPS_PER_WG + threadIdx.x];
-        const double v = (sm[0] + ((mm & 1) ? -sm[half] : sm[half]) + 2.0 * t) / f * pl.hann[i];
+        const double v = (sm[0] + ((mm & 1) ? -sm[half] : sm[half]) + 2.0 * t) / f * window;
         taps[(size_t)plane * f + i] = (float)v;
     }
 }
@@ -844,6 +991,22 @@ struct BandInfo {
     int count[4];                            // band samples compacted by each of the four waves
     int pad[2];
 };
+// frames [b, e) of chunk `ch` of piece `d`, and where the four per-wave band lists of that chunk start:
+// a region of (e - b) + BAND_SLACK floats per chunk, a quarter of it (each wave sees a quarter of the
+// chunk's samples, give or take the scalar head and tail) per wave
+struct BandChunk {
+    long long b, e, wave_cap;
+    float* lists;
+};
+__device__ __forceinline__ BandChunk band_chunk(float* band, long long piece, int chunks, int d, int ch) {
+    BandChunk c;
+    const long long len = (piece + chunks - 1) / chunks;
+    c.b = (long long)d * piece + ch * len;
+    c.e = min((long long)(d + 1) * piece, c.b + len);
+    c.wave_cap = (c.e - c.b + 3) / 4 + BAND_SLACK / 4 - 4;
+    c.lists = band + c.b + ((long long)d * chunks + ch) * BAND_SLACK;
+    return c;
+}
 struct RoundArgs {
     const float* mid;
     long long piece;
@@ -858,31 +1021,90 @@ struct RoundArgs {
     float* band;                // [n + workgroups * BAND_SLACK] compacted band samples
     BandInfo* info;             // [workgroups]
     int build_band;             // 1: round 0 (stream + build), 0: later rounds (use the band if g allows)
+    int step;                   // index of the (first) round this launch runs
     // the limiter's look-back words, preset to "unpublished" here when a limiter launch follows (saves
     // two fill launches on the stream); null otherwise
     unsigned long long* lim_published;
     long long lim_words;
     int* lim_ticket;
+    unsigned long long* tail_gains;   // [16] gains published between the rounds of k_correction_tail, or null
+    int* error;                       // set when a bounded wait expired
 };
+// The decision of one round (stages.py:149-168), taken by ONE 256-thread workgroup after every partial
+// sum has been published: piece sums -> loud pieces -> coefficient -> accumulated gain; with
+// `final_peaks` also the peak / limiter early-out / normalisation scalars.  `total` partials, `per`
+// of them per piece.  Every load is a cold miss: issued in batches of eight per thread, staged in LDS.
+// `step` = index of this round, `gain_in` = the gain it ran with: nothing is read back from the
+// CorrectionState, whose last writer may sit behind another XCD's L2 when rounds share a launch.
+__device__ __forceinline__ double correction_decide(const RoundArgs& a, int total, int per, double* red, double* sums,
+                                                    bool reset_arrivals, int step, double gain_in) {
+    double* stage = sums + a.divisions;                          // [total]
+    for (int k0 = threadIdx.x; k0 < total; k0 += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)       // (write-through stores on the other side, L2-bypassing loads here)
+            v[u] = k0 + 256 * u < total ? __hip_atomic_load(a.partial + k0 + 256 * u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k0 + 256 * u < total) stage[k0 + 256 * u] = v[u];
+    }
+    __shared__ float fscratch[4];
+    __shared__ double new_gain;
+    float m = 0.f;
+    if (a.final_peaks) {
+        for (long long k0 = threadIdx.x; k0 < a.npeaks; k0 += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = k0 + 256 * u < a.npeaks ? a.final_peaks[k0 + 256 * u] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+        }
+    }
+    __syncthreads();
+    piece_sums_to_lds(stage, per, a.divisions, sums);
+    double avg, match;
+    int count;
+    decide_loud<256>(sums, a.divisions, a.piece, 1.0, red, nullptr, nullptr, avg, match, count);
+    const float pk = block_max<256>(m, fscratch);
+    if (threadIdx.x == 0) {
+        const double c = *a.reference_match_rms / fmax(a.eps, match);      // match_levels.py:106-111
+        CorrectionState* cs = a.cs;
+        new_gain = gain_in * c;
+        cs->coeffs[step] = c;
+        cs->steps_done = step + 1;
+        cs->gain = new_gain;
+        if (a.final_peaks) {
+            const double peak = (double)(float)((double)pk * new_gain);      // max |float32(y*gain)|
+            cs->result_peak = peak;
+            const double rect = fmax(peak, a.threshold) / a.threshold;
+            cs->limiter_active = fabs(rect - 1.0) > (1e-8 + 1e-5) ? 1 : 0;   // numpy.isclose defaults, hyrax.py:83
+            cs->normalize_c = fmax(a.eps, peak / a.threshold);               // dsp.py:93-100
+        }
+        if (reset_arrivals)                                                  // ready for the next round or launch
+            __hip_atomic_store(a.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return new_gain;
+}
+
 __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
     MGX_LDS;
     double* red = reinterpret_cast<double*>(mgx_smem);          // 64 doubles of scratch
     double* sums = red + 64;                                     // [divisions]
     __shared__ int is_last;
     const int d = blockIdx.x / a.chunks, ch = blockIdx.x % a.chunks;
-    const long long len = (a.piece + a.chunks - 1) / a.chunks;
-    const long long b = (long long)d * a.piece + ch * len;
-    const long long e = min((long long)(d + 1) * a.piece, b + len);
+    const BandChunk bc = band_chunk(a.band, a.piece, a.chunks, d, ch);
+    const long long b = bc.b, e = bc.e;
     const double g = a.cs->gain;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (a.tail_gains && blockIdx.x == 0 && threadIdx.x < 16) a.tail_gains[threadIdx.x] = ~0ull;   // "not yet": k_correction_tail
     if (a.lim_published) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.lim_words; i += (long long)gridDim.x * 256)
             a.lim_published[i] = ~0ull;
         if (blockIdx.x == 0 && threadIdx.x == 0) *a.lim_ticket = 0;      // ticket only: a raised error sticks
     }
     // this workgroup's slice of the band buffer, one compacted list per wave
-    const long long wave_cap = (len + 3) / 4 + BAND_SLACK / 4 - 4;
-    float* wave_band = a.band + b + (long long)blockIdx.x * BAND_SLACK + wave * wave_cap;
+    float* wave_band = bc.lists + wave * bc.wave_cap;
     BandInfo* info = a.info + blockIdx.x;
     double acc = 0.0;
     // float64 product then clip: the reference clips the float64 mid (dsp.py:109-110)
@@ -916,7 +1138,8 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
                 clipped += __popcll(__ballot(always));
                 const bool in_band = ok && !never && !always;
                 const unsigned long long mask = __ballot(in_band);
-                if (in_band) wave_band[filled + __popcll(mask & below)] = v;
+                const long long slot = filled + __popcll(mask & below);
+                if (in_band && slot < bc.wave_cap) wave_band[slot] = v;      // (a wave's quarter + slack never overflows)
                 filled += __popcll(mask);
             }
         };
@@ -977,49 +1200,167 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
     }
     __syncthreads();
     if (!is_last) return;
-    // The last arriver is alone and every load below is a cold miss: issue them in batches of
-    // eight per thread, stage the partials in LDS, then sum each piece's chunks from there.
-    double* stage = sums + a.divisions;                          // [divisions * chunks]
-    const int total = a.divisions * a.chunks;
-    for (int k0 = threadIdx.x; k0 < total; k0 += 8 * 256) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = k0 + 256 * u < total ? a.partial[k0 + 256 * u] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (k0 + 256 * u < total) stage[k0 + 256 * u] = v[u];
-    }
+    correction_decide(a, a.divisions * a.chunks, a.chunks, red, sums, true, a.step, g);
+}
+
+// Rounds 1 .. K-1 of stages.py:149-168 in ONE launch.  After round 0 a round only touches the band
+// lists (a few MB) and a handful of scalars, so a launch per round was mostly launch, ramp and a chain
+// of cold round trips: 16 us each for ~1 us of work.  Here a small grid (divisions x groups workgroups,
+// at most ~128: every one of them must be resident at once, also next to other handles' kernels) keeps
+// running.  Before the first round a workgroup adds up the closed-form parts of its chunks and copies
+// their band lists into LDS (when they fit); a round is then: sum from LDS -> publish the partial ->
+// one arrival counter -> the last arriver reads the partials (L2-bypassing loads, no fence), decides
+// with one wave and publishes the new gain as an 8-byte word whose value is the flag (preset to
+// all-ones by round 0) -> everybody polls it (one lane, bounded) and goes on.  A gain outside
+// [BAND_G_LO, BAND_G_HI] makes a workgroup stream its part of the mid plane instead (slow with so few
+// workgroups, and never seen: coefficients are ratios of two loudness estimates of nearly the same
+// signal).
+constexpr int TAIL_CACHE_PER_WAVE = 3072;        // floats of band list a wave keeps in LDS
+__host__ __device__ inline size_t correction_tail_lds_bytes(int divisions, int groups) {
+    return ((size_t)64 + divisions + (size_t)divisions * groups) * 8 + (size_t)4 * TAIL_CACHE_PER_WAVE * 4 + 16;
+}
+__global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups, int rounds) {
+    MGX_LDS;
+    double* red = reinterpret_cast<double*>(mgx_smem);          // 64 doubles of scratch
+    double* sums = red + 64;                                     // [divisions]
+    double* stage = sums + a.divisions;                          // [divisions * groups]
+    float* cache = reinterpret_cast<float*>(stage + a.divisions * groups);
+    __shared__ int is_last;
+    __shared__ double gain_now;
     __shared__ float fscratch[4];
-    float m = 0.f;
-    if (a.final_peaks) {
-        for (long long k0 = threadIdx.x; k0 < a.npeaks; k0 += 8 * 256) {
-            float v[8];
+    const int d = blockIdx.x / groups, grp = blockIdx.x % groups;
+    const int ch0 = (int)((long long)grp * a.chunks / groups), ch1 = (int)((long long)(grp + 1) * a.chunks / groups);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, total = a.divisions * groups;
+    if (a.lim_published) {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.lim_words; i += (long long)gridDim.x * 256)
+            a.lim_published[i] = ~0ull;
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.lim_ticket = 0;      // ticket only: a raised error sticks
+    }
+    double g = a.cs->gain;
+    // ---- once: closed-form parts and band lists of this workgroup's chunks (lane c <-> chunk ch0 + c) ----
+    const int nch = ch1 - ch0;                                           // <= 64 (host)
+    int my_count = 0;
+    double part_a = 0.0, part_c = 0.0;
+    if (lane < nch) {
+        const BandInfo* info = a.info + d * a.chunks + ch0 + lane;
+        my_count = info->count[wave];
+        if (wave == 0) { part_a = info->unclipped_sumsq; part_c = info->clipped_count; }
+    }
+    const double closed_a = wave_sum(part_a), closed_c = wave_sum(part_c);   // meaningful on wave 0
+    int before = my_count;                                               // exclusive prefix of the counts over the lanes
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = k0 + 256 * u < a.npeaks ? a.final_peaks[k0 + 256 * u] : 0.f;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) m = fmaxf(m, v[u]);
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(before, o, 64);
+        if (lane >= o) before += v;
+    }
+    const int wave_total = __shfl(before, 63, 64);
+    before -= my_count;
+    const bool cached = wave_total <= TAIL_CACHE_PER_WAVE;               // uniform per wave
+    float* mine = cache + wave * TAIL_CACHE_PER_WAVE;
+    if (cached) {
+        for (int c = 0; c < nch; ++c) {
+            const BandChunk bc = band_chunk(a.band, a.piece, a.chunks, d, ch0 + c);
+            const float* list = bc.lists + wave * bc.wave_cap;
+            const int n = __shfl(my_count, c, 64), off = __shfl(before, c, 64);
+            for (int k = lane; k < n; k += 64) mine[off + k] = list[k];
         }
     }
-    __syncthreads();
-    piece_sums_to_lds(stage, a.chunks, a.divisions, sums);
-    double avg, match;
-    int count;
-    decide_loud<256>(sums, a.divisions, a.piece, 1.0, red, nullptr, nullptr, avg, match, count);
-    const float pk = block_max<256>(m, fscratch);
-    if (threadIdx.x == 0) {
-        const double c = *a.reference_match_rms / fmax(a.eps, match);      // match_levels.py:106-111
-        CorrectionState* cs = a.cs;
-        cs->coeffs[cs->steps_done] = c;
-        cs->steps_done += 1;
-        cs->gain *= c;
-        if (a.final_peaks) {
-            const double peak = (double)(float)((double)pk * cs->gain);      // max |float32(y*gain)|
-            cs->result_peak = peak;
-            const double rect = fmax(peak, a.threshold) / a.threshold;
-            cs->limiter_active = fabs(rect - 1.0) > (1e-8 + 1e-5) ? 1 : 0;   // numpy.isclose defaults, hyrax.py:83
-            cs->normalize_c = fmax(a.eps, peak / a.threshold);               // dsp.py:93-100
+    const float* final_peaks = a.final_peaks;
+    for (int r = 0; r < rounds; ++r) {
+        double acc = 0.0;
+        auto add = [&](float v) {
+            const double c = fmin(fmax((double)v * g, -1.0), 1.0);       // float64 product, then clip (dsp.py:109-110)
+            acc = fma(c, c, acc);
+        };
+        if (g >= BAND_G_LO && g <= BAND_G_HI) {                          // uniform over the grid
+            if (cached) {
+                for (int k = lane; k < wave_total; k += 64) add(mine[k]);
+            } else {
+                for (int c = 0; c < nch; ++c) {
+                    const BandChunk bc = band_chunk(a.band, a.piece, a.chunks, d, ch0 + c);
+                    const float* list = bc.lists + wave * bc.wave_cap;
+                    const int n = __shfl(my_count, c, 64);
+                    for (int k = lane; k < n; k += 64) add(list[k]);
+                }
+            }
+            if (threadIdx.x == 0) acc += g * g * closed_a + closed_c;
+        } else {
+            for (int c = 0; c < nch; ++c) {
+                const BandChunk bc = band_chunk(a.band, a.piece, a.chunks, d, ch0 + c);
+                for (long long i = bc.b + threadIdx.x; i < bc.e; i += 256) add(a.mid[i]);
+            }
         }
-        *a.arrivals = 0;                                                     // ready for the next launch
+        const double s = block_sum<256>(acc, red);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(a.partial + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            is_last = atomicAdd(a.arrivals, 1u) == (unsigned)total - 1;
+        }
+        __syncthreads();
+        const bool last_round = r == rounds - 1;
+        if (is_last) {                                                   // uniform: one workgroup per round
+            for (int k = threadIdx.x; k < total; k += 256)
+                stage[k] = __hip_atomic_load(a.partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float m = 0.f;
+            if (last_round && final_peaks)
+                for (long long k = threadIdx.x; k < a.npeaks; k += 256) m = fmaxf(m, final_peaks[k]);
+            __syncthreads();
+            for (int p = threadIdx.x; p < a.divisions; p += 256) {
+                double t = 0.0;
+                for (int q = 0; q < groups; ++q) t += stage[p * groups + q];
+                sums[p] = t;
+            }
+            const float pk = block_max<256>(m, fscratch);                 // (barrier inside: sums[] is complete after it)
+            if (wave == 0) {
+                double avg, match;
+                int count;
+                wave_decide(sums, a.divisions, a.piece, 1.0, nullptr, nullptr, avg, match, count);
+                if (lane == 0) {
+                    const double c = *a.reference_match_rms / fmax(a.eps, match);      // match_levels.py:106-111
+                    const double next = g * c;
+                    // Write-through stores, field by field: the rounds of one launch are decided by
+                    // workgroups on different XCDs, and two L2s each holding a dirty copy of this line
+                    // would overwrite each other's fields when they write it back.
+                    CorrectionState* cs = a.cs;
+                    auto put = [](double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+                    auto puti = [](int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+                    put(&cs->coeffs[a.step + r], c);
+                    puti(&cs->steps_done, a.step + r + 1);
+                    put(&cs->gain, next);
+                    if (last_round && final_peaks) {
+                        const double peak = (double)(float)((double)pk * next);      // max |float32(y*gain)|
+                        const double rect = fmax(peak, a.threshold) / a.threshold;
+                        put(&cs->result_peak, peak);
+                        puti(&cs->limiter_active, fabs(rect - 1.0) > (1e-8 + 1e-5) ? 1 : 0);   // numpy.isclose defaults, hyrax.py:83
+                        put(&cs->normalize_c, fmax(a.eps, peak / a.threshold));               // dsp.py:93-100
+                    }
+                    // the counter is back at zero before anybody can arrive again
+                    __hip_atomic_store(a.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!last_round)
+                        __hip_atomic_store(a.tail_gains + r, double_bits(next), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        if (last_round) break;
+        if (threadIdx.x == 0) {
+            unsigned long long v = __hip_atomic_load(a.tail_gains + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (v == ~0ull && spins < (1 << 20)) {
+                if (spins < 64) __builtin_amdgcn_s_sleep(2);
+                else __builtin_amdgcn_s_sleep(16);
+                v = __hip_atomic_load(a.tail_gains + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ++spins;
+            }
+            if (v == ~0ull) {
+                *a.error = 1;
+                v = double_bits(1.0);
+            }
+            gain_now = bits_double(v);
+        }
+        __syncthreads();
+        g = gain_now;
+        __syncthreads();
     }
 }
 

@@ -182,8 +182,7 @@ static int analyze_impl(const float* x, long long n, const mgx_config* cfg, int 
     a.piece = piece;
     a.divisions = divisions;
     a.segs_per_piece = (int)(piece / F::N);
-    a.segs_per_wg = 5;
-    a.chunks_per_piece = std::max(1, (a.segs_per_piece + a.segs_per_wg - 1) / a.segs_per_wg);
+    a.chunks_per_piece = std::max(1, (a.segs_per_piece + 4) / 5);
     const int nwg = divisions * a.chunks_per_piece, half = F::N / 2;
     std::vector<double> wg_sumsq(nwg);
     std::vector<float> wg_peak(nwg), wg_spec((size_t)nwg * 2 * (half + 1), 0.f);
@@ -199,7 +198,8 @@ static int analyze_impl(const float* x, long long n, const mgx_config* cfg, int 
     for (int wg = 0; wg < nwg; ++wg) {
         const int d = wg / a.chunks_per_piece, ch = wg % a.chunks_per_piece;
         FOR_THREADS(F::T) AB::init(th[tid]);
-        const int s0 = ch * a.segs_per_wg, s1 = std::min(a.segs_per_piece, s0 + a.segs_per_wg);
+        int s0, s1;
+        Analysis2Block<LOG2N>::chunk_segments(a, ch, s0, s1);
         for (int s = s0; s < s1; ++s) {
             const long long start = d * piece + (long long)s * F::N;
             FOR_THREADS(F::T) { typename AB::Raw raw; AB::fetch(tid, start, a, raw); AB::phase_load(tid, raw, ps[tid], th[tid], lds.data()); }
