@@ -8,7 +8,7 @@
 #include "../../include/mgx.h"
 #include <vector>
 
-#include "limiter2_kernel.h"
+#include "limiter_kernel.h"
 
 namespace mgx {
 
@@ -29,7 +29,8 @@ inline Iir1 butter1(double fc, double fs) {
 struct LimiterParams {
     int attack, hold, hw, hb, ha;
     Iir1 att, hold_f, rel_f;
-    Limiter2Block::Geometry geo;
+    int threads;                                   // blocks per chunk the limiter kernel runs with: 256 or 1024
+    LimiterBlock<256>::Geometry geo;               // (the same struct for every T)
     std::vector<double> w_hold, w_rel, w_att;      // look-back weights (alpha^chunk)^m
 };
 
@@ -66,7 +67,6 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
     const int w = (p.attack & 1) ? p.attack : p.attack + 1;
     p.hw = w - 1;
     p.hb = p.hold - 1;
-    if (2 * p.hw < 16) return "limiter attack window shorter than 17 samples is not implemented";
     const double rho = std::exp(c.attack_filter_coefficient / p.attack);
     if (!(rho > 0.0 && rho < 1.0)) return "attack_filter_coefficient must be negative";
     p.att = Iir1{1.0 - rho, rho, rho * (1.0 - rho)};
@@ -74,8 +74,16 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
     p.rel_f = butter1(c.release_filter_coefficient / c.release_ms, sr);
     // frames after which the attack smoother has forgotten its state (rho^ha <= 1e-8)
     p.ha = (int)std::ceil(std::log(1e-8) / std::log(rho));
-    p.geo = Limiter2Block::geometry(p.hw, p.hb, p.ha);
-    if (p.geo.core_blocks < 64) return "limiter attack/hold times too long for the chunked kernel";
+    // 256 blocks per chunk while the halos leave at least a quarter of them to the core, else 1024
+    p.threads = 256;
+    p.geo = LimiterBlock<256>::geometry(p.hw, p.hb, p.ha);
+    if (p.geo.core_blocks < 64) {
+        p.threads = 1024;
+        const LimiterBlock<1024>::Geometry g = LimiterBlock<1024>::geometry(p.hw, p.hb, p.ha);
+        p.geo.gl = g.gl; p.geo.gr = g.gr; p.geo.gw = g.gw; p.geo.core_blocks = g.core_blocks; p.geo.chunk = g.chunk;
+    }
+    if (p.geo.core_blocks < 64)
+        return "limiter attack/hold times too long for the chunked kernel (halos of more than 960 blocks of 16 frames)";
     if (!(p.hold_f.alpha > 0.0 && p.hold_f.alpha < 1.0 && p.rel_f.alpha > 0.0 && p.rel_f.alpha < 1.0))
         return "hold/release filter is not a stable low-pass";
     p.w_hold = lookback_weights(p.hold_f.alpha, p.geo.chunk, 1 << 16);
@@ -85,7 +93,7 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
 }
 
 // fills everything of Limiter2Args that derives from the parameters (pointers are the caller's)
-inline void limiter_fill(const LimiterParams& p, float threshold, Limiter2Args& a) {
+inline void limiter_fill(const LimiterParams& p, float threshold, LimiterArgs& a) {
     a.threshold = threshold;
     a.hw = p.hw;
     a.hb = p.hb;

@@ -1,32 +1,135 @@
-// Hyrax brick-wall limiter (matchering/limiter/hyrax.py:78-99) in ONE streaming pass -- third
-// generation of the chunk kernel.  Same mathematics and the same chunk geometry / look-back words
-// as limiter2_kernel.h (read its header first); what changed is everything that decided how many
-// workgroups a CU holds and how long each of them waits:
+// Hyrax brick-wall limiter (matchering/limiter/hyrax.py:78-99) in ONE streaming pass.
 //
-//  * ONE LDS plane.  The raw hard-clip gains g0 stay in the plane; a thread forms its 2 x 16 window
-//    maxima from them directly (a suffix run on the left edge, a prefix run on the right edge, whole
-//    block maxima in between) instead of from precomputed prefix / suffix planes.  18.8 KB per
-//    workgroup instead of 36 KB, one barrier less, and the block maxima come out of the load phase
-//    (eight neighbouring lanes hold one block: three DPP steps).
-//  * The attack path (sl -> forward smoother -> backward smoother) runs to completion before the
-//    hold / release path starts, so at most three 16-frame arrays are live at any time: the kernel
-//    is compiled for six workgroups per CU (80 VGPRs) instead of four.
-//  * Look-back words are asked for as soon as the chunk's own aggregates are published and consumed
-//    as late as possible.  The forward attack carry enters linearly, so the whole attack path runs
+// Reference data flow (every array is length n, float64):
+//   rect  = max(|L|,|R|) floored at thr, / thr                    dsp.py:117-121
+//   g0    = 1 - 1/rect                                            hyrax.py:87
+//   sl    = centred sliding max of g0, window 2w-1, w = odd(att)  hyrax.py:35-37
+//   gA    = filtfilt(1-pole rho = exp(coef/att), sl)              hyrax.py:48-51
+//   sh    = trailing sliding max of sl over `hold` samples        hyrax.py:38-40
+//   ho    = lfilter(butter(hold order, hold Hz), sh)              hyrax.py:61-66
+//   ro    = lfilter(butter(rel order, rel Hz), max(sh, ho))       hyrax.py:68-73
+//   gain  = 1 - max(g0, gA, max(ho, ro));  out = x * gain         hyrax.py:75,97,99
+//
+// GPU formulation.  The track is cut into chunks of C = CB*16 frames; a chunk is one T-thread
+// workgroup whose thread t owns "block" t = 16 consecutive frames, GL halo blocks before the chunk's
+// CB core blocks and GR after them (T = 256: four workgroups per CU; T = 1024 for attack / hold times
+// whose halos would not leave a 256-block chunk enough core).
+//
+//  * Frames are loaded coalesced (16 B per lane); only g0 travels through LDS to the owning thread.
+//    The final gain travels back the same way and the frames are re-read (L2 / Infinity Cache) for
+//    the coalesced store: 8 B/frame read + 8 B/frame written reach HBM.
+//  * ONE LDS plane.  The raw hard-clip gains g0 stay in the plane; both sliding maxima are windows
+//    of g0 itself (sh[n] = max g0[n-hw-hb .. n+hw]) and a thread forms its 2 x 16 window maxima from
+//    the plane directly: a suffix run on the left edge, a prefix run on the right edge, whole-block
+//    maxima in between (those come out of the load phase: eight neighbouring lanes hold one block,
+//    three DPP steps).
+//  * Every recurrence is first order (state z: y[n] = b0 x[n] + z[n-1], z[n] = alpha z[n-1] +
+//    beta x[n], scipy's transposed direct form II).  A thread runs its 16 frames in float32 from
+//    a zero state; its block acts on the carried state as an affine map, the maps are composed
+//    across the workgroup by an ordered float64 scan (wave shuffles + one LDS hop), and the exact
+//    outputs are the local run plus alpha^j times the carry.  Rounding never accumulates beyond
+//    16 frames.
+//  * The attack smoother's pole rho = exp(coef/attack) forgets quickly: rho^HA <= 1e-8 after
+//    HA ~ 9*attack frames.  The right halo is HA (+ window) frames long, so the backward run of
+//    scipy.signal.filtfilt started from zero at the end of the halo is exact (to 1e-8) inside the
+//    core and never needs a later chunk.  filtfilt's edge handling (odd extension by 6,
+//    steady-state initial conditions) is applied by the chunks that contain frame 0 / frame n-1.
+//  * The forward attack smoother, the hold and the release low-passes carry state from chunk to
+//    chunk (the latter two for seconds).  Each chunk publishes the state its core frames produce
+//    from a zero carry (one float64 per filter, written once); a chunk's carry is
+//    sum_m (alpha^C)^m * published[chunk-1-m], truncated where (alpha^C)^m <= 1e-10 (1 chunk for
+//    the attack pole, a handful for the 7 Hz hold filter, ~170 for the 0.27 Hz release filter).
+//    No chunk ever waits for another chunk's look-back of the same filter, so the dependency
+//    depth is two (release aggregates need the exact hold output) however long the track is.
+//    Chunk numbers are drawn from an atomic ticket, so every chunk a workgroup waits for has
+//    already started.
+//  * Order of work inside a chunk: the hold path first (its aggregate is what successors wait for
+//    longest), then the attack path to completion -- so that few 16-frame arrays are live at a time --
+//    and the look-back words are asked for as soon as the chunk's own aggregates are published and
+//    taken as late as possible.  The forward attack carry enters linearly, so the attack path runs
 //    on a zero carry while the words are in flight and the carry is added at the end:
 //        gA[n] += carry * kappa * rho^(n - n0),   kappa = b0 + beta*rho / (1 - rho^2)
 //    (the backward smoother's response to the decaying state, summed to infinity: the right halo is
 //    >= 9 time constants long).  Only the chunk that holds the last frame of the track -- filtfilt's
 //    odd extension makes its backward start depend on the forward end state -- waits for its carry
 //    first.
+//  * Chunks that lie strictly inside the track run a branch-free instantiation (FULL) of every phase.
+//
+// Published words are 8-byte granules whose value is the flag: the array is preset to all-ones
+// (not a finite double) before each launch and written with one relaxed agent-scope atomic store
+// (MI355X_MICROARCH.md, inter-workgroup visibility: a single naturally aligned 8-byte sc1 store,
+// polled with relaxed sc1 loads, needs no fence).  Every poll loop is bounded.
 #pragma once
 
-#include "limiter2_kernel.h"
+#include "scan_util.h"
 
 namespace mgx {
 
-struct Limiter3Block {
-    static constexpr int T = 256;
+struct Iir1 {
+    double b0, alpha, beta;        // y = b0*x + z_prev ; z = alpha*z_prev + beta*x
+};
+struct Iir1f {
+    float b0, alpha, beta;
+};
+
+struct LimiterArgs {
+    const float2* y;               // (n,2) level-corrected result before the final gains
+    long long n;
+    float2* out;                   // (n,2) limited output
+    const double* gain;            // device scalar: accumulated level-correction gain
+    const double* post_gain;       // device scalar: final amplitude coefficient (stages.py:203)
+    const int* active;             // device flag: 0 => limiter early-out (hyrax.py:83-85)
+    float threshold;
+    int hw;                        // attack half window = odd(attack) - 1
+    int hb;                        // hold look-back     = hold - 1
+    int gl, gr, gw;                // halo blocks left / right; blocks without a full sl window
+    Iir1 att, hold, rel;           // float64 coefficients (edge states, aggregates)
+    Iir1f attf, holdf, relf;       // float32 copies for the per-frame arithmetic
+    double pa16, ph16, pr16;       // alpha^16 in float64: the decay of a full block
+    long long nchunks;
+    unsigned long long* published; // [3][nchunks]: hold, release, attack chunk aggregates (bit patterns)
+    const double* w_hold;          // (alpha_hold^C)^m, m = 0..n_hold-1
+    const double* w_rel;
+    const double* w_att;
+    int n_hold, n_rel, n_att;
+    int* ticket;                   // chunk dispenser (zeroed before the launch)
+    int* error;                    // set to 1 if a bounded wait expired
+};
+
+constexpr unsigned long long LIMITER_UNPUBLISHED = ~0ull;
+
+// ---- inter-workgroup words ---------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_HOST_EMU)
+__device__ __forceinline__ void publish_word(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long poll_word(unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void backoff(int spins) {             // ~0.03 us at first, ~0.5 us when it drags on
+    if (spins < 8) __builtin_amdgcn_s_sleep(1);
+    else if (spins < 64) __builtin_amdgcn_s_sleep(4);
+    else __builtin_amdgcn_s_sleep(16);
+}
+#else
+inline void publish_word(unsigned long long* p, unsigned long long v) { *p = v; }
+inline unsigned long long poll_word(unsigned long long* p) { return *p; }
+inline void backoff(int) {}
+#endif
+MGX_HD unsigned long long double_bits(double v) {
+    union { double d; unsigned long long u; } c;
+    c.d = v;
+    return c.u;
+}
+MGX_HD double bits_double(unsigned long long u) {
+    union { double d; unsigned long long u; } c;
+    c.u = u;
+    return c.d;
+}
+
+template <int T_>
+struct LimiterBlock {
+    static constexpr int T = T_;
     static constexpr int E = 16;
     static constexpr int STRIDE = E + 1;               // LDS row stride (floats): conflict-free columns
     static constexpr int WAVES = T / 64;
@@ -53,20 +156,32 @@ struct Limiter3Block {
     static MGX_HD double* scalars(float* lds) { return reinterpret_cast<double*>(lds + MISC_OFF + 16 + TOTALS_FLOATS); }
     static MGX_HD int gidx(int i) { return (i >> 4) * STRIDE + (i & 15); }
 
-    using Geometry = Limiter2Block::Geometry;
-    static MGX_HD Geometry geometry(int hw, int hb, int ha) { return Limiter2Block::geometry(hw, hb, ha); }
-    static MGX_HD long long region_start(long long chunk, const Limiter2Args& a) {
-        return Limiter2Block::region_start(chunk, a);
+    struct Geometry {
+        int gl, gr, gw, core_blocks, chunk;
+    };
+    // ha = frames after which the attack pole has decayed to 1e-8
+    static MGX_HD Geometry geometry(int hw, int hb, int ha) {
+        Geometry g;
+        g.gw = (hw + E - 1) / E;
+        const int hab = (ha + E - 1) / E;
+        g.gl = (hw + hb + E - 1) / E;          // left: only the sh window (the attack state is carried in)
+        g.gr = hab + g.gw;                      // right: backward warm-up + sl window
+        g.core_blocks = T - g.gl - g.gr;
+        g.chunk = g.core_blocks * E;
+        return g;
+    }
+    static MGX_HD long long region_start(long long chunk, const LimiterArgs& a) {
+        return chunk * (long long)((T - a.gl - a.gr) * E) - (long long)a.gl * E;
     }
     // the chunk whose region reaches the end of the track: its attack carry is taken up front
-    static MGX_HD bool tail_chunk(long long chunk, const Limiter2Args& a) {
+    static MGX_HD bool tail_chunk(long long chunk, const LimiterArgs& a) {
         return region_start(chunk, a) + FRAMES >= a.n;
     }
 
     // a chunk whose region lies strictly inside the track: every block has 16 frames, no filtfilt edge,
     // plain loads.  All but the first and the last one or two chunks of a track: the phases are compiled
     // twice, FULL = true without any of the per-frame validity tests.
-    static MGX_HD bool full_chunk(long long chunk, const Limiter2Args& a) {
+    static MGX_HD bool full_chunk(long long chunk, const LimiterArgs& a) {
         const long long r0 = region_start(chunk, a);
         return r0 >= 0 && r0 + FRAMES < a.n;
     }
@@ -97,7 +212,7 @@ struct Limiter3Block {
     // ---- P1: coalesced load, g0 -> plane; pm[j] = max of this lane's two frames of iteration j ----
     // (lanes 8q .. 8q+7 of iteration j hold block q + 32 j: the kernel folds them into the block maxima)
     template <bool FULL = false>
-    static MGX_HD void phase_load(int tid, long long chunk, const Limiter2Args& a, float* lds, float (&pm)[E / 2]) {
+    static MGX_HD void phase_load(int tid, long long chunk, const LimiterArgs& a, float* lds, float (&pm)[E / 2]) {
         const long long r0 = region_start(chunk, a);
         const bool interior = FULL || (r0 >= 0 && r0 + FRAMES <= a.n);
         const float g = (float)*a.gain;
@@ -188,14 +303,105 @@ struct Limiter3Block {
             out[j] = fmaxf(out[j], s);
         }
     }
+    // windows shorter than 15 frames (attack times of a few samples): the three parts above would
+    // overlap, so every frame's window is read out directly
+    static MGX_HD bool short_window(int lw, int hw) { return lw + hw < 14; }
+    static MGX_HD void window_direct(int tid, int lw, int hw, const float* lds, float (&out)[E]) {
+        const float* row = plane(const_cast<float*>(lds)) + tid * STRIDE;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) {
+            float m = 0.f;
+            for (int d = j - lw; d <= j + hw; ++d) m = fmaxf(m, row[rel(d)]);
+            out[j] = m;
+        }
+    }
 
-    // ---- first-order recurrences, filtfilt edges: shared with the second generation --------------
-    using L2 = Limiter2Block;
+    // ---- first-order recurrences over a thread's 16 frames, float32 ---------------------------------
+    // state after `count` frames starting from `z0` (frames >= count do not advance the state)
+    static MGX_HD float run_forward(const Iir1f& f, const float (&x)[E], int count, float z0) {
+        float s = z0;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j)
+            if (j < count) s = fmaf(f.alpha, s, f.beta * x[j]);
+        return s;
+    }
+    static MGX_HD float run_backward(const Iir1f& f, const float (&x)[E], int count, float z0) {
+        float s = z0;
+        MGX_UNROLL
+        for (int j = E - 1; j >= 0; --j)
+            if (j < count) s = fmaf(f.alpha, s, f.beta * x[j]);
+        return s;
+    }
+    // outputs y[j] = b0 x[j] + z[j-1] with the true state z0 entering the block; returns the state
+    // after the block.  Rounding accumulates over at most 16 frames (the carry is exact float64
+    // rounded once).
+    static MGX_HD float out_forward(const Iir1f& f, const float (&x)[E], int count, float z0, float (&y)[E]) {
+        float s = z0;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) {
+            if (j < count) {
+                y[j] = fmaf(f.b0, x[j], s);
+                s = fmaf(f.alpha, s, f.beta * x[j]);
+            } else {
+                y[j] = 0.f;
+            }
+        }
+        return s;
+    }
+    static MGX_HD void out_backward(const Iir1f& f, const float (&x)[E], int count, float z0, float (&y)[E]) {
+        float s = z0;
+        MGX_UNROLL
+        for (int j = E - 1; j >= 0; --j) {
+            if (j < count) {
+                y[j] = fmaf(f.b0, x[j], s);
+                s = fmaf(f.alpha, s, f.beta * x[j]);
+            } else {
+                y[j] = 0.f;
+            }
+        }
+    }
+    // alpha^count for the aggregate of a block with `count` valid frames: table[E] for a full block
+    static MGX_HD double block_decay(double full, double alpha, int count) {
+        if (count == E) return full;
+        double r = 1.0;
+        for (int i = 0; i < count; ++i) r *= alpha;
+        return r;
+    }
+
+    // scipy.signal.filtfilt edges (padtype 'odd', padlen 6, lfilter_zi), float64
+    static MGX_HD double filtfilt_left_state(const Iir1& f, const float* sl0 /* sl[0..6] */) {
+        const double x0 = (double)sl0[0];
+        const double zi = f.beta / (1.0 - f.alpha);
+        double z = 0.0;
+        for (int i = 0; i < 6; ++i) {
+            const double e = 2.0 * x0 - (double)sl0[6 - i];
+            if (i == 0) z = zi * e;
+            z = fma(f.alpha, z, f.beta * e);
+        }
+        return z;
+    }
+    // sl_end = sl[n-7 .. n-1]; z_end = forward state after frame n-1.  Returns the backward state
+    // entering frame n-1.
+    static MGX_HD double filtfilt_right_state(const Iir1& f, const float* sl_end, double z_end) {
+        const double xl = (double)sl_end[6];
+        const double zi = f.beta / (1.0 - f.alpha);
+        double yfe[6];
+        double z = z_end;
+        for (int i = 0; i < 6; ++i) {
+            const double e = 2.0 * xl - (double)sl_end[5 - i];
+            yfe[i] = fma(f.b0, e, z);
+            z = fma(f.alpha, z, f.beta * e);
+        }
+        double zb = zi * yfe[5];
+        for (int i = 5; i >= 0; --i) zb = fma(f.alpha, zb, f.beta * yfe[i]);
+        return zb;
+    }
+
 
     // ---- P2: block geometry; sh; block map of the hold filter ----------------------------------------
     // The hold path goes first: its aggregate is what successors wait for longest.
     template <bool FULL = false>
-    static MGX_HD Affine phase_hold_window(int tid, long long chunk, const Limiter2Args& a, Thread& th, const float* lds) {
+    static MGX_HD Affine phase_hold_window(int tid, long long chunk, const LimiterArgs& a, Thread& th, const float* lds) {
         th.base = region_start(chunk, a) + (long long)tid * E;
         th.core = tid >= a.gl && tid < T - a.gr;
         th.has_sl = tid >= a.gl && tid < T - a.gw;
@@ -209,29 +415,33 @@ struct Limiter3Block {
         Affine r = affine_identity();
         MGX_UNROLL
         for (int j = 0; j < E; ++j) th.sh[j] = 0.f;
-        if (th.has_sl) th.inner = range_max(tid, 15 - a.hw, a.hw, lds);
+        const bool short_sl = short_window(a.hw, a.hw);                       // uniform
+        if (th.has_sl && !short_sl) th.inner = range_max(tid, 15 - a.hw, a.hw, lds);
         if (th.core) {
             const int lw = a.hw + a.hb;
-            window16(tid, lw, a.hw, fmaxf(th.inner, range_max(tid, 15 - lw, 14 - a.hw, lds)), lds, th.sh);
+            if (short_window(lw, a.hw)) window_direct(tid, lw, a.hw, lds, th.sh);
+            else if (short_sl) window16(tid, lw, a.hw, range_max(tid, 15 - lw, a.hw, lds), lds, th.sh);
+            else window16(tid, lw, a.hw, fmaxf(th.inner, range_max(tid, 15 - lw, 14 - a.hw, lds)), lds, th.sh);
             if (!FULL) {
                 MGX_UNROLL
                 for (int j = 0; j < E; ++j)
                     if (j >= valid) th.sh[j] = 0.f;                           // windows are truncated at the array ends
             }
             if (valid > 0)
-                r = Affine{L2::block_decay(a.ph16, a.hold.alpha, valid), (double)L2::run_forward(a.holdf, th.sh, valid, 0.f)};
+                r = Affine{block_decay(a.ph16, a.hold.alpha, valid), (double)run_forward(a.holdf, th.sh, valid, 0.f)};
         }
         return r;
     }
     // ---- P3: sl; block map of the forward attack smoother ------------------------------------------
     template <bool FULL = false>
-    static MGX_HD Affine phase_attack_window(int tid, const Limiter2Args& a, Thread& th, float* lds) {
+    static MGX_HD Affine phase_attack_window(int tid, const LimiterArgs& a, Thread& th, float* lds) {
         const int valid = FULL ? E : th.valid;
         Affine r = affine_identity();
         MGX_UNROLL
         for (int j = 0; j < E; ++j) th.sl[j] = 0.f;
         if (th.has_sl) {
-            window16(tid, a.hw, a.hw, th.inner, lds, th.sl);
+            if (short_window(a.hw, a.hw)) window_direct(tid, a.hw, a.hw, lds, th.sl);
+            else window16(tid, a.hw, a.hw, th.inner, lds, th.sl);
             if (!FULL) {
                 MGX_UNROLL
                 for (int j = 0; j < E; ++j)
@@ -245,11 +455,11 @@ struct Limiter3Block {
                 th.inject_right = valid > 0 && th.base + valid == a.n;
             }
             if (valid > 0) {
-                const double decay = L2::block_decay(a.pa16, a.att.alpha, valid);
-                const double zend = (double)L2::run_forward(a.attf, th.sl, valid, 0.f);
+                const double decay = block_decay(a.pa16, a.att.alpha, valid);
+                const double zend = (double)run_forward(a.attf, th.sl, valid, 0.f);
                 r = Affine{decay, zend};
                 if (!FULL && th.inject_left) {
-                    th.edge_state = L2::filtfilt_left_state(a.att, th.sl);
+                    th.edge_state = filtfilt_left_state(a.att, th.sl);
                     r = Affine{0.0, fma(decay, th.edge_state, zend)};
                 }
             }
@@ -261,10 +471,10 @@ struct Limiter3Block {
     struct Polls {
         unsigned long long v[POLL_SLOTS];
     };
-    static MGX_HD void lookback_publish(long long chunk, int slot, const Limiter2Args& a, double b) {
+    static MGX_HD void lookback_publish(long long chunk, int slot, const LimiterArgs& a, double b) {
         publish_word(a.published + (size_t)slot * a.nchunks + chunk, double_bits(b));
     }
-    static MGX_HD void lookback_ask(int lane, long long chunk, int slot, const Limiter2Args& a, Polls& p) {
+    static MGX_HD void lookback_ask(int lane, long long chunk, int slot, const LimiterArgs& a, Polls& p) {
         const int count = slot == 0 ? a.n_hold : (slot == 1 ? a.n_rel : a.n_att);
         MGX_UNROLL
         for (int k = 0; k < POLL_SLOTS; ++k) {
@@ -275,7 +485,7 @@ struct Limiter3Block {
         }
     }
     // this lane's share of sum_m w[m] * published[chunk-1-m] (the caller adds the 64 shares)
-    static MGX_HD double lookback_take(int lane, long long chunk, int slot, const Limiter2Args& a, Polls& p) {
+    static MGX_HD double lookback_take(int lane, long long chunk, int slot, const LimiterArgs& a, Polls& p) {
         const double* w = slot == 0 ? a.w_hold : (slot == 1 ? a.w_rel : a.w_att);
         const int count = slot == 0 ? a.n_hold : (slot == 1 ? a.n_rel : a.n_att);
         double acc = 0.0;
@@ -323,7 +533,7 @@ struct Limiter3Block {
     // ---- P3: forward attack output from carry `att_now` (zero unless tail chunk); block map of the
     //          backward smoother (right-to-left scan).  `p0` = forward attack prefix of this thread.
     template <bool FULL = false>
-    static MGX_HD Affine phase_attack_forward(int tid, const Limiter2Args& a, Thread& th, Affine p0, double att_now,
+    static MGX_HD Affine phase_attack_forward(int tid, const LimiterArgs& a, Thread& th, Affine p0, double att_now,
                                               const float* lds) {
         Affine r = affine_identity();
         const int valid = FULL ? E : th.valid;
@@ -333,13 +543,13 @@ struct Limiter3Block {
         if (th.has_sl) {
             double c = affine_apply(p0, att_now);
             if (!FULL && th.inject_left) c = th.edge_state;
-            const float zend = L2::out_forward(a.attf, th.sl, valid, (float)c, th.yf);
+            const float zend = out_forward(a.attf, th.sl, valid, (float)c, th.yf);
             if (valid > 0) {
-                const double decay = L2::block_decay(a.pa16, a.att.alpha, valid);
-                const double zb = (double)L2::run_backward(a.attf, th.yf, valid, 0.f);
+                const double decay = block_decay(a.pa16, a.att.alpha, valid);
+                const double zb = (double)run_backward(a.attf, th.yf, valid, 0.f);
                 r = Affine{decay, zb};
                 if (!FULL && th.inject_right) {
-                    th.edge_state = L2::filtfilt_right_state(a.att, edge_sl(const_cast<float*>(lds)) + 7, (double)zend);
+                    th.edge_state = filtfilt_right_state(a.att, edge_sl(const_cast<float*>(lds)) + 7, (double)zend);
                     r = Affine{0.0, fma(decay, th.edge_state, zb)};
                 }
             }
@@ -348,13 +558,13 @@ struct Limiter3Block {
     }
     // ---- P4: backward attack output (carry-free part).  `pb` = composition of the blocks to the right
     template <bool FULL = false>
-    static MGX_HD void phase_attack_backward(int tid, const Limiter2Args& a, Thread& th, Affine pb) {
+    static MGX_HD void phase_attack_backward(int tid, const LimiterArgs& a, Thread& th, Affine pb) {
         MGX_UNROLL
         for (int j = 0; j < E; ++j) th.yb[j] = 0.f;
         if (!th.core) return;
         double cb = affine_apply(pb, 0.0);
         if (!FULL && th.inject_right) cb = th.edge_state;
-        L2::out_backward(a.attf, th.yf, FULL ? E : th.valid, (float)cb, th.yb);
+        out_backward(a.attf, th.yf, FULL ? E : th.valid, (float)cb, th.yb);
     }
     // kappa of the file header
     static MGX_HD double attack_kappa(const Iir1& f) { return f.b0 + f.beta * f.alpha / (1.0 - f.alpha * f.alpha); }
@@ -362,14 +572,14 @@ struct Limiter3Block {
     // ---- P5: carries have arrived.  Exact hold output, attack carry term, max(sh, ho) -> block map of
     //          the release filter.  att_deferred = the attack carry not yet applied (0 in a tail chunk)
     template <bool FULL = false>
-    static MGX_HD Affine phase_hold(int tid, const Limiter2Args& a, Thread& th, double hold_carry, double att_deferred) {
+    static MGX_HD Affine phase_hold(int tid, const LimiterArgs& a, Thread& th, double hold_carry, double att_deferred) {
         Affine r = affine_identity();
         const int valid = FULL ? E : th.valid;
         MGX_UNROLL
         for (int j = 0; j < E; ++j) { th.x2[j] = 0.f; th.mx[j] = 0.f; }
         if (!th.core) return r;
         float pw = (float)(att_deferred * attack_kappa(a.att) * th.att_decay);
-        // hold output (L2::out_forward inlined so that sh[j], yb[j] die as x2[j], mx[j] are born)
+        // hold output (out_forward inlined so that sh[j], yb[j] die as x2[j], mx[j] are born)
         float z = (float)affine_apply(th.hold_pre, hold_carry);
         MGX_UNROLL
         for (int j = 0; j < E; ++j) {
@@ -382,13 +592,13 @@ struct Limiter3Block {
             th.mx[j] = fmaxf(ho, ga);
         }
         if (valid > 0)
-            r = Affine{L2::block_decay(a.pr16, a.rel.alpha, valid), (double)L2::run_forward(a.relf, th.x2, valid, 0.f)};
+            r = Affine{block_decay(a.pr16, a.rel.alpha, valid), (double)run_forward(a.relf, th.x2, valid, 0.f)};
         return r;
     }
 
     // ---- P6: release output -> gain -> plane ---------------------------------------------------------
     template <bool FULL = false>
-    static MGX_HD void phase_gain(int tid, const Limiter2Args& a, Thread& th, Affine pr, double rel_carry, float* lds) {
+    static MGX_HD void phase_gain(int tid, const LimiterArgs& a, Thread& th, Affine pr, double rel_carry, float* lds) {
         if (!th.core) return;
         const int valid = FULL ? E : th.valid;
         float z = (float)affine_apply(pr, rel_carry);
@@ -402,46 +612,9 @@ struct Limiter3Block {
         }
     }
 
-    // ---- P7 split in two (experiment): the frames of the store phase are asked for before the release
-    //      look-back is waited for, so that the two latencies overlap; interior chunks only.
-    struct Frames {
-        float4 q[E / 2];
-    };
-    static MGX_HD bool interior_chunk(long long chunk, const Limiter2Args& a) {
-        const long long r0 = region_start(chunk, a);
-        return r0 >= 0 && r0 + FRAMES <= a.n;
-    }
-    static MGX_HD void fetch_frames(int tid, long long chunk, const Limiter2Args& a, Frames& fr) {
-        const long long r0 = region_start(chunk, a);
-        const long long c0 = r0 + (long long)a.gl * E, c1 = r0 + (long long)(T - a.gr) * E;
-        MGX_UNROLL
-        for (int j = 0; j < E / 2; ++j) {
-            const long long f = r0 + 2 * tid + 2 * T * j;
-            fr.q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f >= c0 && f < c1) fr.q[j] = *reinterpret_cast<const float4*>(a.y + f);
-        }
-    }
-    static MGX_HD void phase_store_held(int tid, long long chunk, const Limiter2Args& a, const Frames& fr, const float* lds) {
-        const long long r0 = region_start(chunk, a);
-        const long long c0 = r0 + (long long)a.gl * E, c1 = r0 + (long long)(T - a.gr) * E;
-        const float g = (float)*a.gain, post = (float)*a.post_gain;
-        const float* gn = plane(const_cast<float*>(lds));
-        MGX_UNROLL
-        for (int j = 0; j < E / 2; ++j) {
-            const int i = 2 * tid + 2 * T * j;
-            const long long f = r0 + i;
-            if (f < c0 || f >= c1) continue;
-            const float4 q = fr.q[j];
-            const float2 v0 = scaled(make_float2(q.x, q.y), g), v1 = scaled(make_float2(q.z, q.w), g);
-            const float s0 = own_gain(v0, gn[gidx(i)], true, a.threshold) * post;
-            const float s1 = own_gain(v1, gn[gidx(i + 1)], true, a.threshold) * post;
-            st_stream(reinterpret_cast<float4*>(a.out + f), make_float4(v0.x * s0, v0.y * s0, v1.x * s1, v1.y * s1));
-        }
-    }
-
     // ---- P7: coalesced reload, apply gain, store ---------------------------------------------------
     template <bool FULL = false>
-    static MGX_HD void phase_store(int tid, long long chunk, const Limiter2Args& a, bool with_gain, const float* lds) {
+    static MGX_HD void phase_store(int tid, long long chunk, const LimiterArgs& a, bool with_gain, const float* lds) {
         const long long r0 = region_start(chunk, a);
         const long long c0 = r0 + (long long)a.gl * E, c1 = r0 + (long long)(T - a.gr) * E;
         const bool interior = FULL || (r0 >= 0 && r0 + FRAMES <= a.n);

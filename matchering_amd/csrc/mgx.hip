@@ -569,40 +569,15 @@ static int limiter_state(mgx_handle* h, long long n, const mgx_config* cfg, unsi
     return 0;
 }
 
-// which limiter kernel a launch uses: the third-generation kernel compiled for 6 workgroups per CU;
-// MGX_LIMITER = 2 | 3w4 | 3w5 | 3w6 selects another build for A/B timing (tools/bench_limiter.py)
-static int launch_limiter(mgx_handle* h, const Limiter2Args& a) {
-    const char* which = std::getenv("MGX_LIMITER");
-    const std::string w = which ? which : "3w4";
-    if (w == "2") {
-        const size_t lds = Limiter2Block::LDS_BYTES;
-        MGX_TRY(allow_lds(k_limit, lds));
-        hipLaunchKernelGGL(k_limit, dim3((unsigned)a.nchunks), dim3(Limiter2Block::T), lds, h->stream, a);
+// 256-block chunks (four workgroups per CU) unless the configured attack / hold times need 1024
+static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
+    const dim3 grid((unsigned)a.nchunks);
+    if (threads == 1024) {
+        const size_t lds = LimiterBlock<1024>::LDS_BYTES;
+        MGX_TRY((allow_lds(k_limit<1024, 1>, lds)));
+        hipLaunchKernelGGL((k_limit<1024, 1>), grid, dim3(1024), lds, h->stream, a);
     } else {
-        size_t lds = Limiter3Block::LDS_BYTES;
-        if (const char* pad = std::getenv("MGX_LIM_LDS_PAD")) lds += (size_t)std::atoi(pad);   // occupancy experiments
-        const dim3 grid((unsigned)a.nchunks), block(Limiter3Block::T);
-        if (w == "3w5") hipLaunchKernelGGL((k_limit3<5, false>), grid, block, lds, h->stream, a);
-        else if (w == "3w4p") hipLaunchKernelGGL((k_limit3<4, true>), grid, block, lds, h->stream, a);
-        else if (w == "3w5p") hipLaunchKernelGGL((k_limit3<5, true>), grid, block, lds, h->stream, a);
-        else if (w == "3w6p") hipLaunchKernelGGL((k_limit3<6, true>), grid, block, lds, h->stream, a);
-        else if (w[1] == 'p') {          // persistent: as many workgroups as the chip holds
-            int cus = 256;
-            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-            const int per = w == "3p3" ? 3 : (w == "3p5" ? 5 : 4);
-            const dim3 pg((unsigned)std::min<long long>(a.nchunks, (long long)cus * per));
-            if (w == "3p3") { MGX_TRY((allow_lds(k_limit3p<3>, lds))); hipLaunchKernelGGL((k_limit3p<3>), pg, block, lds, h->stream, a); }
-            else if (w == "3p5") hipLaunchKernelGGL((k_limit3p<5>), pg, block, lds, h->stream, a);
-            else if (w == "3p4p") hipLaunchKernelGGL((k_limit3p<4, true>), pg, block, lds, h->stream, a);
-            else if (w == "3p4a1") hipLaunchKernelGGL((k_limit3p<4, false, 1>), pg, block, lds, h->stream, a);
-            else if (w == "3p4a2") hipLaunchKernelGGL((k_limit3p<4, false, 2>), pg, block, lds, h->stream, a);
-            else hipLaunchKernelGGL((k_limit3p<4>), pg, block, lds, h->stream, a);
-        }
-        else if (w == "3w4a1") hipLaunchKernelGGL((k_limit3<4, false, 1>), grid, block, lds, h->stream, a);
-        else if (w == "3w4a2") hipLaunchKernelGGL((k_limit3<4, false, 2>), grid, block, lds, h->stream, a);
-        else if (w == "3w8a2") hipLaunchKernelGGL((k_limit3<8, false, 2>), grid, block, lds, h->stream, a);
-        else if (w == "3w6") hipLaunchKernelGGL((k_limit3<6, false>), grid, block, lds, h->stream, a);
-        else hipLaunchKernelGGL((k_limit3<4, false>), grid, block, lds, h->stream, a);
+        hipLaunchKernelGGL((k_limit<256, 4>), grid, dim3(256), LimiterBlock<256>::LDS_BYTES, h->stream, a);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -610,12 +585,13 @@ static int launch_limiter(mgx_handle* h, const Limiter2Args& a) {
 
 // everything of a limiter launch but the look-back words, ticket and error flag
 static int limiter_args(mgx_handle* h, const float* y, long long n, const mgx_config* cfg, const double* gain_dev,
-                        const double* post_dev, const int* active_dev, float* out, Limiter2Args& a) {
+                        const double* post_dev, const int* active_dev, float* out, LimiterArgs& a, int* threads) {
     LimiterParams lp;
     const std::string err = limiter_params(*cfg, lp);
     if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
     if (n < 8) return fail(MGX_ERR_ARGUMENT, "limiter input too short");
     limiter_fill(lp, (float)cfg->threshold, a);
+    *threads = lp.threads;
     a.y = reinterpret_cast<const float2*>(y);
     a.n = n;
     a.out = reinterpret_cast<float2*>(out);
@@ -643,8 +619,9 @@ static int limiter_args(mgx_handle* h, const float* y, long long n, const mgx_co
 // preset_done: the caller's previous kernel has already preset the look-back words and the ticket
 static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_config* cfg, const double* gain_dev,
                        const double* post_dev, const int* active_dev, float* out, bool preset_done = false) {
-    Limiter2Args a;
-    MGX_TRY(limiter_args(h, y, n, cfg, gain_dev, post_dev, active_dev, out, a));
+    LimiterArgs a;
+    int threads = 256;
+    MGX_TRY(limiter_args(h, y, n, cfg, gain_dev, post_dev, active_dev, out, a, &threads));
     // published words preset to "unpublished", ticket and error zeroed, every launch
     const size_t pub_bytes = (size_t)3 * a.nchunks * sizeof(unsigned long long);
     MGX_TRY(ensure(h, h->lim_published, pub_bytes));
@@ -656,7 +633,7 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
         HIP_TRY(hipMemsetAsync(h->lim_published.p, 0xff, pub_bytes, h->stream));
         HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 4, h->stream));   // ticket only: a raised error sticks
     }
-    return launch_limiter(h, a);
+    return launch_limiter(h, a, threads);
 }
 
 // a look-back wait expired (never seen; the spin is bounded so that a lost chunk cannot hang the GPU)

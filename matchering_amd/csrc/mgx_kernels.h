@@ -9,8 +9,7 @@
 #include "analysis2_kernel.h"
 #include "conv2_kernel.h"
 #include "fir_plan.h"
-#include "limiter2_kernel.h"
-#include "limiter3_kernel.h"
+#include "limiter_kernel.h"
 
 namespace mgx {
 
@@ -1445,7 +1444,7 @@ __global__ __launch_bounds__(256) void k_frame_peaks(const float2* x, long long 
 }
 
 // ---------------------------------------------------------------------------
-// limiter (limiter2_kernel.h): one launch, grid = chunks
+// limiter (limiter_kernel.h): one launch, grid = chunks
 // ---------------------------------------------------------------------------
 // Ordered composition of affine maps across a workgroup: inclusive scan over the 64 lanes of each
 // wave by shuffles (scan order = lane order, or reversed), wave totals through LDS, then every
@@ -1490,68 +1489,6 @@ __device__ __forceinline__ Affine compose_waves(const Affine* totals, Affine exc
     return affine_then(before, exclusive_in_wave);
 }
 
-__global__ __launch_bounds__(Limiter2Block::T, 4) void k_limit(Limiter2Args a) {
-    using LB = Limiter2Block;
-    MGX_LDS;
-    float* lds = reinterpret_cast<float*>(mgx_smem);
-    int& ticket = *reinterpret_cast<int*>(LB::scalars(lds) + 4);      // dynamic LDS only (16-byte aligned base)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool active = a.active ? (*a.active != 0) : true;
-    if (!active) {                       // hyrax.py:83-85: the array passes through, then stages.py:203
-        LB::phase_store(tid, blockIdx.x, a, false, lds);
-        return;
-    }
-    if (tid == 0) ticket = atomicAdd(a.ticket, 1);
-    __syncthreads();
-    const long long chunk = ticket;
-    LB::Thread th;
-    LB::phase_load(opaque(tid), chunk, a, lds);
-    __syncthreads();
-    LB::phase_planes(opaque(tid), chunk, a, th, lds);
-    __syncthreads();
-
-    // round 1: forward attack smoother (scan 0) and hold filter (scan 1)
-    const LB::ScanIn in1 = LB::phase_windows(opaque(tid), a, th, lds);
-    Affine i0 = wave_inclusive<false>(in1.m0), i1 = wave_inclusive<false>(in1.m1);
-    if (lane == 63) { LB::wave_totals(lds, 0, 0)[wave] = i0; LB::wave_totals(lds, 0, 1)[wave] = i1; }
-    Affine e0 = wave_exclusive<false>(i0), e1 = wave_exclusive<false>(i1);
-    __syncthreads();
-    LB::ScanOut pre;
-    Affine whole;
-    pre.p0 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 0, 0), e0, nullptr);
-    pre.p1 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 0, 1), e1, &whole);
-    if (tid == LB::T - a.gr) LB::lookback_publish(chunk, 2, a, pre.p0.b);      // attack state at the end of the core
-    if (tid == 0) LB::lookback_publish(chunk, 0, a, whole.b);
-    if (wave < 2) {                      // wave 0 gathers the hold carry, wave 1 the attack carry
-        const int slot = wave == 0 ? 0 : 2;
-        const double s = wave_sum(LB::lookback_share(lane, chunk, slot, a));
-        if (lane == 0) LB::scalars(lds)[slot] = s;
-    }
-    __syncthreads();
-
-    // round 2: backward attack smoother, right to left (scan 0), and release filter (scan 1)
-    const LB::ScanIn in2 = LB::phase_exact_first(opaque(tid), a, th, pre, LB::scalars(lds)[2], LB::scalars(lds)[0], lds);
-    i0 = wave_inclusive<true>(in2.m0);
-    i1 = wave_inclusive<false>(in2.m1);
-    if (lane == 0) LB::wave_totals(lds, 1, 0)[wave] = i0;
-    if (lane == 63) LB::wave_totals(lds, 1, 1)[wave] = i1;
-    e0 = wave_exclusive<true>(i0);
-    e1 = wave_exclusive<false>(i1);
-    __syncthreads();
-    pre.p0 = compose_waves<true, LB::WAVES>(LB::wave_totals(lds, 1, 0), e0, nullptr);
-    pre.p1 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 1, 1), e1, &whole);
-    if (tid == 0) LB::lookback_publish(chunk, 1, a, whole.b);
-    if (wave == 0) {
-        const double s = wave_sum(LB::lookback_share(lane, chunk, 1, a));
-        if (lane == 0) LB::scalars(lds)[1] = s;
-    }
-    __syncthreads();
-    LB::phase_gain(opaque(tid), a, th, pre, LB::scalars(lds)[1], lds);
-    __syncthreads();
-    LB::phase_store(opaque(tid), chunk, a, true, lds);
-}
-
-// ---- third generation (limiter3_kernel.h): one LDS plane, six workgroups per CU ----------------
 // maximum over the eight lanes that share lane >> 3 (non-negative values): three DPP steps
 __device__ __forceinline__ float dpp_max8(float v) {
     int x = __float_as_int(v);
@@ -1562,16 +1499,15 @@ __device__ __forceinline__ float dpp_max8(float v) {
 }
 
 // one chunk, from the load phase to the store; FULL = the chunk lies strictly inside the track
-// ABL (timing experiments only, results are wrong): 1 = carries taken as zero, nothing waited for;
-// 2 = load, plane and store phases only
-template <bool FULL, bool PF, int ABL = 0>
-__device__ __forceinline__ void limit3_chunk(const Limiter2Args& a, long long chunk, float* lds) {
-    using LB = Limiter3Block;
+// one chunk, from the load phase to the store; FULL = the chunk lies strictly inside the track
+template <int T, bool FULL>
+__device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chunk, float* lds) {
+    using LB = LimiterBlock<T>;
     // (opaque: nothing derived from the thread id may be hoisted out of a persistent caller's loop)
     const int tid = opaque((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
     {
         float pm[LB::E / 2];
-        LB::phase_load<FULL>(opaque(tid), chunk, a, lds, pm);
+        LB::template phase_load<FULL>(opaque(tid), chunk, a, lds, pm);
 #pragma unroll
         for (int j = 0; j < LB::E / 2; ++j) {
             const float m = dpp_max8(pm[j]);
@@ -1579,16 +1515,12 @@ __device__ __forceinline__ void limit3_chunk(const Limiter2Args& a, long long ch
         }
     }
     __syncthreads();
-    if (ABL == 2) {
-        LB::phase_store<FULL>(opaque(tid), chunk, a, true, lds);
-        return;
-    }
 
     // hold filter first (scan 1): its aggregate is published as early as possible
-    LB::Thread th;
+    typename LB::Thread th;
     Affine whole;
     {
-        const Affine m1 = LB::phase_hold_window<FULL>(opaque(tid), chunk, a, th, lds);
+        const Affine m1 = LB::template phase_hold_window<FULL>(opaque(tid), chunk, a, th, lds);
         const Affine i1 = wave_inclusive<false>(m1);
         if (lane == 63) LB::wave_totals(lds, 1)[wave] = i1;
         const Affine e1 = wave_exclusive<false>(i1);
@@ -1597,12 +1529,12 @@ __device__ __forceinline__ void limit3_chunk(const Limiter2Args& a, long long ch
     }
     if (tid == 0) LB::lookback_publish(chunk, 0, a, whole.b);
     // ask for the predecessors' words now, take them after the attack path (wave 0: hold, wave 1: attack)
-    LB::Polls polls;
-    if (ABL == 0 && wave == 0) LB::lookback_ask(lane, chunk, 0, a, polls);
+    typename LB::Polls polls;
+    if (wave == 0) LB::lookback_ask(lane, chunk, 0, a, polls);
     // forward attack smoother (scan 0)
     Affine p0;
     {
-        const Affine m0 = LB::phase_attack_window<FULL>(opaque(tid), a, th, lds);
+        const Affine m0 = LB::template phase_attack_window<FULL>(opaque(tid), a, th, lds);
         const Affine i0 = wave_inclusive<false>(m0);
         if (lane == 63) LB::wave_totals(lds, 0)[wave] = i0;
         const Affine e0 = wave_exclusive<false>(i0);
@@ -1610,10 +1542,10 @@ __device__ __forceinline__ void limit3_chunk(const Limiter2Args& a, long long ch
         p0 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 0), e0, nullptr);
     }
     if (tid == LB::T - a.gr) LB::lookback_publish(chunk, 2, a, p0.b);          // attack state at the end of the core
-    if (ABL == 0 && wave == 1) LB::lookback_ask(lane, chunk, 2, a, polls);
+    if (wave == 1) LB::lookback_ask(lane, chunk, 2, a, polls);
     const bool tail = !FULL && LB::tail_chunk(chunk, a);                        // uniform
     double att_now = 0.0;
-    if (ABL == 0 && tail) {
+    if (tail) {
         if (wave == 1) {
             const double s = wave_sum(LB::lookback_take(lane, chunk, 2, a, polls));
             if (lane == 0) LB::scalars(lds)[2] = s;
@@ -1623,55 +1555,50 @@ __device__ __forceinline__ void limit3_chunk(const Limiter2Args& a, long long ch
     }
 
     // backward attack smoother, right to left (scan 2)
-    const Affine mb = LB::phase_attack_forward<FULL>(opaque(tid), a, th, p0, att_now, lds);
+    const Affine mb = LB::template phase_attack_forward<FULL>(opaque(tid), a, th, p0, att_now, lds);
     const Affine ib = wave_inclusive<true>(mb);
     if (lane == 0) LB::wave_totals(lds, 2)[wave] = ib;
     const Affine eb = wave_exclusive<true>(ib);
     __syncthreads();
     const Affine pb = compose_waves<true, LB::WAVES>(LB::wave_totals(lds, 2), eb, nullptr);
-    LB::phase_attack_backward<FULL>(opaque(tid), a, th, pb);
-    if (ABL != 0 && tid == 0) { LB::scalars(lds)[0] = 0.0; LB::scalars(lds)[1] = 0.0; LB::scalars(lds)[2] = 0.0; }
-    if (ABL == 0 && wave == 0) {
+    LB::template phase_attack_backward<FULL>(opaque(tid), a, th, pb);
+    if (wave == 0) {
         const double s = wave_sum(LB::lookback_take(lane, chunk, 0, a, polls));
         if (lane == 0) LB::scalars(lds)[0] = s;
     }
-    if (ABL == 0 && wave == 1 && !tail) {
+    if (wave == 1 && !tail) {
         const double s = wave_sum(LB::lookback_take(lane, chunk, 2, a, polls));
         if (lane == 0) LB::scalars(lds)[2] = s;
     }
     __syncthreads();
 
     // hold output, release filter (scan 3)
-    const Affine mr = LB::phase_hold<FULL>(opaque(tid), a, th, LB::scalars(lds)[0], tail ? 0.0 : LB::scalars(lds)[2]);
+    const Affine mr = LB::template phase_hold<FULL>(opaque(tid), a, th, LB::scalars(lds)[0], tail ? 0.0 : LB::scalars(lds)[2]);
     const Affine ir = wave_inclusive<false>(mr);
     if (lane == 63) LB::wave_totals(lds, 3)[wave] = ir;
     const Affine er = wave_exclusive<false>(ir);
     __syncthreads();
     const Affine pr = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 3), er, &whole);
     if (tid == 0) LB::lookback_publish(chunk, 1, a, whole.b);
-    if (ABL == 0 && wave == 0) LB::lookback_ask(lane, chunk, 1, a, polls);
-    LB::Frames fr;
-    constexpr bool held = PF && FULL;
-    if (held) LB::fetch_frames(opaque(tid), chunk, a, fr);
-    if (ABL == 0 && wave == 0) {
+    if (wave == 0) LB::lookback_ask(lane, chunk, 1, a, polls);
+    if (wave == 0) {
         const double s = wave_sum(LB::lookback_take(lane, chunk, 1, a, polls));
         if (lane == 0) LB::scalars(lds)[1] = s;
     }
     __syncthreads();
-    LB::phase_gain<FULL>(opaque(tid), a, th, pr, LB::scalars(lds)[1], lds);
+    LB::template phase_gain<FULL>(opaque(tid), a, th, pr, LB::scalars(lds)[1], lds);
     __syncthreads();
-    if (held) LB::phase_store_held(opaque(tid), chunk, a, fr, lds);
-    else LB::phase_store<FULL>(opaque(tid), chunk, a, true, lds);
+    LB::template phase_store<FULL>(opaque(tid), chunk, a, true, lds);
 }
 
-// WGS = workgroups per CU the kernel is compiled for (register budget 512 / WGS per lane)
-// PF (experiment) = ask for the store phase's frames before waiting for the release look-back
-template <int WGS, bool PF = false, int ABL = 0>
-__global__ __launch_bounds__(Limiter3Block::T, WGS) void k_limit3(Limiter2Args a) {
-    using LB = Limiter3Block;
+// T = threads = 16-frame blocks per chunk (256, or 1024 for long attack / hold times); WGS = workgroups
+// per CU the kernel is compiled for (register budget 512 / (WGS * T / 256) per lane)
+template <int T, int WGS>
+__global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a) {
+    using LB = LimiterBlock<T>;
     MGX_LDS;
     float* lds = reinterpret_cast<float*>(mgx_smem);
-    int& ticket = *reinterpret_cast<int*>(LB::scalars(lds) + 4);
+    int& ticket = *reinterpret_cast<int*>(LB::scalars(lds) + 4);      // dynamic LDS only (16-byte aligned base)
     const int tid = threadIdx.x;
     const bool active = a.active ? (*a.active != 0) : true;
     if (!active) {                       // hyrax.py:83-85: the array passes through, then stages.py:203
@@ -1681,38 +1608,8 @@ __global__ __launch_bounds__(Limiter3Block::T, WGS) void k_limit3(Limiter2Args a
     if (tid == 0) ticket = atomicAdd(a.ticket, 1);
     __syncthreads();
     const long long chunk = ticket;
-    if (LB::full_chunk(chunk, a)) limit3_chunk<true, PF, ABL>(a, chunk, lds);
-    else limit3_chunk<false, PF, ABL>(a, chunk, lds);
-}
-
-// Persistent form: as many workgroups as the chip holds, each drawing chunk after chunk from the
-// ticket counter.  The next ticket is asked for when a chunk starts and read when it ends, so its
-// round trip to the L2 (1-3 us under load) no longer stands in front of every chunk's loads.
-template <int WGS, bool PF = false, int ABL = 0>
-__global__ __launch_bounds__(Limiter3Block::T, WGS) void k_limit3p(Limiter2Args a) {
-    using LB = Limiter3Block;
-    MGX_LDS;
-    float* lds = reinterpret_cast<float*>(mgx_smem);
-    int& ticket = *reinterpret_cast<int*>(LB::scalars(lds) + 4);
-    const int tid = threadIdx.x;
-    const bool active = a.active ? (*a.active != 0) : true;
-    if (!active) {
-        for (long long c = blockIdx.x; c < a.nchunks; c += gridDim.x) LB::phase_store(tid, c, a, false, lds);
-        return;
-    }
-    if (tid == 0) ticket = atomicAdd(a.ticket, 1);
-    __syncthreads();
-    long long chunk = ticket;
-    while (chunk < a.nchunks) {
-        int next = 0;
-        if (tid == 0) next = atomicAdd(a.ticket, 1);
-        if (LB::full_chunk(chunk, a)) limit3_chunk<true, PF, ABL>(a, chunk, lds);
-        else limit3_chunk<false, PF, ABL>(a, chunk, lds);
-        __syncthreads();                 // the store phase has read the gain plane; the ticket slot is free
-        if (tid == 0) ticket = next;
-        __syncthreads();
-        chunk = ticket;
-    }
+    if (LB::full_chunk(chunk, a)) limit_chunk<T, true>(a, chunk, lds);
+    else limit_chunk<T, false>(a, chunk, lds);
 }
 
 }  // namespace mgx

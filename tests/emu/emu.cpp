@@ -15,7 +15,6 @@
 #include "../../matchering_amd/csrc/conv2_kernel.h"
 #include "../../matchering_amd/csrc/fir_design.h"
 #include "../../matchering_amd/csrc/host_params.h"
-#include "../../matchering_amd/csrc/limiter3_kernel.h"
 
 using namespace mgx;
 
@@ -262,12 +261,11 @@ extern "C" int emu_analyze(const float* x, long long n, const mgx_config* cfg, i
 }
 
 // ---------------------------------------------------------------------------
-extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, double gain, double post_gain,
-                         float* out, float* dbg_sl, float* dbg_sh) {
-    LimiterParams lp;
-    if (!limiter_params(*cfg, lp).empty()) return -1;
-    using LB = Limiter3Block;
-    Limiter2Args a;
+template <int T>
+static int limit_impl(const LimiterParams& lp, const float* x, long long n, const mgx_config* cfg, double gain,
+                      double post_gain, float* out, float* dbg_sl, float* dbg_sh) {
+    using LB = LimiterBlock<T>;
+    LimiterArgs a;
     limiter_fill(lp, (float)cfg->threshold, a);
     a.y = reinterpret_cast<const float2*>(x);
     a.n = n;
@@ -285,7 +283,7 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
     a.ticket = &ctrl[0];
     a.error = &ctrl[1];
     std::vector<float> lds(LB::LDS_BYTES / 4 + 8);
-    std::vector<LB::Thread> th(LB::T);
+    std::vector<typename LB::Thread> th(LB::T);
     std::vector<Affine> in0(LB::T), in1(LB::T), pre0(LB::T), pre1(LB::T);
     // the workgroup scans of the device kernel (wave shuffles there), as plain ordered loops
     auto scan = [&](const std::vector<Affine>& in, std::vector<Affine>& pre, bool reverse) {
@@ -300,7 +298,7 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
     auto carry = [&](long long chunk, int slot) {
         double s = 0.0;
         for (int lane = 0; lane < 64; ++lane) {
-            LB::Polls p;
+            typename LB::Polls p;
             LB::lookback_ask(lane, chunk, slot, a, p);
             s += LB::lookback_take(lane, chunk, slot, a, p);
         }
@@ -347,6 +345,14 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
         FOR_THREADS(LB::T) LB::phase_store(tid, chunk, a, true, lds.data());
     }
     return ctrl[1] ? -2 : 0;
+}
+
+extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, double gain, double post_gain,
+                         float* out, float* dbg_sl, float* dbg_sh) {
+    LimiterParams lp;
+    if (!limiter_params(*cfg, lp).empty()) return -1;
+    if (lp.threads == 1024) return limit_impl<1024>(lp, x, n, cfg, gain, post_gain, out, dbg_sl, dbg_sh);
+    return limit_impl<256>(lp, x, n, cfg, gain, post_gain, out, dbg_sl, dbg_sh);
 }
 
 // host FIR design (product code, re-exported here so the CPU tests need no HIP runtime)

@@ -201,6 +201,39 @@ def test_limiter_phases(emu, name):
     assert np.abs(out - want).max() <= 5e-6
 
 
+# attack / hold times at the edges of the chunk geometry: windows of a few samples (read out frame by
+# frame), windows just over and under the 15-frame split, halos that need the 1024-block chunks
+ODD_LIMITERS = [
+    dict(sr=44100, attack=0.1, hold=0.1),          # 4-sample attack (window 9), 4-sample hold
+    dict(sr=8000, attack=0.3, hold=0.5),           # attack 2 samples -> window 5; hold 4
+    dict(sr=8000, attack=1.0, hold=1.0),           # attack 8 -> half window 8: the split form at its shortest
+    dict(sr=44100, attack=0.18, hold=3.0),         # short attack window inside a long hold window
+    dict(sr=44100, attack=8.0, hold=2.0),          # halos of ~220 blocks: 1024-block chunks
+    dict(sr=96000, attack=3.0, hold=12.0),         # the same at 96 kHz, long hold
+]
+
+
+@pytest.mark.parametrize("lim", ODD_LIMITERS)
+def test_limiter_unusual_attack_and_hold_times(emu, lim):
+    import matchering_amd as mg
+    from matchering_amd.synth import synth
+
+    sr = lim["sr"]
+    kw = dict(attack=lim["attack"], hold=lim["hold"])
+    x = synth(1.2 if sr > 50000 else 2.0, sr, 9).astype(np.float64)
+    x *= 1.5 / np.abs(x).max()
+    y = np.ascontiguousarray(x, dtype=np.float32)
+    cfg = mg.Config(internal_sample_rate=sr, limiter=mg.LimiterConfig(**kw))
+    native = cfg.to_native()
+    out = np.zeros_like(y)
+    rc = emu.emu_limit(_fp(y), ctypes.c_longlong(y.shape[0]), ctypes.byref(native), ctypes.c_double(1.0),
+                       ctypes.c_double(1.0), _fp(out), None, None)
+    assert rc == 0
+    want = mo.limit(y.astype(np.float64), mo.params(internal_sample_rate=sr, **kw))
+    assert rms_error(out, want) <= 1e-6
+    assert np.abs(out - want).max() <= 5e-6
+
+
 def test_limiter_lookback_across_many_chunks(emu):
     """Default 44.1 kHz limiter on 14 s of hot material: ~85 chunks, so the release filter's carry
     is a truncated look-back over ~70 predecessor chunks and the hold filter's over 3."""

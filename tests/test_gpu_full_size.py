@@ -103,11 +103,29 @@ def test_eight_4min_pairs_in_two_lanes_match_the_oracle():
 
     pairs = [make_pair(240.0, 44100, pair=b) for b in range(8)]
     many = batch.master_many(pairs, mg.Config(), need_default=True, lanes=2)
-    for b in (0, 5):                                   # the oracle takes seconds per pair: spot-check two
+    for b in range(8):                                 # every pair against the oracle (~5 s of CPU each)
         want = mo.master(pairs[b][0], pairs[b][1], mo.params(), True, False, False)[0]
         assert rms_error(many[b][0], want) <= RMS_TOL
     thr = mg.Config().threshold
     assert all(np.abs(m[0]).max() <= thr * (1 + 1e-5) for m in many)
+
+
+def test_96k_16k_tap_pair_at_full_size_against_the_oracle():
+    """BASELINE config #5 at its full size: a four-minute 96 kHz pair (23.04 M frames, 17 pieces) with a
+    16384-tap matching FIR -- the partitioned overlap-save path and the 16384-point analysis -- and the
+    limiter at 96 kHz (attack window 193 frames)."""
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd.synth import make_pair
+
+    t, r = make_pair(240.0, 96000, pair=5)
+    kw = dict(internal_sample_rate=96000, fft_size=16384)
+    got = stages.main(t, r, mg.Config(**kw), need_default=True, need_no_limiter=True)
+    want = mo.master(t, r, mo.params(**kw), True, True, False)
+    for mine, ref in zip(got[:2], want[:2]):
+        assert rms_error(mine, ref) <= RMS_TOL
+        assert np.abs(mine - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(got[0]).max() <= mg.Config(**kw).threshold * (1 + 1e-5)
 
 
 def test_maximum_length_15min_against_the_oracle():

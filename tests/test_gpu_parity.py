@@ -228,6 +228,32 @@ def test_limiter_stage(name, oracle_runs):
     assert np.abs(out[:64] - want[:64]).max() <= 1e-6 and np.abs(out[-64:] - want[-64:]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("lim", [
+    dict(sr=44100, attack=0.1, hold=0.1),          # windows of a few samples, read out frame by frame
+    dict(sr=8000, attack=1.0, hold=1.0),           # half window 8: the split form at its shortest
+    dict(sr=44100, attack=0.18, hold=3.0),
+    dict(sr=44100, attack=8.0, hold=2.0),          # halos of ~220 blocks: the 1024-block chunks
+    dict(sr=96000, attack=3.0, hold=12.0),
+])
+def test_limiter_unusual_attack_and_hold_times(lim):
+    """LimiterConfig accepts any positive attack / hold (defaults.py:39-46): the kernel's chunk geometry
+    follows (limiter_kernel.h), checked here against hyrax.py:78-99 restated."""
+    import matchering_amd as mg
+    from matchering_amd import kernels
+    from matchering_amd.synth import synth
+
+    sr = lim["sr"]
+    kw = dict(attack=lim["attack"], hold=lim["hold"])
+    x = synth(3.0, sr, 9).astype(np.float64)
+    x *= 1.5 / np.abs(x).max()
+    y = x.astype(np.float32)
+    out, active = kernels.limit(y, mg.Config(internal_sample_rate=sr, limiter=mg.LimiterConfig(**kw)))
+    want = mo.limit(y.astype(np.float64), mo.params(internal_sample_rate=sr, **kw))
+    assert active
+    assert rms_error(out, want) <= 1e-6
+    assert np.abs(out - want).max() <= 5e-6
+
+
 def test_clipped_piece_sumsq():
     from matchering_amd import kernels
 
