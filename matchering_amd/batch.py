@@ -60,7 +60,9 @@ class _Lanes:
     """``lanes`` worker threads, each bound to its own device handle, draining one job queue."""
 
     def __init__(self, make_worker, lanes):
-        self.jobs = queue.Queue()
+        # bounded: ``submit`` blocks while every lane is busy and one job per lane is waiting, so whoever
+        # feeds the lanes (the file loaders of process_batch) runs only that far ahead of the GPU
+        self.jobs = queue.Queue(maxsize=max(1, lanes))
         self.failure = None
         self.threads = [threading.Thread(target=self._run, args=(make_worker, lane), daemon=True)
                         for lane in range(lanes)]
@@ -193,21 +195,28 @@ def process_batch(jobs, config=None, rank=None, world_size=None, device_index=No
             return run
 
         pool = _Lanes(worker_for, max(1, lanes))
+        # Host memory stays bounded whatever the batch size: at most `io_threads` decoded pairs wait for
+        # the lanes (the loaders are started one by one as their predecessors are consumed, and the lane
+        # queue is bounded), and at most `lanes + io_threads` mastered triples wait for their writers.
+        unsaved = threading.Semaphore(max(1, lanes) + max(1, io_threads))
 
         def done(index, triple, exc):
             if exc is None:
-                savers.append(io.submit(_save_job, jobs[index], triple, config))
+                unsaved.acquire()
+                future = io.submit(_save_job, jobs[index], triple, config)
+                future.add_done_callback(lambda _f: unsaved.release())
+                savers.append(future)
 
-        # loaders run at most `io_threads` jobs ahead of the lanes
-        ahead = [io.submit(_load_job, jobs[i], config) for i in mine[:io_threads]]
+        ahead = {k: io.submit(_load_job, jobs[i], config) for k, i in enumerate(mine[:io_threads])}
         nxt = len(ahead)
         try:
             for k, i in enumerate(mine):
-                arrays = ahead[k].result()
+                arrays = ahead.pop(k).result()            # (popped: the decoded arrays live on only in the job)
                 if nxt < len(mine):
-                    ahead.append(io.submit(_load_job, jobs[mine[nxt]], config))
+                    ahead[nxt] = io.submit(_load_job, jobs[mine[nxt]], config)
                     nxt += 1
                 pool.submit(i, (i, arrays), done)
+                del arrays
         finally:
             pool.close()
         for s in savers:

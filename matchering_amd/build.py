@@ -56,7 +56,7 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fno-slp-vectorize: packing the butterflies' float pairs into v_pk_* costs more v_mov shuffles
     # than it saves on gfx950 (k_conv 233 -> 196 us, k_analyze 108 -> 65 us, profiles/r01_d_*)
-    cmd = [hipcc, *FLAGS, *extra_flags, "-o", out] + SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    cmd = [hipcc, *FLAGS, *extra_flags, "-o", out] + SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-lrocprofiler-sdk-roctx", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)

@@ -28,22 +28,11 @@
 
 namespace mgx {
 
-// Cache policy of the streaming accesses.  The output is stored non-temporal (aux 2): it is not read
-// again by this kernel and must not push the input frames out of the L2 before their second use
-// (measured 197 -> 175 us and 70 MB less fetched per 8-minute track).  Non-temporal or sc0 LOADS were
-// measured slower (198 / 186 us) and stay at the default policy; the macros remain for experiments.
-#ifndef MGX_CONV_ST_AUX
-#define MGX_CONV_ST_AUX 2
-#endif
-#ifndef MGX_CONV_LD2_AUX
-#define MGX_CONV_LD2_AUX 0
-#endif
-#ifndef MGX_CONV_LD1_AUX
-#define MGX_CONV_LD1_AUX 0
-#endif
-#ifndef MGX_CONV_H_AUX
-#define MGX_CONV_H_AUX 0
-#endif
+// Cache policy of the streaming accesses (aux bits of the buffer instructions: 2 = nt).  The output is
+// stored non-temporal: it is not read again by this kernel and must not push the input frames out of
+// the L2 before their second use (measured 197 -> 175 us and 70 MB less fetched per 8-minute track).
+// Non-temporal or sc0 LOADS were measured slower (198 / 186 us) and stay at the default policy.
+constexpr int CONV_STORE_AUX = 2;
 
 struct Conv2Args {
     const float2* x;       // (n,2) interleaved L/R input frames
@@ -57,21 +46,14 @@ struct Conv2Args {
     long long npairs;      // ceil(n / N)
     float* pair_peak;      // [npairs] max(|yL|,|yR|) per pair, or nullptr
     unsigned* queue;       // [8] pairs handed out per XCD beyond the first round, [8] workgroups done; zero between launches
-#ifdef MGX_CONV_STAMPS
-    long long* stamps;     // [workgroups][8 pairs][32] s_memtime values (timing experiments)
-#endif
 };
 
-// TSHIFT: taps per block = N >> TSHIFT.  1 = the usual N = 2F (half of every block is fresh output);
-// 2 = "wide" blocks N = 4F (three quarters fresh: 28 % less transform work per frame, but a
-// 16384-point block for F = 4096 allows only one workgroup per CU).
-// V: transform plan variant (fft2.h); 1 = twice the threads, half the registers each.
-template <int LOG2N, int TSHIFT = 1, int V = 0>
+template <int LOG2N>
 struct Conv2Block {
-    using F = Fft2<LOG2N, V>;
+    using F = Fft2<LOG2N>;
     static constexpr int N = F::N;
     static constexpr int T = F::T;
-    static constexpr int TAPS = N >> TSHIFT;
+    static constexpr int TAPS = N >> 1;               // N = 2F: half of every block is fresh output
     static constexpr int LOUT = N - TAPS;             // fresh output frames per block
     static constexpr int R0 = F::R0;
     static constexpr int RL = F::RL;
@@ -120,7 +102,6 @@ struct Conv2Block {
     struct Raw {
         float2 f[CNT0][NLOAD];
     };
-    template <int AUX = 0>
     static MGX_HD void fetch_frames(int tid, long long pair, const Conv2Args& a, int part, Raw& raw) {
         if (!active0(tid)) return;
         const long long i0 = first_input(pair, a.parts, part);
@@ -134,10 +115,10 @@ struct Conv2Block {
                 // the window starts before the track: the displacement goes into the lane offset, which
                 // then wraps to the frame's true offset where there is one
                 MGX_UNROLL
-                for (int j = 0; j < NLOAD; ++j) raw.f[c][j] = ld_f2_or_zero<AUX>(src, lane + (unsigned)(j * S0 * 8));
+                for (int j = 0; j < NLOAD; ++j) raw.f[c][j] = ld_f2_or_zero(src, lane + (unsigned)(j * S0 * 8));
             } else {
                 MGX_UNROLL
-                for (int j = 0; j < NLOAD; ++j) raw.f[c][j] = ld_f2<AUX>(src, lane, (unsigned)(j * S0 * 8));   // literal displacements
+                for (int j = 0; j < NLOAD; ++j) raw.f[c][j] = ld_f2(src, lane, (unsigned)(j * S0 * 8));   // literal displacements
             }
         }
     }
@@ -204,7 +185,7 @@ struct Conv2Block {
     static MGX_HD void phase_load(int tid, long long pair, bool edge, const Conv2Args& a, const Persist& ps,
                                   float2* lds, int part = 0) {
         Raw raw;
-        fetch_frames<SIDE ? MGX_CONV_LD2_AUX : MGX_CONV_LD1_AUX>(tid, pair, a, part, raw);
+        fetch_frames(tid, pair, a, part, raw);
         phase_pass0<SIDE>(tid, raw, ps, lds);
     }
 
@@ -226,7 +207,7 @@ struct Conv2Block {
         if (!F::has_row(tid)) return;
         const MemView hv = mem_view(h, (long long)N * 8);
         MGX_UNROLL
-        for (int q = 0; q < RL; ++q) f.h[q] = ld_f2<MGX_CONV_H_AUX>(hv, (unsigned)tid * 8u, (unsigned)(q * F::L * 8));
+        for (int q = 0; q < RL; ++q) f.h[q] = ld_f2(hv, (unsigned)tid * 8u, (unsigned)(q * F::L * 8));
     }
     static MGX_HD void phase_filter(int tid, const RowFilter& f, float2* lds) {
         if (!F::has_row(tid)) return;
@@ -309,10 +290,10 @@ struct Conv2Block {
                 const unsigned fa = first + (unsigned)(j * S0), fb = fa + (unsigned)LOUT;
                 // output offsets are never negative, so the literal displacement may stay in the scalar
                 // operand: the range check adds it to the lane offset (tools/micro/buffer_range.hip)
-                st_f2<MGX_CONV_ST_AUX>(dst, first * 8u, (unsigned)(j * S0 * 8), ya);
-                st_f2<MGX_CONV_ST_AUX>(dst, first * 8u, (unsigned)((j * S0 + LOUT) * 8), yb);
-                st_f1<MGX_CONV_ST_AUX>(dm, first * 4u, (unsigned)(j * S0 * 4), m.x);
-                st_f1<MGX_CONV_ST_AUX>(dm, first * 4u, (unsigned)((j * S0 + LOUT) * 4), m.y);
+                st_f2<CONV_STORE_AUX>(dst, first * 8u, (unsigned)(j * S0 * 8), ya);
+                st_f2<CONV_STORE_AUX>(dst, first * 8u, (unsigned)((j * S0 + LOUT) * 8), yb);
+                st_f1<CONV_STORE_AUX>(dm, first * 4u, (unsigned)(j * S0 * 4), m.x);
+                st_f1<CONV_STORE_AUX>(dm, first * 4u, (unsigned)((j * S0 + LOUT) * 4), m.y);
                 const float pa = fmaxf(fabsf(ya.x), fabsf(ya.y)), pb = fmaxf(fabsf(yb.x), fabsf(yb.y));
                 peak = fmaxf(peak, fmaxf(!edge || fa < frames ? pa : 0.f, !edge || fb < frames ? pb : 0.f));
             }

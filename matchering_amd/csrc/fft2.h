@@ -112,34 +112,28 @@ MGX_HD void dft_regs(float2 (&v)[R]) {
 // ---------------------------------------------------------------------------
 // Plans: log2 of the radix of each pass; the last entry is the row pass
 // ---------------------------------------------------------------------------
-// V = 0: the default plan.  V = 1 ("thin"): twice the threads with half the registers each, for
-// kernels whose LDS footprint allows only two workgroups per CU and that are bound by latency, not
-// by arithmetic: rows of 16 in the last pass (T = N/16); the radix-32 middle pass then has only
-// N/32 butterflies and half of the threads sit it out.
-template <int LOG2N, int V = 0>
+template <int LOG2N>
 struct Fft2Plan;
-#define MGX_PLAN(L, V_, NP, A, B_, C_)                      \
+#define MGX_PLAN(L, NP, A, B_, C_)                          \
     template <>                                             \
-    struct Fft2Plan<L, V_> {                                \
+    struct Fft2Plan<L> {                                    \
         static constexpr int P = NP;                        \
         static constexpr int LR[3] = {A, B_, C_};           \
     };
-MGX_PLAN(6, 0, 2, 3, 3, 0)
-MGX_PLAN(7, 0, 2, 3, 4, 0)
-MGX_PLAN(8, 0, 2, 4, 4, 0)
-MGX_PLAN(9, 0, 2, 4, 5, 0)
-MGX_PLAN(10, 0, 2, 5, 5, 0)
-MGX_PLAN(11, 0, 3, 3, 3, 5)
-MGX_PLAN(12, 0, 3, 4, 4, 4)
-MGX_PLAN(13, 0, 3, 4, 4, 5)
-MGX_PLAN(14, 0, 3, 4, 5, 5)
-MGX_PLAN(12, 1, 3, 3, 5, 4)
-MGX_PLAN(13, 1, 3, 4, 5, 4)
+MGX_PLAN(6, 2, 3, 3, 0)
+MGX_PLAN(7, 2, 3, 4, 0)
+MGX_PLAN(8, 2, 4, 4, 0)
+MGX_PLAN(9, 2, 4, 5, 0)
+MGX_PLAN(10, 2, 5, 5, 0)
+MGX_PLAN(11, 3, 3, 3, 5)
+MGX_PLAN(12, 3, 4, 4, 4)
+MGX_PLAN(13, 3, 4, 4, 5)
+MGX_PLAN(14, 3, 4, 5, 5)
 #undef MGX_PLAN
 
-template <int LOG2N, int V = 0>
+template <int LOG2N>
 struct Fft2 {
-    using Plan = Fft2Plan<LOG2N, V>;
+    using Plan = Fft2Plan<LOG2N>;
     static constexpr int N = 1 << LOG2N;
     static constexpr int P = Plan::P;
     static constexpr int LAST = P - 1;
@@ -266,90 +260,8 @@ struct Fft2 {
     }
 
     // ---- middle pass (P == 3), LDS -> LDS ---------------------------------------------------
-    // Split middle pass (thin plans): the pass has only T/2 radix-32 butterflies, so each is shared
-    // by two lanes (l, l+32) of one wave.  Lane half p computes the 16 outputs of parity p: it reads
-    // all 32 inputs, folds them to 16 (first radix-2 stage of the decimation-in-frequency form,
-    // x_j + x_{j+16} for p = 0, (x_j - x_{j+16}) w_32^j for p = 1) and runs a 16-point transform.
-    // Reading twice costs LDS bandwidth the kernel has to spare; it keeps every thread busy and the
-    // pass at 16 complex registers.  Both lanes of a butterfly run in lockstep and every read
-    // precedes every write, so the pass stays in place without a barrier; the host emulation calls
-    // the two halves (gather, scatter) in separate thread loops.
-    static constexpr bool SPLIT_MID = P == 3 && NB(1) * 2 == T && R(1) == 32;
-    static_assert(P < 3 || !partial(1) || SPLIT_MID, "a middle pass with idle threads must be a split one");
-    struct MidHalf {
-        float2 v[16];
-    };
-    static MGX_HD int split_butterfly(int tid) { return ((tid >> 6) << 5) | (tid & 31); }
-    static MGX_HD int split_parity(int tid) { return (tid >> 5) & 1; }
-    // sign = +1 / -1 and w[j-1] = 1 / exp(-/+ 2 pi i j/32) for parity 0 / 1 (INV: conjugate)
-    template <bool INV>
-    static MGX_HD void split_factors(int parity, float& sign, float2 (&w)[15]) {
-        sign = parity ? -1.f : 1.f;
-        MGX_UNROLL
-        for (int j = 1; j < 16; ++j) {
-            const float2 u = unit32(j);
-            w[j - 1] = make_float2(parity ? u.x : 1.f, parity ? (INV ? u.y : -u.y) : 0.f);
-        }
-    }
-    static MGX_HD void fwd_mid_gather(int tid, const float2* lds, MidHalf& h) {
-        const float2* p = lds + base<MID>(split_butterfly(tid));
-        float sign;
-        float2 w[15];
-        split_factors<false>(split_parity(tid), sign, w);
-        MGX_UNROLL
-        for (int j = 0; j < 16; ++j) {
-            const float2 a = p[off<MID>(j)], b = p[off<MID>(j + 16)];
-            const float2 y = make_float2(a.x + sign * b.x, a.y + sign * b.y);
-            h.v[j] = j == 0 ? y : cmul(y, w[j - 1]);
-        }
-    }
-    static MGX_HD void fwd_mid_scatter(int tid, MidHalf& h, float2* lds, const float2* table) {
-        constexpr int s = S(MID);
-        const int u = split_butterfly(tid), parity = split_parity(tid), n = u % s;
-        float2* p = lds + base<MID>(u) + (parity ? off<MID>(1) : 0);
-        dft_regs<16, false>(h.v);
-        MGX_UNROLL
-        for (int k = 0; k < 16; ++k) {            // output q = 2k + parity
-            float2 x = h.v[bitrev(k, 4)];
-            // twiddle row q-1 of the table; q = 0 (k = 0, parity 0) is 1: read row 0 and select
-            const float2 t = table[(k == 0 ? 0 : 2 * k - 1 + parity) * s + n];
-            if (k == 0) x = parity ? cmul(x, t) : x;
-            else x = cmul(x, t);
-            p[off<MID>(2 * k)] = x;
-        }
-    }
-    static MGX_HD void inv_mid_gather(int tid, const float2* lds, const float2* table, MidHalf& h) {
-        constexpr int s = S(MID);
-        const int u = split_butterfly(tid), n = u % s;
-        const float2* p = lds + base<MID>(u);
-        float sign;
-        float2 w[15];
-        split_factors<true>(split_parity(tid), sign, w);
-        MGX_UNROLL
-        for (int q = 0; q < 16; ++q) {
-            float2 a = p[off<MID>(q)], b = p[off<MID>(q + 16)];
-            if (q != 0) a = cmulc(a, table[(q - 1) * s + n]);
-            b = cmulc(b, table[(q + 15) * s + n]);
-            const float2 z = make_float2(a.x + sign * b.x, a.y + sign * b.y);
-            h.v[bitrev(q, 4)] = q == 0 ? z : cmul(z, w[q - 1]);
-        }
-    }
-    static MGX_HD void inv_mid_scatter(int tid, MidHalf& h, float2* lds) {
-        const int u = split_butterfly(tid), parity = split_parity(tid);
-        float2* p = lds + base<MID>(u) + (parity ? off<MID>(1) : 0);
-        dft_regs<16, true>(h.v);
-        MGX_UNROLL
-        for (int k = 0; k < 16; ++k) p[off<MID>(2 * k)] = h.v[k];      // x_j, j = 2k + parity
-    }
-
     static MGX_HD void fwd_mid(int tid, float2* lds, const float2* table) {
         constexpr int r = R(MID), bits = lr(MID), s = S(MID);
-        if (SPLIT_MID) {
-            MidHalf h;
-            fwd_mid_gather(tid, lds, h);
-            fwd_mid_scatter(tid, h, lds, table);
-            return;
-        }
         float2 w[r - 1];
         const int n = tid % s;
         MGX_UNROLL
@@ -371,12 +283,6 @@ struct Fft2 {
     }
     static MGX_HD void inv_mid(int tid, float2* lds, const float2* table) {
         constexpr int r = R(MID), bits = lr(MID), s = S(MID);
-        if (SPLIT_MID) {
-            MidHalf h;
-            inv_mid_gather(tid, lds, table, h);
-            inv_mid_scatter(tid, h, lds);
-            return;
-        }
         float2 w[r - 1];
         const int n = tid % s;
         MGX_UNROLL

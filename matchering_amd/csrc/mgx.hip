@@ -2,6 +2,7 @@
 // every entry point that needs a GPU fails with MGX_ERR_NO_DEVICE / MGX_ERR_HIP.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -127,11 +128,22 @@ static void stage_mark(mgx_handle* h, int stage, int end) {
     hipEventRecord(h->stage_ev[stage][end], h->stream);
     if (end) h->stage_used[stage] = true;
 }
+// (+ a roctx range per stage: `rocprofv3 --marker-trace` shows which launches belong to which stage of
+// stages.py:210-272; a push/pop costs nothing when no profiler is attached)
+static const char* const STAGE_NAMES[MGX_STAGE_COUNT] = {"mgx:analyze", "mgx:design_fir", "mgx:filter_spectra",
+                                                         "mgx:convolve", "mgx:correct_levels", "mgx:scale_outputs",
+                                                         "mgx:limit"};
 struct StageScope {
     mgx_handle* h;
     int stage;
-    StageScope(mgx_handle* h_, int s) : h(h_), stage(s) { stage_mark(h, stage, 0); }
-    ~StageScope() { stage_mark(h, stage, 1); }
+    StageScope(mgx_handle* h_, int s) : h(h_), stage(s) {
+        roctxRangePushA(STAGE_NAMES[stage]);
+        stage_mark(h, stage, 0);
+    }
+    ~StageScope() {
+        stage_mark(h, stage, 1);
+        roctxRangePop();
+    }
 };
 
 // control words shared by the kernels that count arrivals: [0] limiter ticket, [1] limiter error flag,
@@ -446,15 +458,15 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     return 0;
 }
 
-template <int LOG2N, bool MULTI, int TSHIFT = 1, int V = 0>
+template <int LOG2N, bool MULTI>
 static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr) {
-    using F = Fft2<LOG2N, V>;
-    const size_t lds = conv_lds_bytes<LOG2N, V>();
-    MGX_TRY((allow_lds(k_conv_prep<LOG2N, TSHIFT, V>, lds)));
-    MGX_TRY((allow_lds(k_conv<LOG2N, MULTI, TSHIFT, V>, lds)));
+    using F = Fft2<LOG2N>;
+    const size_t lds = conv_lds_bytes<LOG2N>();
+    MGX_TRY((allow_lds(k_conv_prep<LOG2N>, lds)));
+    MGX_TRY((allow_lds(k_conv<LOG2N, MULTI>, lds)));
     {
         StageScope scope(h, MGX_STAGE_FILTER_SPECTRA);
-        hipLaunchKernelGGL((k_conv_prep<LOG2N, TSHIFT, V>), dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev,
+        hipLaunchKernelGGL((k_conv_prep<LOG2N>), dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev,
                            a.tw, (float2*)h->filt.p, a.parts, gain_ptr, gain);
     }
     HIP_TRY(hipGetLastError());
@@ -471,28 +483,10 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
     const int per_cu = std::max(1, std::min(2048 / F::T, (int)((size_t)160 * 1024 / lds)));
     const long long cap = (long long)dev_cus * per_cu;
     const unsigned grid = (unsigned)(((std::min<long long>(a.npairs, cap) + 7) / 8) * 8);
-#ifdef MGX_CONV_STAMPS
-    static long long* stamps_dev = nullptr;
-    const size_t stamp_words = (size_t)grid * 8 * 32;
-    if (!stamps_dev) HIP_TRY(hipMalloc(&stamps_dev, (size_t)4096 * 8 * 32 * sizeof(long long)));
-    HIP_TRY(hipMemsetAsync(stamps_dev, 0, stamp_words * sizeof(long long), h->stream));
-    a.stamps = stamps_dev;
-#endif
     {
         StageScope scope(h, MGX_STAGE_CONVOLVE);
-        hipLaunchKernelGGL((k_conv<LOG2N, MULTI, TSHIFT, V>), dim3(grid), dim3(F::T), lds, h->stream, a);
+        hipLaunchKernelGGL((k_conv<LOG2N, MULTI>), dim3(grid), dim3(F::T), lds, h->stream, a);
     }
-#ifdef MGX_CONV_STAMPS
-    if (const char* path = std::getenv("MGX_STAMPS_OUT")) {
-        std::vector<long long> host(stamp_words);
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        HIP_TRY(hipMemcpy(host.data(), stamps_dev, stamp_words * sizeof(long long), hipMemcpyDeviceToHost));
-        if (FILE* f = std::fopen(path, "wb")) {
-            std::fwrite(host.data(), sizeof(long long), stamp_words, f);
-            std::fclose(f);
-        }
-    }
-#endif
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -500,7 +494,7 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
 // taps_dev: [2][F] float (mid then side) already on the device.  F <= 8192: one overlap-save block of
 // N = 2F per filter; longer filters (config #5: 16 k taps at 96 kHz) are cut into K = F/4096
 // partitions on N = 8192 blocks (uniformly partitioned overlap-save), because N = 2F no longer fits
-// a CU's LDS.  MGX_CONV_BLOCK_LOG2=<l> forces N = 2^l with K = 2F/N partitions (tests).
+// a CU's LDS.
 static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const float* taps_dev, double gain,
                     float* y, float* ymid, long long* npairs_out, const double* gain_ptr = nullptr) {
     const int l = ilog2_exact(taps);
@@ -508,10 +502,6 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     MGX_TRY(check_length(n));
     int log2b = l + 1;
     if (log2b > 14) log2b = 13;
-    if (const char* forced = std::getenv("MGX_CONV_BLOCK_LOG2")) {
-        const int f = std::atoi(forced);
-        if ((f == 10 || f == 13) && f <= l + 1) log2b = f;      // the partitioned kernel exists for these two
-    }
     const size_t nb = (size_t)1 << log2b;
     const int parts = (int)((size_t)2 * taps / nb);
     const long long pair_frames = (long long)nb;
@@ -528,11 +518,7 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     a.pair_peak = nullptr;
     MGX_TRY(get_twiddles(h, log2b, &a.tw));
     if (npairs_out) *npairs_out = a.npairs;
-    if (parts > 1) {
-        if (log2b == 13) return launch_conv<13, true>(h, a, taps_dev, gain, gain_ptr);
-        if (log2b == 10) return launch_conv<10, true>(h, a, taps_dev, gain, gain_ptr);
-        return fail(MGX_ERR_UNSUPPORTED, "partitioned convolution is built for 1024- and 8192-frame blocks only");
-    }
+    if (parts > 1) return launch_conv<13, true>(h, a, taps_dev, gain, gain_ptr);
     switch (log2b) {
 #define CASE(L) case L: return launch_conv<L, false>(h, a, taps_dev, gain, gain_ptr);
         CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)

@@ -63,9 +63,9 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // ---------------------------------------------------------------------------
 // convolution
 // ---------------------------------------------------------------------------
-template <int LOG2N, int V = 0>
+template <int LOG2N>
 constexpr size_t conv_lds_bytes() {
-    return ((size_t)Fft2<LOG2N, V>::LDS_ELEMS + Fft2<LOG2N, V>::MID_TABLE) * sizeof(float2) + 128;
+    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 128;
 }
 
 // The phases of a kernel share index arithmetic (LDS addresses derived from the thread id).  Left
@@ -80,74 +80,51 @@ __device__ __forceinline__ int opaque(int v) {
 
 // workgroups of k_conv a CU holds (LDS and thread limits), and the waves per SIMD that makes: the
 // register budget the kernel is compiled for
-template <int LOG2N, int V = 0>
+template <int LOG2N>
 constexpr int conv_workgroups_per_cu() {
-    constexpr int by_lds = (int)((size_t)160 * 1024 / conv_lds_bytes<LOG2N, V>());
-    constexpr int by_threads = 2048 / Fft2<LOG2N, V>::T;
+    constexpr int by_lds = (int)((size_t)160 * 1024 / conv_lds_bytes<LOG2N>());
+    constexpr int by_threads = 2048 / Fft2<LOG2N>::T;
     constexpr int w = by_lds < by_threads ? by_lds : by_threads;
     return w < 1 ? 1 : (w > 2 ? 2 : w);             // more than two co-resident transforms do not pay
 }
-template <int LOG2N, int V = 0>
+template <int LOG2N>
 constexpr int conv_waves_per_simd() {
-    constexpr int w = conv_workgroups_per_cu<LOG2N, V>() * (Fft2<LOG2N, V>::T / 64) / 4;
+    constexpr int w = conv_workgroups_per_cu<LOG2N>() * (Fft2<LOG2N>::T / 64) / 4;
     return w < 2 ? 2 : w;
 }
 
-// Phase timeline (timing experiments only: -DMGX_CONV_STAMPS): thread 0 records s_memtime at every
-// phase boundary of its first pairs; tools/conv_stamps.py turns the dump into a table.
-struct Stamper {
-#ifdef MGX_CONV_STAMPS
-    long long* p;
-    int i;
-    __device__ __forceinline__ void mark(int tid) {
-        if (tid == 0 && p) p[i] = (long long)__builtin_amdgcn_s_memtime();
-        ++i;
-    }
-#else
-    __device__ __forceinline__ void mark(int) {}
-#endif
-};
-
 // One channel of one pair, from pass 0 (`pass0`) up to the inverse middle pass (conv2_kernel.h).
-template <int LOG2N, bool SIDE, int TSHIFT, int V, class Pass0>
+template <int LOG2N, bool SIDE, class Pass0>
 __device__ __forceinline__ void conv_channel(int tid, const Conv2Args& a, float2* lds, const float2* mid_table,
-                                             Stamper& sm, Pass0 pass0) {
-    using CB = Conv2Block<LOG2N, TSHIFT, V>;
-    using F = Fft2<LOG2N, V>;
+                                             Pass0 pass0) {
+    using CB = Conv2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
     typename CB::RowFilter rf;
     pass0();
     // (the scheduler must not lift the filter loads above pass 0: there is no room for them yet)
     __builtin_amdgcn_sched_barrier(0);
     CB::fetch_filter(tid, SIDE ? a.h_side : a.h_mid, rf);      // a phase early: the middle pass hides its latency
-    sm.mark(tid);
     __syncthreads();
-    sm.mark(tid);
     if (F::P == 3) {
         CB::phase_fwd_mid(opaque(tid), lds, mid_table);
-        sm.mark(tid);
         __syncthreads();
-        sm.mark(tid);
     }
     CB::phase_filter(tid, rf, lds);
-    sm.mark(tid);
     __syncthreads();
-    sm.mark(tid);
     if (F::P == 3) {
         CB::phase_inv_mid(opaque(tid), lds, mid_table);
-        sm.mark(tid);
         __syncthreads();
-        sm.mark(tid);
     }
     __builtin_amdgcn_sched_barrier(0);      // keeps the next phase's LDS reads from being lifted into this one
 }
 // uniformly partitioned overlap-save: one forward transform per filter partition, products
 // accumulated on the thread's row, one inverse transform
-template <int LOG2N, bool SIDE, int TSHIFT, int V>
+template <int LOG2N, bool SIDE>
 __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair, bool edge, const Conv2Args& a,
-                                                         const typename Conv2Block<LOG2N, TSHIFT, V>::Persist& ps,
+                                                         const typename Conv2Block<LOG2N>::Persist& ps,
                                                          float2* lds, const float2* mid_table) {
-    using CB = Conv2Block<LOG2N, TSHIFT, V>;
-    using F = Fft2<LOG2N, V>;
+    using CB = Conv2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
     const float2* h = SIDE ? a.h_side : a.h_mid;
     typename CB::RowFilter rf;
     typename CB::RowAcc acc;
@@ -179,34 +156,30 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
 // (Issuing the NEXT pair's frame loads before the epilogue's stores -- software pipelining -- was
 // built and measured: the 48-96 registers in flight make the 8192-point kernel spill at the 256 a
 // wave has here, and a spilling kernel is far slower than an unpipelined one, 294 vs 153 us.)
-template <int LOG2N, bool MULTI, int TSHIFT, int V>
+template <int LOG2N, bool MULTI>
 __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2Args& a,
-                                           const typename Conv2Block<LOG2N, TSHIFT, V>::Persist& ps, float2* lds,
-                                           const float2* mid_table, Stamper& sm) {
-    using CB = Conv2Block<LOG2N, TSHIFT, V>;
+                                           const typename Conv2Block<LOG2N>::Persist& ps, float2* lds,
+                                           const float2* mid_table) {
+    using CB = Conv2Block<LOG2N>;
     const bool edge = !CB::interior(pair, a.n, a.parts);
     typename CB::Kept kept;
-    sm.mark(tid);
     if (MULTI) {
-        conv_channel_partitioned<LOG2N, false, TSHIFT, V>(tid, pair, edge, a, ps, lds, mid_table);
+        conv_channel_partitioned<LOG2N, false>(tid, pair, edge, a, ps, lds, mid_table);
         CB::phase_keep_mid(tid, ps, lds, kept);
         __syncthreads();
-        conv_channel_partitioned<LOG2N, true, TSHIFT, V>(tid, pair, edge, a, ps, lds, mid_table);
+        conv_channel_partitioned<LOG2N, true>(tid, pair, edge, a, ps, lds, mid_table);
     } else {
         typename CB::Raw raw;
         typename CB::Held held;
-        CB::template fetch_frames<MGX_CONV_LD1_AUX>(tid, pair, a, 0, raw);
-        conv_channel<LOG2N, false, TSHIFT, V>(
-            tid, a, lds, mid_table, sm, [&]() { CB::phase_pass0_mid(tid, raw, ps, lds, held); });
+        CB::fetch_frames(tid, pair, a, 0, raw);
+        conv_channel<LOG2N, false>(
+            tid, a, lds, mid_table, [&]() { CB::phase_pass0_mid(tid, raw, ps, lds, held); });
         CB::phase_keep_mid(tid, ps, lds, kept);
-        sm.mark(tid);
         __syncthreads();
-        sm.mark(tid);
-        conv_channel<LOG2N, true, TSHIFT, V>(
-            tid, a, lds, mid_table, sm, [&]() { CB::phase_pass0_side(tid, held, ps, lds); });
+        conv_channel<LOG2N, true>(
+            tid, a, lds, mid_table, [&]() { CB::phase_pass0_side(tid, held, ps, lds); });
     }
     const float pk = CB::phase_store(tid, pair, edge, a, ps, lds, kept);
-    sm.mark(tid);
     return pk;
 }
 
@@ -220,10 +193,10 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2A
 // Two workgroups per CU (LDS): the second launch bound is waves per SIMD, i.e. the register budget.
 // MULTI = more than one filter partition (its own instantiation: the accumulator row costs registers
 // the plain kernel should not pay for)
-template <int LOG2N, bool MULTI, int TSHIFT = 1, int V = 0>
-__global__ __launch_bounds__((Fft2<LOG2N, V>::T), (conv_waves_per_simd<LOG2N, V>())) void k_conv(Conv2Args a) {
-    using CB = Conv2Block<LOG2N, TSHIFT, V>;
-    using F = Fft2<LOG2N, V>;
+template <int LOG2N, bool MULTI>
+__global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) void k_conv(Conv2Args a) {
+    using CB = Conv2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
     float2* mid_table = lds + F::LDS_ELEMS;
@@ -238,8 +211,7 @@ __global__ __launch_bounds__((Fft2<LOG2N, V>::T), (conv_waves_per_simd<LOG2N, V>
     const long long first = xcd * per + slot;
     int* next_slot = reinterpret_cast<int*>(scratch + 16);
     long long pair = first;
-    for (int it = 0; pair < end; ++it) {
-        (void)it;                               // numbers the pair for the phase stamps only
+    while (pair < end) {
         unsigned ticket = 0;
         if (tid == 0) ticket = atomicAdd(a.queue + xcd, 1u);
         // The pass-0 twiddles stay in registers across pairs, but nothing derived from them (or
@@ -247,12 +219,7 @@ __global__ __launch_bounds__((Fft2<LOG2N, V>::T), (conv_waves_per_simd<LOG2N, V>
         // not have.  An empty asm makes the values opaque per iteration.
 #pragma unroll
         for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
-        Stamper sm;
-#ifdef MGX_CONV_STAMPS
-        sm.p = a.stamps && it < 8 ? a.stamps + ((long long)blockIdx.x * 8 + it) * 32 : nullptr;
-        sm.i = 0;
-#endif
-        const float pk = conv_pair<LOG2N, MULTI, TSHIFT, V>(tid, pair, a, ps, lds, mid_table, sm);
+        const float pk = conv_pair<LOG2N, MULTI>(tid, pair, a, ps, lds, mid_table);
         const float bp = block_max<F::T>(pk, scratch);
         if (tid == 0) {
             if (a.pair_peak) a.pair_peak[pair] = bp;
@@ -260,7 +227,6 @@ __global__ __launch_bounds__((Fft2<LOG2N, V>::T), (conv_waves_per_simd<LOG2N, V>
         }
         __syncthreads();
         pair = xcd * per + slots + *next_slot;
-        sm.mark(tid);
     }
     // the last workgroup to run out of pairs leaves the counters at zero for the next launch
     if (tid == 0 && atomicAdd(a.queue + 8, 1u) == gridDim.x - 1) {
@@ -270,11 +236,11 @@ __global__ __launch_bounds__((Fft2<LOG2N, V>::T), (conv_waves_per_simd<LOG2N, V>
 
 // filter spectra: grid = 2 * parts; taps = [2][parts * N/2] float (mid then side), tables =
 // [2][parts][N] float2.  Workgroup (ch, k) transforms partition k of channel ch.
-template <int LOG2N, int TSHIFT = 1, int V = 0>
-__global__ __launch_bounds__((Fft2<LOG2N, V>::T)) void k_conv_prep(const float* taps, const float2* tw, float2* tables,
+template <int LOG2N>
+__global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_prep(const float* taps, const float2* tw, float2* tables,
                                                               int parts, const double* gain_ptr, double gain) {
-    using CB = Conv2Block<LOG2N, TSHIFT, V>;
-    using F = Fft2<LOG2N, V>;
+    using CB = Conv2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
     float2* mid_table = lds + F::LDS_ELEMS;

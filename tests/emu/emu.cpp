@@ -33,28 +33,19 @@ static std::vector<float2> twiddles(int n) {
 template <class F>
 static void mid_pass(bool inverse, float2* lds, const float2* table) {
     if (F::P != 3) return;
-    if (F::SPLIT_MID) {
-        std::vector<typename F::MidHalf> h(F::T);
-        if (inverse) {
-            FOR_THREADS(F::T) F::inv_mid_gather(tid, lds, table, h[tid]);
-            FOR_THREADS(F::T) F::inv_mid_scatter(tid, h[tid], lds);
-        } else {
-            FOR_THREADS(F::T) F::fwd_mid_gather(tid, lds, h[tid]);
-            FOR_THREADS(F::T) F::fwd_mid_scatter(tid, h[tid], lds, table);
-        }
-    } else {
+    {
         if (inverse) { FOR_THREADS(F::T) F::inv_mid(tid, lds, table); }
         else { FOR_THREADS(F::T) F::fwd_mid(tid, lds, table); }
     }
 }
 
 // ---------------------------------------------------------------------------
-template <int LOG2N, int TSHIFT = 1, int V = 0>
+template <int LOG2N>
 static int conv_impl(const float* x, long long n, const double* fir_mid, const double* fir_side, int taps,
                      double gain, float* y, float* ymid, double* peak) {
-    using CB = Conv2Block<LOG2N, TSHIFT, V>;
+    using CB = Conv2Block<LOG2N>;
     using F = typename CB::F;
-    const int parts = TSHIFT == 1 ? 2 * taps / F::N : 1;
+    const int parts = 2 * taps / F::N;
     const std::vector<float2> tw = twiddles(F::N);
     std::vector<float2> lds(F::LDS_ELEMS), mid_table(F::MID_TABLE + 1), tables((size_t)2 * parts * F::N);
     std::vector<float> h(2 * taps);
@@ -136,25 +127,6 @@ extern "C" int emu_convolve_blocked(const float* x, long long n, const double* f
 #define CASE(L) case L: return conv_impl<L>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
         CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
-        default: return -4;
-    }
-}
-// "wide" blocks: N = 4 * taps
-extern "C" int emu_convolve_wide(const float* x, long long n, const double* fir_mid, const double* fir_side,
-                                 int taps, double gain, float* y, float* ymid, double* peak) {
-    switch (ilog2_exact(taps) + 2) {
-        case 9: return conv_impl<9, 2>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
-        case 11: return conv_impl<11, 2>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
-        case 14: return conv_impl<14, 2>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
-        default: return -4;
-    }
-}
-// "thin" transform plans (fft2.h, V = 1): rows of 16, twice the threads
-extern "C" int emu_convolve_thin(const float* x, long long n, const double* fir_mid, const double* fir_side,
-                                 int taps, double gain, float* y, float* ymid, double* peak) {
-    switch (ilog2_exact(taps) + 1) {
-        case 12: return conv_impl<12, 1, 1>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
-        case 13: return conv_impl<13, 1, 1>(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak);
         default: return -4;
     }
 }

@@ -87,44 +87,6 @@ def test_partitioned_convolution_phases(emu, taps, block_log2, n):
     assert abs(peak.value - np.abs(y).max()) <= 1e-6
 
 
-@pytest.mark.parametrize("taps,n", [(128, 3000), (512, 1), (512, 9000), (4096, 30000)])
-def test_wide_block_convolution_phases(emu, taps, n):
-    """Blocks of N = 4*taps (three quarters of every block are fresh output)."""
-    rng = np.random.RandomState(taps + n)
-    x = np.ascontiguousarray((0.3 * rng.randn(n, 2)).astype(np.float32))
-    hm, hs = rng.randn(taps) / np.sqrt(taps), rng.randn(taps) / np.sqrt(taps)
-    y = np.zeros((n, 2), dtype=np.float32)
-    ymid = np.zeros(n, dtype=np.float32)
-    peak = ctypes.c_double()
-    rc = emu.emu_convolve_wide(_fp(x), ctypes.c_longlong(n), _dp(hm), _dp(hs), ctypes.c_int(taps),
-                               ctypes.c_double(1.1), _fp(y), _fp(ymid), ctypes.byref(peak))
-    assert rc == 0
-    mid, side = mo.mid_side(x.astype(np.float64))
-    want, want_mid = mo.convolve_same(mid * 1.1, hm, side * 1.1, hs)
-    assert rms_error(y, want) <= 1e-6
-    assert rms_error(ymid, want_mid) <= 1e-6
-
-
-@pytest.mark.parametrize("taps,n", [(2048, 9001), (4096, 1), (4096, 3 * 8192 + 5)])
-def test_thin_plan_convolution_phases(emu, taps, n):
-    """Transform plans with rows of 16 and twice the threads (fft2.h, V = 1): the radix-32 middle pass
-    leaves half of the threads idle."""
-    rng = np.random.RandomState(taps + n)
-    x = np.ascontiguousarray((0.3 * rng.randn(n, 2)).astype(np.float32))
-    hm, hs = rng.randn(taps) / np.sqrt(taps), rng.randn(taps) / np.sqrt(taps)
-    y = np.zeros((n, 2), dtype=np.float32)
-    ymid = np.zeros(n, dtype=np.float32)
-    peak = ctypes.c_double()
-    rc = emu.emu_convolve_thin(_fp(x), ctypes.c_longlong(n), _dp(hm), _dp(hs), ctypes.c_int(taps),
-                               ctypes.c_double(0.9), _fp(y), _fp(ymid), ctypes.byref(peak))
-    assert rc == 0
-    mid, side = mo.mid_side(x.astype(np.float64))
-    want, want_mid = mo.convolve_same(mid * 0.9, hm, side * 0.9, hs)
-    assert rms_error(y, want) <= 1e-6
-    assert rms_error(ymid, want_mid) <= 1e-6
-    assert abs(peak.value - np.abs(y).max()) <= 1e-6
-
-
 def test_convolution_identity(emu):
     # scipy "same" centring (match_frequencies.py:112): delta at (F-1)//2 is the identity
     rng = np.random.RandomState(5)

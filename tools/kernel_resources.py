@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 from matchering_amd import build as b
 
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
-       "-Rpass-analysis=kernel-resource-usage", "-Wno-unused-value", "-o", "/tmp/libmgx_res.so"] + b.SOURCES + ["-L/opt/rocm/lib", "-lrccl"]
+       "-Rpass-analysis=kernel-resource-usage", "-Wno-unused-value", "-o", "/tmp/libmgx_res.so"] + b.SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-lrocprofiler-sdk-roctx"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = {}
 want = sys.argv[1:] or [""]
