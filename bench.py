@@ -290,17 +290,56 @@ def main():
             from matchering_amd import stages
 
             target, reference = wl.host_pair
-            t0 = time.perf_counter()
-            stages.main(target, reference, wl.cfg, need_default=wl.want_limiter, need_no_limiter=not wl.want_limiter,
-                        device=wl.dev)
-            line["pcie_inclusive"] = {"value": round(target.shape[0] / (time.perf_counter() - t0) / 1e6, 2),
-                                      "unit": "Msamples/s", "note": "numpy in/out through stages.main, one pair"}
+            took = []
+            for _ in range(3):             # the first call fills the pinned-host and HBM block pools
+                t0 = time.perf_counter()
+                stages.main(target, reference, wl.cfg, need_default=wl.want_limiter,
+                            need_no_limiter=not wl.want_limiter, device=wl.dev)
+                took.append(time.perf_counter() - t0)
+            line["pcie_inclusive"] = {"value": round(target.shape[0] / min(took) / 1e6, 2), "unit": "Msamples/s",
+                                      "note": "pageable numpy in -> pinned numpy out through stages.main, one pair, "
+                                              "best of 3 calls"}
+            line["pcie_inclusive_batch"] = host_to_host_batch(mg, make_pair)
         if not args.no_cpu_baseline and ranks.world == 1:
             line["cpu_baseline"] = cpu_baseline(wl, name)
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
     if ranks.rank == 0:
         print(json.dumps(line))
     ranks.finish()
+
+
+def host_to_host_batch(mg, make_pair, pairs=8, seconds=240.0, lanes=2):
+    """Config #4's per-GPU share from host arrays to host arrays: eight four-minute pairs through
+    batch.master_many (two lanes = two device handles, one pair's PCIe copies under the other's kernels).
+    The inputs sit in pinned host memory, where a loader thread would decode them; PCIe moves 24 B per
+    frame (target + reference up, result down), so ~2.3 G frames/s is the bound at 55 GB/s."""
+    from matchering_amd import batch
+    from matchering_amd.device import pinned
+
+    staged = []
+    for k in range(pairs):
+        t, r = make_pair(seconds, 44100, pair=200 + k)
+        pt, pr = pinned.empty(t.shape), pinned.empty(r.shape)
+        pt[...] = t
+        pr[...] = r
+        staged.append((pt, pr))
+    cfg = mg.Config()
+    peaks = {}
+
+    def consume(index, triple):            # what a writer thread would do, minus the file: look at it, let it go
+        peaks[index] = float(np.abs(triple[0][::4096]).max())
+
+    frames = sum(p[0].shape[0] for p in staged)
+    wall = None
+    for attempt in range(3):               # the first passes fill the block pools (pinned host, HBM)
+        peaks.clear()
+        t0 = time.perf_counter()
+        batch.master_many(staged, cfg, need_default=True, lanes=lanes, on_result=consume)
+        took = time.perf_counter() - t0
+        wall = took if wall is None else min(wall, took)
+    assert len(peaks) == pairs and all(0.0 < v < 1.0 for v in peaks.values())
+    return {"value": round(frames / wall / 1e6, 2), "unit": "Msamples/s", "ms_per_batch": round(wall * 1e3, 2),
+            "note": f"{pairs} x {seconds:.0f} s pairs, pinned numpy in -> pinned numpy out, {lanes} lanes"}
 
 
 def _oracle_worker(seconds, sample_rate, fft, need, pair):

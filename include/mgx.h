@@ -92,6 +92,14 @@ int mgx_free(mgx_handle* h, void* dev);
 int mgx_memcpy_h2d(mgx_handle* h, void* dev, const void* host, size_t bytes);
 int mgx_memcpy_d2h(mgx_handle* h, void* host, const void* dev, size_t bytes);
 int mgx_synchronize(mgx_handle* h);
+/* Page-locked host memory and copies that return at once (ordered on the handle's stream; the host
+ * buffer must stay valid and untouched until mgx_synchronize): what a host needs to overlap the
+ * upload of pair k+1 and the download of pair k-1 with the kernels of pair k (loader.py:30-47 and
+ * saver.py:27-33 sit on either side of stages.main; PCIe is the bound of the whole process()). */
+int mgx_host_alloc(size_t bytes, void** host);
+int mgx_host_free(void* host);
+int mgx_memcpy_h2d_async(mgx_handle* h, void* dev, const void* host, size_t bytes);
+int mgx_memcpy_d2h_async(mgx_handle* h, void* host, const void* dev, size_t bytes);
 /* HIP-event timing on the handle's stream: bracket any sequence of calls */
 int mgx_timer_start(mgx_handle* h);
 int mgx_timer_stop(mgx_handle* h, float* milliseconds);

@@ -90,6 +90,10 @@ SYMBOLS = {
                                       c_double_p, c_double_p]),
     "mgx_convolve": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, c_double_p, c_double_p, ctypes.c_int32,
                                     ctypes.c_double, _VP, _VP, c_double_p]),
+    "mgx_host_alloc": (ctypes.c_int, [ctypes.c_size_t, ctypes.POINTER(_VP)]),
+    "mgx_host_free": (ctypes.c_int, [_VP]),
+    "mgx_memcpy_h2d_async": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_size_t]),
+    "mgx_memcpy_d2h_async": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_size_t]),
     "mgx_stage_timing": (ctypes.c_int, [_VP, ctypes.c_int32]),
     "mgx_stage_times": (ctypes.c_int, [_VP, c_float_p]),
     "mgx_clipped_piece_sumsq": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,

@@ -99,32 +99,52 @@ class _Lanes:
             raise self.failure
 
 
-def _device_worker(device_index, config, needs, master):
-    """A callable mastering one (target, reference) array pair on its own device handle."""
+_lane_devices = {}
+_lane_devices_lock = threading.Lock()
+
+
+def lane_device(device_index, lane):
+    """The device handle of lane ``lane`` on GPU ``device_index``: created once per process and kept --
+    with it its FIR plans, workspaces and recycled HBM blocks, which a batch should not pay for twice."""
+    from .device import Device
+
+    with _lane_devices_lock:
+        key = (device_index, lane)
+        if key not in _lane_devices:
+            _lane_devices[key] = Device(device_index)
+        return _lane_devices[key]
+
+
+def _device_worker(device_index, lane, config, needs, master):
+    """A callable mastering one (target, reference) array pair on the lane's own device handle."""
     if master is not None:                         # tests inject a stand-in for the GPU
         return lambda pair: master(pair[0], pair[1], config, *needs)
-    from .device import Device
     from .stages import main
 
-    dev = Device(device_index)
+    dev = lane_device(device_index, lane)
     return lambda pair: main(pair[0], pair[1], config, *needs, device=dev)
 
 
 def master_many(pairs, config=None, need_default=True, need_no_limiter=False,
-                need_no_limiter_normalized=False, device_index=0, lanes=2, master=None):
+                need_no_limiter_normalized=False, device_index=0, lanes=2, master=None, on_result=None):
     """``stages.main`` over a list of (target, reference) arrays on ONE GPU, ``lanes`` pairs in flight.
 
     Returns the list of result triples in the order of ``pairs``.  Results are bit-identical to
     calling ``stages.main`` pair by pair: lanes only change when work is submitted, never what is
-    computed."""
+    computed.  With ``on_result(index, triple)`` every triple is handed over as it completes (from a lane
+    thread) and NOT kept: the pinned host blocks the results live in are recycled as soon as the
+    consumer lets go of them, and the returned list holds ``None``."""
     config = config if config is not None else Config()
     needs = (need_default, need_no_limiter, need_no_limiter_normalized)
     out = [None] * len(pairs)
 
     def done(index, value, exc):
-        out[index] = value
+        if on_result is not None and exc is None:
+            on_result(index, value)
+        else:
+            out[index] = value
 
-    pool = _Lanes(lambda lane: _device_worker(device_index, config, needs, master), max(1, min(lanes, len(pairs) or 1)))
+    pool = _Lanes(lambda lane: _device_worker(device_index, lane, config, needs, master), max(1, min(lanes, len(pairs) or 1)))
     for i, pair in enumerate(pairs):
         pool.submit(i, pair, done)
     pool.close()
@@ -190,7 +210,7 @@ def process_batch(jobs, config=None, rank=None, world_size=None, device_index=No
                 index, arrays = item
                 needs = _needs_of(jobs[index]["results"])
                 if needs not in workers:
-                    workers[needs] = _device_worker(device_index, config, needs, master)
+                    workers[needs] = _device_worker(device_index, lane, config, needs, master)
                 return workers[needs](arrays)
             return run
 

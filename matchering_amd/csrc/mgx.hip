@@ -751,6 +751,27 @@ int mgx_memcpy_d2h(mgx_handle* h, void* host, const void* dev, size_t bytes) {
     HIP_TRY(hipStreamSynchronize(h->stream));
     return 0;
 }
+// pinned host memory + copies that do not wait: the pieces of an overlapped host <-> HBM pipeline
+int mgx_host_alloc(size_t bytes, void** host) {
+    if (!host) return fail(MGX_ERR_ARGUMENT, "null argument");
+    HIP_TRY(hipHostMalloc(host, bytes ? bytes : 256, hipHostMallocDefault));
+    return 0;
+}
+int mgx_host_free(void* host) {
+    if (!host) return 0;
+    HIP_TRY(hipHostFree(host));
+    return 0;
+}
+int mgx_memcpy_h2d_async(mgx_handle* h, void* dev, const void* host, size_t bytes) {
+    if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
+    HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, h->stream));
+    return 0;
+}
+int mgx_memcpy_d2h_async(mgx_handle* h, void* host, const void* dev, size_t bytes) {
+    if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
+    HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    return 0;
+}
 int mgx_synchronize(mgx_handle* h) {
     if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
     HIP_TRY(hipStreamSynchronize(h->stream));

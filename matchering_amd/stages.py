@@ -63,7 +63,9 @@ def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default
                 debug(f"unlimited result normalised by {to_db(report.normalize_coefficient)} to reach the threshold")
             if need_default and not report.limiter_active:
                 debug("the result stays under the threshold: the limiter passes it through")
-            results = tuple(dev.download(b, (n, 2)) if b is not None else None for b in outs)
+            # queued one behind the other, then ONE wait; the arrays live in pinned host memory
+            results = tuple(dev.download(b, (n, 2), wait=False) if b is not None else None for b in outs)
+            dev.synchronize()
         finally:
             for b in (t_dev, r_dev, *outs):
                 if b is not None:

@@ -427,3 +427,24 @@ def test_other_fft_sizes(fft_size):
     want = mo.master(t, r, mo.params(**kw), True, True, False)
     for mine, ref in zip(got[:2], want[:2]):
         assert rms_error(mine, ref) <= RMS_TOL
+
+
+def test_pinned_and_pageable_transfers_agree():
+    """Device.upload moves pinned arrays by DMA where they are and stages everything else through pinned
+    blocks in chunks; Device.download returns pinned arrays.  Same bytes either way, odd sizes included."""
+    from matchering_amd.device import default_device, pinned
+
+    dev = default_device()
+    rng = np.random.RandomState(5)
+    for n in (1, 1023, (8 << 20) // 8 + 7, 3 * (8 << 20) // 8 - 1):
+        x = rng.randn(n, 2).astype(np.float32)
+        px = pinned.empty(x.shape)
+        px[...] = x
+        assert pinned.holds(px) and not pinned.holds(x)
+        with dev.lock:
+            a, b = dev.upload(x), dev.upload(px)
+            ya, yb = dev.download(a, x.shape, wait=False), dev.download(b, x.shape, wait=False)
+            dev.synchronize()
+            a.release()
+            b.release()
+        assert pinned.holds(ya) and np.array_equal(ya, x) and np.array_equal(yb, x)

@@ -352,8 +352,11 @@ def test_stages_main_host_glue_with_a_stand_in_device():
             rep.limiter_active = 1
             return rep
 
-        def download(self, buf, shape, dtype=np.float32):
+        def download(self, buf, shape, dtype=np.float32, wait=True):
             return buf.array.reshape(shape).astype(dtype)
+
+        def synchronize(self):
+            pass
 
     t, r = make_pair(6.0, 44100, pair=1, reference_gain=0.5)       # quiet reference: the amplitude branch logs too
     lines = []
