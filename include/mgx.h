@@ -160,6 +160,16 @@ int mgx_limit(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cf
 /* dsp.py:89-90 amplify on interleaved frames: out = x * gain */
 int mgx_scale(mgx_handle* h, const float* x_dev, int64_t n, double gain, float* out_dev);
 
+/* Album mode (the use of the FIR broadcast): stages.main with the matching-EQ FIR
+ * GIVEN instead of designed from this pair's spectra -- `fir_dev` = [2][fft_size] float32 in HBM, mid
+ * taps then side taps, e.g. the table mgx_last_fir returns on the rank that designed it, after
+ * mgx_comm_broadcast_f32 brought it here.  Levels are still matched per track (stages.py:80-91,
+ * 138-170 unchanged); only match_frequencies.py:78-101 is replaced. */
+int mgx_master_with_fir(mgx_handle* h, const float* target_dev, int64_t n_target, const float* reference_dev,
+                        int64_t n_reference, const mgx_config* cfg, const float* fir_dev, float* result_dev,
+                        float* result_no_limiter_dev, float* result_no_limiter_normalized_dev,
+                        mgx_report* report);
+
 /* Measurement aid (bench.py): with timing enabled, mgx_master brackets each of
  * its stages with HIP events recorded on the handle's own stream (no synchronisation is added);
  * mgx_stage_times waits for the stream and returns the device time of every stage of the LAST

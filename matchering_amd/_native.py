@@ -83,6 +83,8 @@ SYMBOLS = {
     "mgx_timer_stop": (ctypes.c_int, [_VP, c_float_p]),
     "mgx_master": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, _VP, ctypes.c_int64, ctypes.POINTER(MgxConfig),
                                   _VP, _VP, _VP, ctypes.POINTER(MgxReport)]),
+    "mgx_master_with_fir": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, _VP, ctypes.c_int64, ctypes.POINTER(MgxConfig),
+                                           _VP, _VP, _VP, _VP, ctypes.POINTER(MgxReport)]),
     "mgx_analyze": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.POINTER(MgxConfig), ctypes.c_int,
                                    c_double_p, c_double_p, c_double_p, c_int32_p, c_int64_p,
                                    c_double_p, c_int32_p, c_double_p, c_double_p]),

@@ -151,6 +151,49 @@ def master_many(pairs, config=None, need_default=True, need_no_limiter=False,
     return out
 
 
+def master_album(targets, reference, config=None, rank=None, world_size=None, device_index=None, root=0,
+                 exchange=None, need_default=True, need_no_limiter=False, need_no_limiter_normalized=False):
+    """Album mode across the ranks of one node: ONE matching FIR for every track.
+
+    Rank ``root`` masters ``targets[0]`` against ``reference`` the ordinary way; the FIR pair it designed
+    (2 x fft_size float32, 32 KiB at the default size) is the only thing that crosses xGMI -- one
+    ``ncclBroadcast`` over RCCL -- and every rank then masters its share of the targets (track i -> rank
+    i mod world) with that FIR given (``mgx_master_with_fir``), levels still matched per track.  Returns
+    ``{index: triple}`` for this rank's tracks.  ``exchange(payload, size)`` must hand rank 0's 128-byte
+    RCCL id to all ranks (bench.Ranks.broadcast_bytes); not needed with one rank."""
+    from .stages import main
+
+    config = config if config is not None else Config()
+    r, w, local = rank_and_world(rank, world_size)
+    dev = lane_device(local if device_index is None else device_index, 0)
+    needs = (need_default, need_no_limiter, need_no_limiter_normalized)
+    count = 2 * config.fft_size
+    mine = shard(targets, r, w)
+    results = {}
+    with dev.lock:
+        fir = dev.alloc(count * 4)
+        if r == root:                                           # the design pass; its result is track 0's
+            first = main(targets[0], reference, config, *needs, device=dev)
+            taps_ptr, taps = dev.last_fir()
+            assert taps == config.fft_size
+            designed = dev.download(taps_ptr, (count,))
+            fir.release()
+            fir = dev.upload(designed)
+            if 0 in mine:
+                results[0] = first
+        dev.comm_init(r, w, exchange)
+        try:
+            dev.comm_broadcast(fir, count, root)
+            dev.synchronize()
+        finally:
+            dev.comm_destroy()
+        for i in mine:
+            if i not in results:
+                results[i] = main(targets[i], reference, config, *needs, device=dev, fir=fir)
+        fir.release()
+    return results
+
+
 def _needs_of(results):
     return (any(r.use_limiter for r in results),
             any(not r.use_limiter and not r.normalize for r in results),

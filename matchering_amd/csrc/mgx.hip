@@ -395,7 +395,9 @@ static int build_fir_operator(mgx_handle* h, const FirPlanView& pl, double** out
     return 0;
 }
 
-static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork& tw, const TrackWork& rw) {
+// fir_given: a FIR pair to use instead of the designed one (album mode), or null
+static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork& tw, const TrackWork& rw,
+                          const float* fir_given) {
     FirDesignParams p{cfg->fft_size, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac,
                       cfg->lowess_it, cfg->lowess_delta, cfg->min_value};
     std::shared_ptr<FirPlanHost> plan = FirPlanHost::get(p);
@@ -445,6 +447,13 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
         in.part_r = (const double*)rw.part.p;
         hipLaunchKernelGGL(k_fir_raw, dim3((pl.bins + 255) / 256, 2), dim3(256), 0, h->stream, pl, in, raw,
                            (double*)h->scalars.p, (CorrectionState*)h->cstate.p);
+    }
+    if (fir_given) {             // the levels above are this pair's own; the matching EQ is somebody else's
+        if (fir_given != (const float*)h->taps.p)
+            HIP_TRY(hipMemcpyAsync(h->taps.p, fir_given, (size_t)2 * cfg->fft_size * sizeof(float),
+                                   hipMemcpyDeviceToDevice, h->stream));
+        h->last_taps = cfg->fft_size;
+        return 0;
     }
     hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
                        (const int2*)pd.band, (const double*)raw, scratch);
@@ -928,9 +937,10 @@ int mgx_scale(mgx_handle* h, const float* x_dev, int64_t n, double gain, float* 
 }
 
 // ---- the boundary: stages.main ----------------------------------------------
-int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const float* reference_dev,
-               int64_t n_reference, const mgx_config* cfg, float* result_dev, float* result_no_limiter_dev,
-               float* result_no_limiter_normalized_dev, mgx_report* report) {
+} // extern "C"
+static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target, const float* reference_dev,
+                       int64_t n_reference, const mgx_config* cfg, const float* fir_given, float* result_dev,
+                       float* result_no_limiter_dev, float* result_no_limiter_normalized_dev, mgx_report* report) {
     if (!h || !target_dev || !reference_dev) return fail(MGX_ERR_ARGUMENT, "null argument");
     MGX_TRY(check_config(cfg));
     HIP_TRY(hipSetDevice(h->device));
@@ -955,7 +965,7 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
     // the level gain of stages.py:80-88 (a device scalar) folded into the filter spectra
     {
         StageScope scope(h, MGX_STAGE_DESIGN_FIR);
-        MGX_TRY(run_fir_design(h, cfg, tw, rw));
+        MGX_TRY(run_fir_design(h, cfg, tw, rw, fir_given));
     }
     MGX_TRY(ensure(h, h->y, (size_t)n_target * sizeof(float2)));
     MGX_TRY(ensure(h, h->mid, (size_t)n_target * sizeof(float)));
@@ -1086,6 +1096,21 @@ int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const f
         report->limiter_active = hc->limiter_active;
     }
     return 0;
+}
+
+extern "C" {
+int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target, const float* reference_dev,
+               int64_t n_reference, const mgx_config* cfg, float* result_dev, float* result_no_limiter_dev,
+               float* result_no_limiter_normalized_dev, mgx_report* report) {
+    return master_impl(h, target_dev, n_target, reference_dev, n_reference, cfg, nullptr, result_dev,
+                       result_no_limiter_dev, result_no_limiter_normalized_dev, report);
+}
+int mgx_master_with_fir(mgx_handle* h, const float* target_dev, int64_t n_target, const float* reference_dev,
+                        int64_t n_reference, const mgx_config* cfg, const float* fir_dev, float* result_dev,
+                        float* result_no_limiter_dev, float* result_no_limiter_normalized_dev, mgx_report* report) {
+    if (!fir_dev) return fail(MGX_ERR_ARGUMENT, "null FIR");
+    return master_impl(h, target_dev, n_target, reference_dev, n_reference, cfg, fir_dev, result_dev,
+                       result_no_limiter_dev, result_no_limiter_normalized_dev, report);
 }
 
 int mgx_stage_timing(mgx_handle* h, int32_t enable) {

@@ -229,18 +229,48 @@ class Device:
 
     # ---- the boundary ------------------------------------------------------------
     def master(self, target, n_target, reference, n_reference, native_config, result=None,
-               result_no_limiter=None, result_no_limiter_normalized=None, want_report=True):
-        """``mgx_master`` on device buffers.  Outputs are DeviceBuffers or None."""
+               result_no_limiter=None, result_no_limiter_normalized=None, want_report=True, fir=None):
+        """``mgx_master`` on device buffers.  Outputs are DeviceBuffers or None.  ``fir`` (a DeviceBuffer
+        holding [2][fft_size] float32) replaces the designed matching FIR: ``mgx_master_with_fir``."""
         report = MgxReport() if want_report else None
 
         def p(b):
             return ctypes.c_void_p(b.ptr) if b is not None else None
 
-        check(library().mgx_master(
-            self.handle, p(target), n_target, p(reference), n_reference, ctypes.byref(native_config),
-            p(result), p(result_no_limiter), p(result_no_limiter_normalized),
-            ctypes.byref(report) if report is not None else None))
+        rep = ctypes.byref(report) if report is not None else None
+        if fir is None:
+            check(library().mgx_master(
+                self.handle, p(target), n_target, p(reference), n_reference, ctypes.byref(native_config),
+                p(result), p(result_no_limiter), p(result_no_limiter_normalized), rep))
+        else:
+            check(library().mgx_master_with_fir(
+                self.handle, p(target), n_target, p(reference), n_reference, ctypes.byref(native_config), p(fir),
+                p(result), p(result_no_limiter), p(result_no_limiter_normalized), rep))
         return report
+
+    def last_fir(self):
+        """(device address, taps) of the FIR pair the last ``master`` designed or was given."""
+        ptr, taps = ctypes.c_void_p(), ctypes.c_int32()
+        check(library().mgx_last_fir(self.handle, ctypes.byref(ptr), ctypes.byref(taps)))
+        return ptr.value, taps.value
+
+    # ---- RCCL: the FIR exchange of the multi-GPU path --------------------------------
+    def comm_init(self, rank, world, exchange=None):
+        """Join a communicator of ``world`` ranks.  ``exchange(payload, size) -> bytes`` must hand rank 0's
+        128-byte id to every rank (bench.Ranks.broadcast_bytes does); not needed for world == 1."""
+        lib = library()
+        uid = ctypes.create_string_buffer(128)
+        if rank == 0:
+            check(lib.mgx_comm_unique_id(uid))
+        payload = uid.raw if exchange is None else exchange(uid.raw, 128)
+        check(lib.mgx_comm_init(self.handle, ctypes.c_char_p(payload), rank, world))
+
+    def comm_broadcast(self, buf, count, root=0):
+        ptr = buf if isinstance(buf, int) else buf.ptr
+        check(library().mgx_comm_broadcast_f32(self.handle, ctypes.c_void_p(ptr), count, root))
+
+    def comm_destroy(self):
+        check(library().mgx_comm_destroy(self.handle))
 
 
 _default = {}

@@ -26,7 +26,10 @@ def _as_frames(array, name):
 
 
 def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default: bool = True,
-         need_no_limiter: bool = False, need_no_limiter_normalized: bool = False, device=None):
+         need_no_limiter: bool = False, need_no_limiter_normalized: bool = False, device=None, fir=None):
+    # (``device``: the handle to run on, default the process-wide one; ``fir``: a DeviceBuffer with a
+    # matching FIR to apply instead of designing one -- batch.master_album.  Both are additions to the
+    # reference's signature, keyword-only in spirit.)
     dev = device if device is not None else default_device()
     target = _as_frames(target, "target")
     reference = _as_frames(reference, "reference")
@@ -43,7 +46,7 @@ def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default
         outs = [dev.alloc(n * 8) if need else None
                 for need in (need_default, need_no_limiter, need_no_limiter_normalized)]
         try:
-            report = dev.master(t_dev, n, r_dev, nr, native, *outs)
+            report = dev.master(t_dev, n, r_dev, nr, native, *outs, fir=fir)
             debug(f"target: {report.target_divisions} pieces of {report.target_piece} frames, "
                   f"{report.target_loud_count} of them loud; reference: {report.reference_divisions} pieces of "
                   f"{report.reference_piece} frames, {report.reference_loud_count} loud")

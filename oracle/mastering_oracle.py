@@ -293,9 +293,11 @@ def limit(y, cfg):
 # the pipeline  (stages.py:210-272)
 # --------------------------------------------------------------------------
 def master(target, reference, cfg, need_default=True, need_no_limiter=False,
-           need_no_limiter_normalized=False, trace=None):
+           need_no_limiter_normalized=False, trace=None, fir=None):
     """Float64 restatement of ``matchering.stages.main``.  ``trace`` (a dict)
-    receives the intermediates the per-stage parity tests compare against."""
+    receives the intermediates the per-stage parity tests compare against.
+    ``fir`` = (mid taps, side taps) replaces the FIR pair of stage 2 (not a reference
+    feature: the checker of the album mode of matchering_amd/batch.py)."""
     target = np.asarray(target, dtype=np.float64)
     reference = np.asarray(reference, dtype=np.float64)
     eps = cfg.min_value
@@ -310,6 +312,8 @@ def master(target, reference, cfg, need_default=True, need_no_limiter=False,
     # stage 2, stages.py:107-135
     fir_mid, dm = design_fir(t.mid_loud * c0, r.mid_loud, cfg)
     fir_side, ds = design_fir(t.side_loud * c0, r.side_loud, cfg)
+    if fir is not None:
+        fir_mid, fir_side = np.asarray(fir[0], dtype=np.float64), np.asarray(fir[1], dtype=np.float64)
     y, y_mid = convolve_same(t_mid, fir_mid, t_side, fir_side)
 
     # stage 3, stages.py:138-170

@@ -122,3 +122,78 @@ def test_gpu_lanes_are_bit_identical_to_single_runs():
     for (t, r), triple in zip(pairs, many):
         want = stages.main(t, r, cfg, need_default=True, need_no_limiter=True)
         assert np.array_equal(triple[0], want[0]) and np.array_equal(triple[1], want[1])
+
+
+@pytest.mark.gpu
+def test_gpu_album_mode_one_broadcast_fir_for_every_track():
+    """batch.master_album on one rank: the FIR designed on track 0 goes through ncclBroadcast (RCCL, a
+    one-rank communicator here) and is applied to every track; levels are matched per track.  Track 0
+    equals ordinary mastering bit for bit, the others equal the oracle run with that FIR given."""
+    import mastering_oracle as mo
+    from matchering_amd import stages
+
+    cfg = mg.Config(max_piece_size=2.0)
+    reference = np.clip(2.5 * synth(5.0, 44100, 40), -1, 1).astype(np.float32)
+    targets = [(0.5 * synth(6.0 + b, 44100, 41 + b, corner=1500.0 + 700.0 * b)).astype(np.float32) for b in range(3)]
+    album = batch.master_album(targets, reference, cfg, rank=0, world_size=1, need_default=True, need_no_limiter=True)
+    assert sorted(album) == [0, 1, 2]
+    plain = stages.main(targets[0], reference, cfg, need_default=True, need_no_limiter=True)
+    assert np.array_equal(album[0][0], plain[0]) and np.array_equal(album[0][1], plain[1])
+    tr = {}
+    ocfg = mo.params(max_piece_size=2.0)
+    mo.master(targets[0], reference, ocfg, True, True, False, trace=tr)
+    for b in (1, 2):
+        want = mo.master(targets[b], reference, ocfg, True, True, False, fir=(tr["fir_mid"], tr["fir_side"]))
+        own = mo.master(targets[b], reference, ocfg, True, True, False)
+        for mine, ref, other in zip(album[b][:2], want[:2], own[:2]):
+            err = float(np.sqrt(np.mean((mine.astype(np.float64) - ref) ** 2)))
+            assert err <= 1e-5
+            assert float(np.sqrt(np.mean((ref - other) ** 2))) > 10 * err     # it IS another FIR than the track's own
+
+
+def _batch_rank(rank, world, tmp, port, queue):
+    import os
+    import sys
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")     # both ranks on the one GPU
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import matchering_amd as mg2
+    from matchering_amd import batch as b2
+
+    cfg = mg2.Config(max_piece_size=2.0)
+    jobs = [{"target": os.path.join(tmp, f"t{k}.wav"), "reference": os.path.join(tmp, f"r{k}.wav"),
+             "results": [mg2.Result(os.path.join(tmp, f"out{k}.wav"), "FLOAT")]} for k in range(5)]
+    queue.put((rank, b2.process_batch(jobs, cfg, lanes=2, io_threads=2)))
+
+
+@pytest.mark.gpu
+def test_gpu_process_batch_two_ranks_share_the_gpu(tmp_path):
+    """The N > 1 path of the batch front end with real kernels: two PROCESSES (rank 0 and 1 of a world of
+    2, both on the one visible GPU) take their shares of five jobs -- pair i -> rank i mod 2 -- and every
+    result file matches the oracle."""
+    import multiprocessing as mp
+
+    import mastering_oracle as mo
+
+    rate = 44100
+    pairs = []
+    for k in range(5):
+        t = (0.5 * synth(4.0 + 0.5 * k, rate, 61 + 2 * k)).astype(np.float32)
+        r = np.clip(2.5 * synth(4.0, rate, 62 + 2 * k), -1, 1).astype(np.float32)
+        audio_io.write_wav(str(tmp_path / f"t{k}.wav"), t, rate, "FLOAT")
+        audio_io.write_wav(str(tmp_path / f"r{k}.wav"), r, rate, "FLOAT")
+        pairs.append((t, r))
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    procs = [ctx.Process(target=_batch_rank, args=(rank, 2, str(tmp_path), 0, queue)) for rank in range(2)]
+    for p in procs:
+        p.start()
+    shares = dict(queue.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert shares == {0: [0, 2, 4], 1: [1, 3]}
+    for k, (t, r) in enumerate(pairs):
+        got, _ = audio_io.read_wav(str(tmp_path / f"out{k}.wav"))
+        want = mo.master(t, r, mo.params(max_piece_size=2.0), True, False, False)[0]
+        assert float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2))) <= 1e-5

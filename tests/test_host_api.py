@@ -332,7 +332,8 @@ def test_stages_main_host_glue_with_a_stand_in_device():
             self.buffers.append(b)
             return b
 
-        def master(self, t, n, r, nr, native, result=None, result_no_limiter=None, result_no_limiter_normalized=None):
+        def master(self, t, n, r, nr, native, result=None, result_no_limiter=None, result_no_limiter_normalized=None,
+                   fir=None):
             tr = {}
             outs = mo.master(t.array.astype(np.float64), r.array.astype(np.float64),
                              mo.params(max_piece_size=2.0), result is not None, result_no_limiter is not None,
