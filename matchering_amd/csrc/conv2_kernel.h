@@ -34,22 +34,6 @@ namespace mgx {
 // Non-temporal or sc0 LOADS were measured slower (198 / 186 us) and stay at the default policy.
 constexpr int CONV_STORE_AUX = 2;
 
-// What round 0 leaves behind per SEGMENT of a piece -- a chunk of k_correction_round, or the part of a
-// convolution pair that lies in the piece when the convolution's epilogue does round 0 itself
-// (conv_round0 below).  Segments are indexed [piece][slot]; k_correction_tail reads nothing else.
-constexpr int BAND_MAX_WAVES = 16;
-struct BandSeg {
-    double sumsq;                            // round 0's own sum over the segment: sum clip(m)^2 (fused mode)
-    double unclipped_sumsq;                  // A: sum of m^2 over |m| <= 1/BAND_G_HI
-    double clipped_count;                    // C: samples with |m| > 1/BAND_G_LO
-    long long begin, end;                    // frames of the segment (for the rare re-stream)
-    long long list0;                         // float index in the band buffer of producer wave 0's list
-    int stride;                              // floats between the lists of consecutive producer waves
-    int reversed;                            // 1: a list grows downwards from list0 + stride - 1
-    int waves;                               // producer waves (0: an empty slot)
-    int pad;
-    int count[BAND_MAX_WAVES];               // band samples compacted by each producer wave
-};
 struct Conv2Args {
     const float2* x;       // (n,2) interleaved L/R input frames
     long long n;           // frames
@@ -62,17 +46,6 @@ struct Conv2Args {
     long long npairs;      // ceil(n / N)
     float* pair_peak;      // [npairs] max(|yL|,|yR|) per pair, or nullptr
     unsigned* queue;       // [8] pairs handed out per XCD beyond the first round, [8] workgroups done; zero between launches
-    // Round 0 of the level correction (stages.py:149-160) on the mid results as they pass by
-    // (conv_round0, mgx_kernels.h), or nullptr.  A pointer, not the fields: the kernel has no scalar
-    // registers to spare, and these are read once per pair.
-    const struct Round0Plan* r0;
-};
-struct Round0Plan {
-    BandSeg* segs;         // [divisions][slots]: sums and band lists per (piece, pair part)
-    float* band;           // [npairs * N] band lists, one region of N / waves floats per pair and wave
-    long long piece;       // piece size of the TARGET (stages.py:153-154), > N
-    int divisions, slots;
-    unsigned long long* tail_gains;      // [16] preset to "not yet" for k_correction_tail
 };
 
 template <int LOG2N>
@@ -319,8 +292,6 @@ struct Conv2Block {
                 // operand: the range check adds it to the lane offset (tools/micro/buffer_range.hip)
                 st_f2<CONV_STORE_AUX>(dst, first * 8u, (unsigned)(j * S0 * 8), ya);
                 st_f2<CONV_STORE_AUX>(dst, first * 8u, (unsigned)((j * S0 + LOUT) * 8), yb);
-                // (with no mid plane asked for `dm` is an empty view: the range check drops these stores before
-                // they cost anything but their issue slots -- a branch around them costs 40 spilled registers)
                 st_f1<CONV_STORE_AUX>(dm, first * 4u, (unsigned)(j * S0 * 4), m.x);
                 st_f1<CONV_STORE_AUX>(dm, first * 4u, (unsigned)((j * S0 + LOUT) * 4), m.y);
                 const float pa = fmaxf(fabsf(ya.x), fabsf(ya.y)), pb = fmaxf(fabsf(yb.x), fabsf(yb.y));

@@ -79,7 +79,7 @@ struct mgx_handle {
     std::map<int, float2*> twiddles;
     TrackWork track[2];
     DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars, conv_queue;
-    DevBuf lim_published, lim_ctrl, lim_weights, round_ctr, tail_gains, band, band_info, round0_plan;
+    DevBuf lim_published, lim_ctrl, lim_weights, round_ctr, tail_gains, band, band_info;
     std::vector<double> lim_weights_host;
     DevBuf fir_scratch;
     std::map<const FirPlanHost*, PlanDev> plan_dev;               // uploaded plan blobs + dense operators
@@ -468,8 +468,7 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
 }
 
 template <int LOG2N, bool MULTI>
-static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr,
-                       const Round0Plan& plan) {
+static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr) {
     using F = Fft2<LOG2N>;
     const size_t lds = conv_lds_bytes<LOG2N>();
     MGX_TRY((allow_lds(k_conv_prep<LOG2N>, lds)));
@@ -477,7 +476,7 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
     {
         StageScope scope(h, MGX_STAGE_FILTER_SPECTRA);
         hipLaunchKernelGGL((k_conv_prep<LOG2N>), dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev,
-                           a.tw, (float2*)h->filt.p, a.parts, gain_ptr, gain, plan, const_cast<Round0Plan*>(a.r0));
+                           a.tw, (float2*)h->filt.p, a.parts, gain_ptr, gain);
     }
     HIP_TRY(hipGetLastError());
     MGX_TRY(ensure(h, h->block_peak, (size_t)a.npairs * sizeof(float)));
@@ -505,18 +504,13 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
 // N = 2F per filter; longer filters (config #5: 16 k taps at 96 kHz) are cut into K = F/4096
 // partitions on N = 8192 blocks (uniformly partitioned overlap-save), because N = 2F no longer fits
 // a CU's LDS.
-// frames per convolution pair for a FIR of `taps`: the block size N = 2 * taps while that fits a CU's LDS
-static int conv_block_log2(int taps) {
-    const int log2b = ilog2_exact(taps) + 1;
-    return log2b > 14 ? 13 : log2b;
-}
 static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const float* taps_dev, double gain,
-                    float* y, float* ymid, long long* npairs_out, const double* gain_ptr = nullptr,
-                    const Round0Plan* r0 = nullptr) {
+                    float* y, float* ymid, long long* npairs_out, const double* gain_ptr = nullptr) {
     const int l = ilog2_exact(taps);
     if (l < 0) return fail(MGX_ERR_ARGUMENT, "FIR length must be a power of two");
     MGX_TRY(check_length(n));
-    const int log2b = conv_block_log2(taps);
+    int log2b = l + 1;
+    if (log2b > 14) log2b = 13;
     const size_t nb = (size_t)1 << log2b;
     const int parts = (int)((size_t)2 * taps / nb);
     const long long pair_frames = (long long)nb;
@@ -531,18 +525,11 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     a.parts = parts;
     a.npairs = (n + pair_frames - 1) / pair_frames;
     a.pair_peak = nullptr;
-    a.r0 = nullptr;
-    Round0Plan plan{};
-    if (r0) {
-        MGX_TRY(ensure(h, h->round0_plan, sizeof(Round0Plan)));
-        a.r0 = (const Round0Plan*)h->round0_plan.p;
-        plan = *r0;
-    }
     MGX_TRY(get_twiddles(h, log2b, &a.tw));
     if (npairs_out) *npairs_out = a.npairs;
-    if (parts > 1) return launch_conv<13, true>(h, a, taps_dev, gain, gain_ptr, plan);
+    if (parts > 1) return launch_conv<13, true>(h, a, taps_dev, gain, gain_ptr);
     switch (log2b) {
-#define CASE(L) case L: return launch_conv<L, false>(h, a, taps_dev, gain, gain_ptr, plan);
+#define CASE(L) case L: return launch_conv<L, false>(h, a, taps_dev, gain, gain_ptr);
         CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return fail(MGX_ERR_UNSUPPORTED, "FIR length not supported by the convolution kernel");
@@ -722,7 +709,7 @@ int mgx_destroy(mgx_handle* h) {
     hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
-                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info, &h->round0_plan,
+                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info,
                       &h->conv_queue};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -981,58 +968,38 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
         MGX_TRY(run_fir_design(h, cfg, tw, rw, fir_given));
     }
     MGX_TRY(ensure(h, h->y, (size_t)n_target * sizeof(float2)));
-    // Round 0 of stage 3 rides in the convolution's epilogue (conv_round0) whenever a pair of blocks meets
-    // at most one piece boundary; then no mid plane is written at all.  Tiny pieces fall back to the mid
-    // plane and a launch of k_correction_round.
-    const int rounds = cfg->rms_correction_steps;
-    const long long span = 1ll << conv_block_log2(f);
-#ifdef MGX_DEV_SEPARATE_ROUND0        // development builds only (tools/ab_libs.sh): the unfused path on every size
-    const bool fused = false;
-#else
-    const bool fused = rounds >= 1 && tw.piece > span;
-#endif
-    const int seg_slots = fused ? (int)(tw.piece / span) + 2 : std::max(1, 1024 / tw.divisions);
-    MGX_TRY(ensure(h, h->band_info, (size_t)tw.divisions * seg_slots * sizeof(BandSeg)));
-    MGX_TRY(ensure(h, h->tail_gains, 16 * sizeof(unsigned long long)));
-    Round0Plan r0{(BandSeg*)h->band_info.p, nullptr, tw.piece, tw.divisions, seg_slots, (unsigned long long*)h->tail_gains.p};
-    if (fused) {
-        MGX_TRY(ensure(h, h->band, (size_t)((n_target + span - 1) / span) * span * sizeof(float)));
-    } else {
-        MGX_TRY(ensure(h, h->mid, (size_t)n_target * sizeof(float)));
-        MGX_TRY(ensure(h, h->band, ((size_t)n_target + (size_t)tw.divisions * seg_slots * BAND_SLACK) * sizeof(float)));
-    }
-    r0.band = (float*)h->band.p;
+    MGX_TRY(ensure(h, h->mid, (size_t)n_target * sizeof(float)));
     long long nblocks = 0;
-    MGX_TRY(run_conv(h, target_dev, n_target, f, (const float*)h->taps.p, 1.0, (float*)h->y.p,
-                     fused ? nullptr : (float*)h->mid.p, &nblocks, (const double*)h->scalars.p, fused ? &r0 : nullptr));
-    // stage 3 (stages.py:138-170): scalar feedback stays on the device; the rounds after the first share
-    // one launch, and the last round also derives the peak / early-out / normalisation scalars (the state
-    // was reset by k_match_curve)
+    MGX_TRY(run_conv(h, target_dev, n_target, f, (const float*)h->taps.p, 1.0, (float*)h->y.p, (float*)h->mid.p,
+                     &nblocks, (const double*)h->scalars.p));
+    // stage 3 (stages.py:138-170): scalar feedback stays on the device; one launch per round, the last
+    // round also derives the peak / early-out / normalisation scalars (the state was reset by k_fir_raw)
     CorrectionState* cs = (CorrectionState*)h->cstate.p;
     bool limiter_preset = false;
     {
         StageScope scope(h, MGX_STAGE_CORRECT_LEVELS);
         RoundArgs ra;
-        ra.mid = fused ? nullptr : (const float*)h->mid.p;
-        ra.y = (const float2*)h->y.p;
-        ra.pair_span = fused ? span : 0;
+        ra.mid = (const float*)h->mid.p;
         ra.piece = tw.piece;
         ra.divisions = tw.divisions;
         ra.chunks = std::max(1, 1024 / tw.divisions);        // ~1000 workgroups: each pays one publish + ticket
-        ra.slots = seg_slots;
         MGX_TRY(ensure(h, h->partial, (size_t)ra.divisions * ra.chunks * sizeof(double)));
         ra.partial = (double*)h->partial.p;
         // arrival counters [1 + divisions], zero between launches; the 16 gain words of k_correction_tail
         // live in their own buffer (a layout that moved with `divisions` would leave one call's preset
         // gain words where the next call counts arrivals)
         const size_t ctr_bytes = (size_t)(1 + ra.divisions) * sizeof(unsigned);
+        MGX_TRY(ensure(h, h->tail_gains, 16 * sizeof(unsigned long long)));
         if (h->round_ctr.bytes < ctr_bytes) {                 // zeroed when (re)allocated, reset by each launch
             MGX_TRY(ensure(h, h->round_ctr, std::max(ctr_bytes, (size_t)4096)));
             HIP_TRY(hipMemsetAsync(h->round_ctr.p, 0, h->round_ctr.bytes, h->stream));
         }
         ra.arrivals = (unsigned*)h->round_ctr.p;
+        const size_t wgs = (size_t)ra.divisions * ra.chunks;
+        MGX_TRY(ensure(h, h->band, ((size_t)n_target + wgs * BAND_SLACK) * sizeof(float)));
+        MGX_TRY(ensure(h, h->band_info, wgs * sizeof(BandInfo)));
         ra.band = (float*)h->band.p;
-        ra.segs = (BandSeg*)h->band_info.p;
+        ra.info = (BandInfo*)h->band_info.p;
         ra.reference_match_rms = &((const TrackStats*)rw.stats.p)->match_rms;
         ra.eps = cfg->min_value;
         ra.threshold = cfg->threshold;
@@ -1044,13 +1011,11 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
         if (lds_step > (size_t)150 * 1024)
             return fail(MGX_ERR_UNSUPPORTED, "too many analysis pieces for the level-correction kernel's LDS");
         MGX_TRY(allow_lds(k_correction_round, lds_step));
+        const int rounds = cfg->rms_correction_steps;
         ra.lim_published = nullptr;
         ra.lim_words = 0;
         ra.lim_ticket = nullptr;
-        ra.final_peaks = nullptr;
-        ra.build_band = 0;
-        ra.step = 0;
-        ra.tail_gains = (unsigned long long*)h->tail_gains.p;
+        ra.tail_gains = rounds > 1 ? (unsigned long long*)h->tail_gains.p : nullptr;
         auto with_final = [&](RoundArgs& r) -> int {          // the launch that runs the last round
             r.final_peaks = (const float*)h->block_peak.p;
             if (result_dev) {
@@ -1059,25 +1024,27 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
             }
             return 0;
         };
-        if (rounds >= 1 && !fused) {                          // round 0 streams the mid plane and builds the band lists
-            RoundArgs first = ra;
-            first.build_band = 1;
-            if (rounds == 1) MGX_TRY(with_final(first));
-            hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, first);
+        if (rounds >= 1) {                                    // round 0 streams the mid plane and builds the band lists
+            RoundArgs r0 = ra;
+            r0.final_peaks = nullptr;
+            r0.build_band = 1;
+            r0.step = 0;
+            if (rounds == 1) MGX_TRY(with_final(r0));
+            hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, r0);
         }
-        const int tail_rounds = fused ? rounds : rounds - 1;  // every further round inside one small resident grid
-        if (tail_rounds >= 1) {
+        if (rounds > 1) {                                     // every further round inside one small resident grid
             RoundArgs rt = ra;
-            rt.step = fused ? 0 : 1;
+            rt.build_band = 0;
+            rt.step = 1;
             MGX_TRY(with_final(rt));
-            // at most ~128 workgroups, at most 64 segments (the lanes of a wave) per workgroup
-            const int groups = std::max((ra.slots + 63) / 64, std::max(1, std::min(ra.slots, 128 / ra.divisions)));
+            // at most ~128 workgroups, at most 64 chunks (the lanes of a wave) per workgroup
+            const int groups = std::max((ra.chunks + 63) / 64, std::max(1, std::min(ra.chunks, 128 / ra.divisions)));
             const size_t lds_tail = correction_tail_lds_bytes(ra.divisions, groups);
             if (lds_tail > (size_t)150 * 1024)
                 return fail(MGX_ERR_UNSUPPORTED, "too many analysis pieces for the level-correction kernel's LDS");
             MGX_TRY(allow_lds(k_correction_tail, lds_tail));
             hipLaunchKernelGGL(k_correction_tail, dim3(ra.divisions * groups), dim3(256), lds_tail, h->stream, rt, groups,
-                               tail_rounds, fused ? 1 : 0);
+                               rounds - 1);
         }
         if (rounds == 0)
             hipLaunchKernelGGL(k_finalize_scalars, dim3(1), dim3(256), 0, h->stream, (const float*)h->block_peak.p,

@@ -60,27 +60,12 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
     return r;
 }
 
-// ---- band bookkeeping of the level-correction rounds (explained at k_correction_round) ----
-constexpr double BAND_G_LO = 0.7, BAND_G_HI = 1.5;
-constexpr int BAND_SLACK = 2048;             // floats of padding per workgroup in the band buffer
-// float32 thresholds on |m|, each rounded towards the inside of the band: |m| <= never implies
-// |m| <= 1/BAND_G_HI exactly, |m| >= always implies |m| > 1/BAND_G_LO
-__device__ __forceinline__ float band_threshold_never() {
-    const float t = (float)(1.0 / BAND_G_HI);
-    return (double)t <= 1.0 / BAND_G_HI ? t : __uint_as_float(__float_as_uint(t) - 1u);
-}
-__device__ __forceinline__ float band_threshold_always() {
-    const float t = (float)(1.0 / BAND_G_LO);
-    return (double)t > 1.0 / BAND_G_LO ? t : __uint_as_float(__float_as_uint(t) + 1u);
-}
-
 // ---------------------------------------------------------------------------
 // convolution
 // ---------------------------------------------------------------------------
 template <int LOG2N>
 constexpr size_t conv_lds_bytes() {
-    // transform buffer | middle-pass table | 128 B of reduction scratch | per-wave partials of conv_round0
-    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 128 + 64 * BAND_MAX_WAVES;
+    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 128;
 }
 
 // The phases of a kernel share index arithmetic (LDS addresses derived from the thread id).  Left
@@ -167,166 +152,6 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
     }
 }
 
-// ---- round 0 of the level correction inside the convolution -----------------------------------------
-// stages.py:149-160 needs, per piece of the target, the sum of clip(mid)^2 of the convolved mid channel
-// (the gain is 1 at round 0: the level gain of stages.py:80-88 is in the filter).  The mid results of a
-// pair sit in registers between the two channels of conv_pair, so the sum is taken there instead of
-// writing a mid plane (4 B/frame) and streaming it back in a launch of its own; the same pass leaves
-// what the later rounds need (k_correction_round explains the band): sum of m^2 of the never-clipped,
-// count of the always-clipped, the band's values compacted per wave.  A pair that straddles a piece
-// boundary yields two segments (piece sizes above N frames: at most one boundary per pair).
-// Per-wave partials go to `part` (LDS: per wave 4 doubles + 4 ints in 64 bytes); thread 0 combines them
-// after the workgroup's next barrier (conv_round0_publish).
-// The general form (a pair that meets a piece boundary or the end of the counted frames: one pair per
-// piece): out of line, so that its two-of-everything bookkeeping costs the common path no registers.
-// The samples come from LDS (`mids`: [T][2*CNT0*HALF] floats, written by the caller; the transform
-// buffer is idle between the two channels).
-template <int LOG2N>
-__device__ __attribute__((noinline)) void conv_round0_split(int tid, long long o0, long long edge, long long limit,
-                                                            float* band, const float* mids, char* part) {
-    using CB = Conv2Block<LOG2N>;
-    using F = Fft2<LOG2N>;
-    constexpr int WAVES = F::T / 64, SPAN = 2 * CB::LOUT, PER_WAVE = SPAN / WAVES, PER_THREAD = 2 * CB::CNT0 * CB::HALF;
-    const int wave = tid >> 6, lane = tid & 63;
-    float* list = band + o0 + (long long)wave * PER_WAVE;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const float t_never = band_threshold_never(), t_always = band_threshold_always();
-    float acc[2] = {0.f, 0.f}, low[2] = {0.f, 0.f};
-    int clipped[2] = {0, 0}, filled[2] = {0, 0};
-    const bool act = CB::active0(tid);
-    for (int i = 0; i < PER_THREAD; ++i) {                 // sample i of the thread: butterfly c, output j, block A or B
-        const int c = i / (2 * CB::HALF), j = (i / 2) % CB::HALF, second = i & 1;
-        const long long f = o0 + tid + c * CB::T + j * CB::S0 + second * CB::LOUT;
-        const float v = mids[(size_t)i * F::T + tid];
-        const float cl = fminf(fmaxf(v, -1.0f), 1.0f), m = fabsf(v);
-        const bool ok = act && f < limit, hi = f >= edge;
-        const float cc = ok ? cl * cl : 0.f;
-        acc[0] += hi ? 0.f : cc;
-        acc[1] += hi ? cc : 0.f;
-        const bool never = ok && m <= t_never, always = ok && m >= t_always;
-        const float ll = never ? v * v : 0.f;
-        low[0] += hi ? 0.f : ll;
-        low[1] += hi ? ll : 0.f;
-        clipped[0] += __popcll(__ballot(always && !hi));
-        clipped[1] += __popcll(__ballot(always && hi));
-        const bool in_band = ok && !never && !always;
-        const unsigned long long m0 = __ballot(in_band && !hi), m1 = __ballot(in_band && hi);
-        if (in_band && !hi) list[filled[0] + __popcll(m0 & below)] = v;
-        if (in_band && hi) list[PER_WAVE - 1 - (filled[1] + __popcll(m1 & below))] = v;   // the second list grows down
-        filled[0] += __popcll(m0);
-        filled[1] += __popcll(m1);
-    }
-    const double a0 = wave_sum((double)acc[0]), a1 = wave_sum((double)acc[1]);
-    const double l0 = wave_sum((double)low[0]), l1 = wave_sum((double)low[1]);
-    if (lane == 0) {
-        double* pd = reinterpret_cast<double*>(part + 64 * wave);
-        int* pi = reinterpret_cast<int*>(pd + 4);
-        pd[0] = a0; pd[1] = a1; pd[2] = l0; pd[3] = l1;
-        pi[0] = clipped[0]; pi[1] = clipped[1]; pi[2] = filled[0]; pi[3] = filled[1];
-    }
-}
-template <int LOG2N>
-__device__ __forceinline__ void conv_round0(int tid_, long long pair, const Conv2Args& a,
-                                            const typename Conv2Block<LOG2N>::Kept& k, char* part, float* lds) {
-    using CB = Conv2Block<LOG2N>;
-    using F = Fft2<LOG2N>;
-    constexpr int WAVES = F::T / 64, SPAN = 2 * CB::LOUT, PER_WAVE = SPAN / WAVES;
-    // (opaque: a lane mask or list address hoisted out of the persistent loop would sit in registers the
-    // filter phase does not have -- it answers with 46 spills)
-    const int tid = opaque(tid_);
-    const int wave = tid >> 6, lane = tid & 63;
-    const long long o0 = CB::first_output(pair);
-    const long long piece = a.r0->piece;
-    float* const band = a.r0->band;
-    const long long edge = (o0 / piece + 1) * piece;                     // first frame of the next piece
-    const long long limit = min((long long)a.r0->divisions * piece, a.n);        // frames from here on count nowhere
-    const bool act = CB::active0(tid);
-    if (!(o0 + SPAN <= edge && o0 + SPAN <= limit)) {                    // uniform, rare
-        __syncthreads();                                                 // every thread is through with the side results in LDS
-#pragma unroll
-        for (int c = 0; c < CB::CNT0; ++c)
-#pragma unroll
-            for (int j = 0; j < CB::HALF; ++j) {
-                lds[(size_t)((c * CB::HALF + j) * 2 + 0) * F::T + tid] = act ? k.v[c][j].x : 0.f;
-                lds[(size_t)((c * CB::HALF + j) * 2 + 1) * F::T + tid] = act ? k.v[c][j].y : 0.f;
-            }
-        conv_round0_split<LOG2N>(tid, o0, edge, limit, band, lds, part);        // (reads only its own LDS column)
-        return;
-    }
-    float* list = band + o0 + (long long)wave * PER_WAVE;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    const float t_never = band_threshold_never(), t_always = band_threshold_always();
-    // float32 sums over this thread's <= 32 samples (each term <= 1.5: 3e-7 of random relative error per
-    // thread, 1e-9 after the hundred thousand threads of a piece), float64 from the wave sums on
-    float acc = 0.f, low = 0.f;
-    int clipped = 0, filled = 0;                                         // wave-uniform
-    auto visit = [&](float v) {
-        const float c = fminf(fmaxf(v, -1.0f), 1.0f);
-        const float m = fabsf(v);
-        acc = fmaf(c, c, acc);
-        const bool never = m <= t_never, always = m >= t_always;
-        low = fmaf(never ? v : 0.f, v, low);
-        clipped += __popcll(__ballot(act && always));
-        const bool in_band = act && !never && !always;
-        const unsigned long long mask = __ballot(in_band);
-        if (in_band) list[filled + __popcll(mask & below)] = v;
-        filled += __popcll(mask);
-    };
-#pragma unroll
-    for (int c = 0; c < CB::CNT0; ++c)
-#pragma unroll
-        for (int j = 0; j < CB::HALF; ++j) {
-            visit(act ? k.v[c][j].x : 0.f);
-            visit(act ? k.v[c][j].y : 0.f);
-            // (left alone the scheduler interleaves all 2*CNT0*HALF visits for latency hiding and takes
-            // every register the wave has; the side channel's held samples are then spilled)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    const double a0 = wave_sum((double)acc), l0 = wave_sum((double)low);
-    if (lane == 0) {
-        double* pd = reinterpret_cast<double*>(part + 64 * wave);
-        int* pi = reinterpret_cast<int*>(pd + 4);
-        pd[0] = a0; pd[1] = 0.0; pd[2] = l0; pd[3] = 0.0;
-        pi[0] = clipped; pi[1] = 0; pi[2] = filled; pi[3] = 0;
-    }
-}
-// after a barrier: thread 0 writes the one or two segment records of the pair
-template <int LOG2N>
-__device__ __forceinline__ void conv_round0_publish(long long pair, const Conv2Args& a, const char* part) {
-    using CB = Conv2Block<LOG2N>;
-    using F = Fft2<LOG2N>;
-    constexpr int WAVES = F::T / 64, SPAN = 2 * CB::LOUT, PER_WAVE = SPAN / WAVES;
-    const Round0Plan r0 = *a.r0;
-    const long long o0 = CB::first_output(pair);
-    const long long d0 = o0 / r0.piece, edge = (d0 + 1) * r0.piece;
-    const long long limit = min((long long)r0.divisions * r0.piece, a.n);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const long long d = d0 + h;
-        const long long b = h == 0 ? o0 : edge, e = min(h == 0 ? min(edge, o0 + SPAN) : o0 + SPAN, limit);
-        if (d >= r0.divisions || b >= e) continue;
-        BandSeg* s = r0.segs + (size_t)d * r0.slots + (pair - d * r0.piece / SPAN);
-        double sumsq = 0.0, lowsum = 0.0, clips = 0.0;
-        for (int w = 0; w < WAVES; ++w) {
-            const double* pd = reinterpret_cast<const double*>(part + 64 * w);
-            const int* pi = reinterpret_cast<const int*>(pd + 4);
-            sumsq += pd[h];
-            lowsum += pd[2 + h];
-            clips += (double)pi[h];
-            s->count[w] = pi[2 + h];
-        }
-        s->sumsq = sumsq;
-        s->unclipped_sumsq = lowsum;
-        s->clipped_count = clips;
-        s->begin = b;
-        s->end = e;
-        s->list0 = o0;
-        s->stride = PER_WAVE;
-        s->reversed = h;
-        s->waves = WAVES;
-    }
-}
-
 // One pair of output blocks: mid channel, then side channel + epilogue.
 // (Issuing the NEXT pair's frame loads before the epilogue's stores -- software pipelining -- was
 // built and measured: the 48-96 registers in flight make the 8192-point kernel spill at the 256 a
@@ -334,7 +159,7 @@ __device__ __forceinline__ void conv_round0_publish(long long pair, const Conv2A
 template <int LOG2N, bool MULTI>
 __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2Args& a,
                                            const typename Conv2Block<LOG2N>::Persist& ps, float2* lds,
-                                           const float2* mid_table, char* r0_part) {
+                                           const float2* mid_table) {
     using CB = Conv2Block<LOG2N>;
     const bool edge = !CB::interior(pair, a.n, a.parts);
     typename CB::Kept kept;
@@ -355,11 +180,6 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2A
             tid, a, lds, mid_table, [&]() { CB::phase_pass0_side(tid, held, ps, lds); });
     }
     const float pk = CB::phase_store(tid, pair, edge, a, ps, lds, kept);
-    // The statistics of the mid results come last, although the values have been in registers since the
-    // end of the mid channel: between the channels the side samples wait in 48 registers, and the
-    // compiler answers the statistics' 64 conditional stores there by spilling all of them.
-    __builtin_amdgcn_sched_barrier(0);
-    if (a.r0) conv_round0<LOG2N>(tid, pair, a, kept, r0_part, reinterpret_cast<float*>(lds));
     return pk;
 }
 
@@ -390,7 +210,6 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
     const long long end = min(a.npairs, (xcd + 1) * per);
     const long long first = xcd * per + slot;
     int* next_slot = reinterpret_cast<int*>(scratch + 16);
-    if (a.r0 && blockIdx.x == 0 && tid < 16) a.r0->tail_gains[tid] = ~0ull;              // "not yet": k_correction_tail
     long long pair = first;
     while (pair < end) {
         unsigned ticket = 0;
@@ -400,10 +219,9 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         // not have.  An empty asm makes the values opaque per iteration.
 #pragma unroll
         for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
-        const float pk = conv_pair<LOG2N, MULTI>(tid, pair, a, ps, lds, mid_table, reinterpret_cast<char*>(scratch + 32));
-        const float bp = block_max<F::T>(pk, scratch);     // (its barriers order conv_round0's partials before their reader)
+        const float pk = conv_pair<LOG2N, MULTI>(tid, pair, a, ps, lds, mid_table);
+        const float bp = block_max<F::T>(pk, scratch);
         if (tid == 0) {
-            if (a.r0) conv_round0_publish<LOG2N>(pair, a, reinterpret_cast<char*>(scratch + 32));
             if (a.pair_peak) a.pair_peak[pair] = bp;
             *next_slot = (int)ticket;
         }
@@ -420,16 +238,13 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
 // [2][parts][N] float2.  Workgroup (ch, k) transforms partition k of channel ch.
 template <int LOG2N>
 __global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_prep(const float* taps, const float2* tw, float2* tables,
-                                                              int parts, const double* gain_ptr, double gain,
-                                                              Round0Plan plan, Round0Plan* plan_out) {
+                                                              int parts, const double* gain_ptr, double gain) {
     using CB = Conv2Block<LOG2N>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
     float2* mid_table = lds + F::LDS_ELEMS;
     const int tid = threadIdx.x, ch = blockIdx.x / parts, k = blockIdx.x % parts;
-    // (the convolution reads its round-0 plan from memory; this launch, which precedes it, puts it there)
-    if (plan_out && blockIdx.x == 0 && tid == 0) *plan_out = plan;
     const double g = gain_ptr ? *gain_ptr * gain : gain;      // asked for first: nothing below should wait for it
     typename CB::Persist ps;
     CB::load_persist(tid, tw, mid_table, ps);
@@ -1123,6 +938,24 @@ __global__ __launch_bounds__(1024) void k_correction_step(const double* partial,
 // wave}; later rounds read just that (a few MB instead of 85) unless the gain has left the range,
 // in which case they stream the plane again.  The split is exact: sum min(g^2 m^2, 1) is the same
 // number either way, up to float64 summation order.
+constexpr double BAND_G_LO = 0.7, BAND_G_HI = 1.5;
+constexpr int BAND_SLACK = 2048;             // floats of padding per workgroup in the band buffer
+// float32 thresholds on |m|, each rounded towards the inside of the band: |m| <= never implies
+// |m| <= 1/BAND_G_HI exactly, |m| >= always implies |m| > 1/BAND_G_LO
+__device__ __forceinline__ float band_threshold_never() {
+    const float t = (float)(1.0 / BAND_G_HI);
+    return (double)t <= 1.0 / BAND_G_HI ? t : __uint_as_float(__float_as_uint(t) - 1u);
+}
+__device__ __forceinline__ float band_threshold_always() {
+    const float t = (float)(1.0 / BAND_G_LO);
+    return (double)t > 1.0 / BAND_G_LO ? t : __uint_as_float(__float_as_uint(t) + 1u);
+}
+struct BandInfo {
+    double unclipped_sumsq;                  // A: sum of m^2 over |m| <= 1/BAND_G_HI
+    double clipped_count;                    // C: samples with |m| > 1/BAND_G_LO
+    int count[4];                            // band samples compacted by each of the four waves
+    int pad[2];
+};
 // frames [b, e) of chunk `ch` of piece `d`, and where the four per-wave band lists of that chunk start:
 // a region of (e - b) + BAND_SLACK floats per chunk, a quarter of it (each wave sees a quarter of the
 // chunk's samples, give or take the scalar head and tail) per wave
@@ -1151,10 +984,7 @@ struct RoundArgs {
     const float* final_peaks;   // per-pair peaks of the convolution, or null
     long long npeaks;
     float* band;                // [n + workgroups * BAND_SLACK] compacted band samples
-    BandSeg* segs;              // [divisions][slots] (slots = chunks for k_correction_round)
-    int slots;
-    const float2* y;            // the convolved frames: mid = (L + R) / 2 when no mid plane was written
-    long long pair_span;        // frames per convolution pair when the segments are pair parts, else 0
+    BandInfo* info;             // [workgroups]
     int build_band;             // 1: round 0 (stream + build), 0: later rounds (use the band if g allows)
     int step;                   // index of the (first) round this launch runs
     // the limiter's look-back words, preset to "unpublished" here when a limiter launch follows (saves
@@ -1240,7 +1070,7 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
     }
     // this workgroup's slice of the band buffer, one compacted list per wave
     float* wave_band = bc.lists + wave * bc.wave_cap;
-    BandSeg* info = a.segs + (size_t)d * a.slots + ch;
+    BandInfo* info = a.info + blockIdx.x;
     double acc = 0.0;
     // float64 product then clip: the reference clips the float64 mid (dsp.py:109-110)
     auto add = [&](float v) {
@@ -1312,15 +1142,8 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
             __syncthreads();
             const double hi = block_sum<256>(lane == 0 ? (double)clipped : 0.0, red + 8);
             if (threadIdx.x == 0) {
-                info->sumsq = 0.0;
                 info->unclipped_sumsq = lo;
                 info->clipped_count = hi;
-                info->begin = b;
-                info->end = e;
-                info->list0 = bc.lists - a.band;
-                info->stride = (int)bc.wave_cap;
-                info->reversed = 0;
-                info->waves = 4;
             }
             __syncthreads();
         }
@@ -1361,9 +1184,7 @@ constexpr int TAIL_CACHE_PER_WAVE = 3072;        // floats of band list a wave k
 __host__ __device__ inline size_t correction_tail_lds_bytes(int divisions, int groups) {
     return ((size_t)64 + divisions + (size_t)divisions * groups) * 8 + (size_t)4 * TAIL_CACHE_PER_WAVE * 4 + 16;
 }
-// `from_sums` = the first of the `rounds` is round 0 and its per-segment sums are already in the
-// segment records (the convolution's epilogue put them there): it only has to be decided.
-__global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups, int rounds, int from_sums) {
+__global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups, int rounds) {
     MGX_LDS;
     double* red = reinterpret_cast<double*>(mgx_smem);          // 64 doubles of scratch
     double* sums = red + 64;                                     // [divisions]
@@ -1373,45 +1194,25 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
     __shared__ double gain_now;
     __shared__ float fscratch[4];
     const int d = blockIdx.x / groups, grp = blockIdx.x % groups;
-    // slots of piece d that exist: all of them for chunks; for convolution pairs those from the pair holding
-    // the piece's first frame to the one holding its last
-    int valid = a.slots;
-    if (a.pair_span > 0)
-        valid = (int)((((long long)(d + 1) * a.piece - 1) / a.pair_span) - ((long long)d * a.piece / a.pair_span)) + 1;
-    const int s0 = (int)((long long)grp * valid / groups), s1 = (int)((long long)(grp + 1) * valid / groups);
+    const int ch0 = (int)((long long)grp * a.chunks / groups), ch1 = (int)((long long)(grp + 1) * a.chunks / groups);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, total = a.divisions * groups;
     if (a.lim_published) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.lim_words; i += (long long)gridDim.x * 256)
             a.lim_published[i] = ~0ull;
         if (blockIdx.x == 0 && threadIdx.x == 0) *a.lim_ticket = 0;      // ticket only: a raised error sticks
     }
-    double g = from_sums ? 1.0 : a.cs->gain;                             // stages.py:138-170 starts from gain 1
-    // ---- once: this workgroup's segments (lane c <-> slot s0 + c): closed-form parts, list geometry,
-    //      and the band lists themselves copied into LDS when they fit.  Thread-wave w takes the lists
-    //      of producer waves w, w + 4, ... ----
-    const int nseg = s1 - s0;                                            // <= 64 (host)
-    int cnt[BAND_MAX_WAVES / 4] = {0, 0, 0, 0};
-    int stride = 0, reversed = 0;
-    long long list0 = 0, seg_begin = 0, seg_end = 0;
-    double part_a = 0.0, part_c = 0.0, part_s = 0.0;
-    if (lane < nseg) {
-        const BandSeg* seg = a.segs + (size_t)d * a.slots + s0 + lane;
-        const int waves = seg->waves;
-        if (waves > 0) {
-#pragma unroll
-            for (int q = 0; q < BAND_MAX_WAVES / 4; ++q)
-                if (wave + 4 * q < waves) cnt[q] = seg->count[wave + 4 * q];
-            stride = seg->stride;
-            reversed = seg->reversed;
-            list0 = seg->list0;
-            seg_begin = seg->begin;
-            seg_end = seg->end;
-            if (wave == 0) { part_a = seg->unclipped_sumsq; part_c = seg->clipped_count; part_s = seg->sumsq; }
-        }
+    double g = a.cs->gain;
+    // ---- once: closed-form parts and band lists of this workgroup's chunks (lane c <-> chunk ch0 + c) ----
+    const int nch = ch1 - ch0;                                           // <= 64 (host)
+    int my_count = 0;
+    double part_a = 0.0, part_c = 0.0;
+    if (lane < nch) {
+        const BandInfo* info = a.info + d * a.chunks + ch0 + lane;
+        my_count = info->count[wave];
+        if (wave == 0) { part_a = info->unclipped_sumsq; part_c = info->clipped_count; }
     }
-    const double closed_a = wave_sum(part_a), closed_c = wave_sum(part_c), given_s = wave_sum(part_s);   // wave 0's
-    const int my_count = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-    int before = my_count;                                               // -> exclusive prefix of the counts over the lanes
+    const double closed_a = wave_sum(part_a), closed_c = wave_sum(part_c);   // meaningful on wave 0
+    int before = my_count;                                               // exclusive prefix of the counts over the lanes
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         const int v = __shfl_up(before, o, 64);
@@ -1421,26 +1222,14 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
     before -= my_count;
     const bool cached = wave_total <= TAIL_CACHE_PER_WAVE;               // uniform per wave
     float* mine = cache + wave * TAIL_CACHE_PER_WAVE;
-    // visits every band sample of this thread-wave's lists (from LDS once cached): f(value)
-    auto each_listed = [&](auto f, bool fill_cache) {
-        for (int c = 0; c < nseg; ++c) {
-            const long long l0 = __shfl(list0, c, 64);
-            const int st = __shfl(stride, c, 64), rev = __shfl(reversed, c, 64);
-            int off = __shfl(before, c, 64);
-#pragma unroll
-            for (int q = 0; q < BAND_MAX_WAVES / 4; ++q) {
-                const int n = __shfl(cnt[q], c, 64);
-                const float* list = a.band + l0 + (long long)(wave + 4 * q) * st;
-                for (int k = lane; k < n; k += 64) {
-                    const float v = list[rev ? st - 1 - k : k];
-                    if (fill_cache) mine[off + k] = v;
-                    else f(v);
-                }
-                off += n;
-            }
+    if (cached) {
+        for (int c = 0; c < nch; ++c) {
+            const BandChunk bc = band_chunk(a.band, a.piece, a.chunks, d, ch0 + c);
+            const float* list = bc.lists + wave * bc.wave_cap;
+            const int n = __shfl(my_count, c, 64), off = __shfl(before, c, 64);
+            for (int k = lane; k < n; k += 64) mine[off + k] = list[k];
         }
-    };
-    if (cached) each_listed([](float) {}, true);
+    }
     const float* final_peaks = a.final_peaks;
     for (int r = 0; r < rounds; ++r) {
         double acc = 0.0;
@@ -1448,22 +1237,22 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
             const double c = fmin(fmax((double)v * g, -1.0), 1.0);       // float64 product, then clip (dsp.py:109-110)
             acc = fma(c, c, acc);
         };
-        if (from_sums && r == 0) {
-            if (threadIdx.x == 0) acc = given_s;
-        } else if (g >= BAND_G_LO && g <= BAND_G_HI) {                   // uniform over the grid
+        if (g >= BAND_G_LO && g <= BAND_G_HI) {                          // uniform over the grid
             if (cached) {
                 for (int k = lane; k < wave_total; k += 64) add(mine[k]);
             } else {
-                each_listed(add, false);
+                for (int c = 0; c < nch; ++c) {
+                    const BandChunk bc = band_chunk(a.band, a.piece, a.chunks, d, ch0 + c);
+                    const float* list = bc.lists + wave * bc.wave_cap;
+                    const int n = __shfl(my_count, c, 64);
+                    for (int k = lane; k < n; k += 64) add(list[k]);
+                }
             }
             if (threadIdx.x == 0) acc += g * g * closed_a + closed_c;
         } else {
-            for (int c = 0; c < nseg; ++c) {
-                const long long b = __shfl(seg_begin, c, 64), e = __shfl(seg_end, c, 64);
-                for (long long i = b + threadIdx.x; i < e; i += 256) {
-                    if (a.mid) add(a.mid[i]);
-                    else { const float2 f = a.y[i]; add((f.x + f.y) * 0.5f); }      // dsp.py:59-60 on the stored frames
-                }
+            for (int c = 0; c < nch; ++c) {
+                const BandChunk bc = band_chunk(a.band, a.piece, a.chunks, d, ch0 + c);
+                for (long long i = bc.b + threadIdx.x; i < bc.e; i += 256) add(a.mid[i]);
             }
         }
         const double s = block_sum<256>(acc, red);
