@@ -646,6 +646,33 @@ struct LimiterBlock {
             }
         }
     }
+
+    // The same for a chunk inside the track, in two halves: the reload is issued while the release
+    // look-back is in flight (the kernel has nothing else to do there), the rest follows the gains.
+    struct Reload { float4 q[E / 2]; };
+    static MGX_HD void phase_reload(int tid, long long chunk, const LimiterArgs& a, Reload& r) {
+        // (every frame of the region exists; the halos' share is loaded too rather than branched around)
+        const float2* y = a.y + region_start(chunk, a) + 2 * tid;
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) r.q[j] = *reinterpret_cast<const float4*>(y + 2 * T * j);
+    }
+    static MGX_HD void phase_store_reloaded(int tid, long long chunk, const LimiterArgs& a, const Reload& r, const float* lds) {
+        const long long r0 = region_start(chunk, a);
+        const long long c0 = r0 + (long long)a.gl * E, c1 = r0 + (long long)(T - a.gr) * E;
+        const float g = (float)*a.gain, post = (float)*a.post_gain;
+        const float* gn = plane(const_cast<float*>(lds));
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) {
+            const int i = 2 * tid + 2 * T * j;
+            const long long f = r0 + i;
+            if (f < c0 || f >= c1) continue;
+            const float4 q = r.q[j];
+            const float2 v0 = scaled(make_float2(q.x, q.y), g), v1 = scaled(make_float2(q.z, q.w), g);
+            const float s0 = own_gain(v0, gn[gidx(i)], true, a.threshold) * post;
+            const float s1 = own_gain(v1, gn[gidx(i + 1)], true, a.threshold) * post;
+            st_stream(reinterpret_cast<float4*>(a.out + f), make_float4(v0.x * s0, v0.y * s0, v1.x * s1, v1.y * s1));
+        }
+    }
 };
 
 }  // namespace mgx

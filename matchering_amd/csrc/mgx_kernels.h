@@ -1547,6 +1547,8 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     const Affine pr = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 3), er, &whole);
     if (tid == 0) LB::lookback_publish(chunk, 1, a, whole.b);
     if (wave == 0) LB::lookback_ask(lane, chunk, 1, a, polls);
+    typename LB::Reload again;
+    if (FULL) LB::phase_reload(opaque(tid), chunk, a, again);
     if (wave == 0) {
         const double s = wave_sum(LB::lookback_take(lane, chunk, 1, a, polls));
         if (lane == 0) LB::scalars(lds)[1] = s;
@@ -1554,7 +1556,8 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     __syncthreads();
     LB::template phase_gain<FULL>(opaque(tid), a, th, pr, LB::scalars(lds)[1], lds);
     __syncthreads();
-    LB::template phase_store<FULL>(opaque(tid), chunk, a, true, lds);
+    if (FULL) LB::phase_store_reloaded(opaque(tid), chunk, a, again, lds);
+    else LB::template phase_store<FULL>(opaque(tid), chunk, a, true, lds);
 }
 
 // T = threads = 16-frame blocks per chunk (256, or 1024 for long attack / hold times); WGS = workgroups

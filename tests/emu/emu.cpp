@@ -314,7 +314,13 @@ static int limit_impl(const LimiterParams& lp, const float* x, long long n, cons
         LB::lookback_publish(chunk, 1, a, whole_rel.b);
         const double rel_carry = carry(chunk, 1);
         FOR_THREADS(LB::T) LB::phase_gain(tid, a, th[tid], pre1[tid], rel_carry, lds.data());
-        FOR_THREADS(LB::T) LB::phase_store(tid, chunk, a, true, lds.data());
+        if (LB::full_chunk(chunk, a)) {       // as limit_chunk<T, true>: the frames are reloaded ahead of the gains
+            std::vector<typename LB::Reload> again(LB::T);
+            FOR_THREADS(LB::T) LB::phase_reload(tid, chunk, a, again[tid]);
+            FOR_THREADS(LB::T) LB::phase_store_reloaded(tid, chunk, a, again[tid], lds.data());
+        } else {
+            FOR_THREADS(LB::T) LB::phase_store(tid, chunk, a, true, lds.data());
+        }
     }
     return ctrl[1] ? -2 : 0;
 }
