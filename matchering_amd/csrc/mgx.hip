@@ -1119,6 +1119,11 @@ int mgx_stage_timing(mgx_handle* h, int32_t enable) {
     for (bool& u : h->stage_used) u = false;
     return 0;
 }
+#ifdef MGX_DEV_LIMITER_PHASES        // development builds only (tools/limiter_phases.py)
+int mgx_dev_phase_ticks_read(unsigned* out, int chunks) {       // out: [chunks][16]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx::mgx_dev_phase_ticks), (size_t)chunks * 16 * sizeof(unsigned)) != hipSuccess;
+}
+#endif
 int mgx_stage_times(mgx_handle* h, float* ms) {
     if (!h || !ms) return fail(MGX_ERR_ARGUMENT, "null argument");
     HIP_TRY(hipStreamSynchronize(h->stream));

@@ -1464,6 +1464,20 @@ __device__ __forceinline__ float dpp_max8(float v) {
     return __int_as_float(x);
 }
 
+#ifdef MGX_DEV_LIMITER_PHASES      // development builds only: where a chunk's time goes (tools/limiter_phases.py)
+constexpr int DEV_PHASE_CHUNKS = 16384;
+__device__ unsigned mgx_dev_phase_ticks[DEV_PHASE_CHUNKS][16];       // [chunk][mark]: ticks since the previous mark; [15] = start time
+#define DEV_MARK(k)                                                                                  \
+    do {                                                                                             \
+        if (threadIdx.x == 0 && chunk < DEV_PHASE_CHUNKS) {                                          \
+            const long long now = wall_clock64();                                                    \
+            mgx_dev_phase_ticks[chunk][k] = (unsigned)(now - dev_last);                              \
+            dev_last = now;                                                                          \
+        }                                                                                            \
+    } while (0)
+#else
+#define DEV_MARK(k)
+#endif
 // one chunk, from the load phase to the store; FULL = the chunk lies strictly inside the track
 // one chunk, from the load phase to the store; FULL = the chunk lies strictly inside the track
 template <int T, bool FULL>
@@ -1471,6 +1485,10 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     using LB = LimiterBlock<T>;
     // (opaque: nothing derived from the thread id may be hoisted out of a persistent caller's loop)
     const int tid = opaque((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
+#ifdef MGX_DEV_LIMITER_PHASES
+    long long dev_last = wall_clock64();
+    if (threadIdx.x == 0 && chunk < DEV_PHASE_CHUNKS) mgx_dev_phase_ticks[chunk][15] = (unsigned)dev_last;
+#endif
     {
         float pm[LB::E / 2];
         LB::template phase_load<FULL>(opaque(tid), chunk, a, lds, pm);
@@ -1481,6 +1499,7 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
         }
     }
     __syncthreads();
+    DEV_MARK(0);      // load
 
     // hold filter first (scan 1): its aggregate is published as early as possible
     typename LB::Thread th;
@@ -1493,6 +1512,7 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
         __syncthreads();
         th.hold_pre = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 1), e1, &whole);
     }
+    DEV_MARK(1);      // hold window + scan
     if (tid == 0) LB::lookback_publish(chunk, 0, a, whole.b);
     // ask for the predecessors' words now, take them after the attack path (wave 0: hold, wave 1: attack)
     typename LB::Polls polls;
@@ -1507,6 +1527,7 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
         __syncthreads();
         p0 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 0), e0, nullptr);
     }
+    DEV_MARK(2);      // attack window + scan
     if (tid == LB::T - a.gr) LB::lookback_publish(chunk, 2, a, p0.b);          // attack state at the end of the core
     if (wave == 1) LB::lookback_ask(lane, chunk, 2, a, polls);
     const bool tail = !FULL && LB::tail_chunk(chunk, a);                        // uniform
@@ -1528,6 +1549,7 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     __syncthreads();
     const Affine pb = compose_waves<true, LB::WAVES>(LB::wave_totals(lds, 2), eb, nullptr);
     LB::template phase_attack_backward<FULL>(opaque(tid), a, th, pb);
+    DEV_MARK(3);      // attack forward, scan, backward
     if (wave == 0) {
         const double s = wave_sum(LB::lookback_take(lane, chunk, 0, a, polls));
         if (lane == 0) LB::scalars(lds)[0] = s;
@@ -1536,7 +1558,9 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
         const double s = wave_sum(LB::lookback_take(lane, chunk, 2, a, polls));
         if (lane == 0) LB::scalars(lds)[2] = s;
     }
+    DEV_MARK(4);      // take hold (wave 0)
     __syncthreads();
+    DEV_MARK(5);      // barrier after the takes (waits for wave 1's attack take)
 
     // hold output, release filter (scan 3)
     const Affine mr = LB::template phase_hold<FULL>(opaque(tid), a, th, LB::scalars(lds)[0], tail ? 0.0 : LB::scalars(lds)[2]);
@@ -1545,19 +1569,24 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     const Affine er = wave_exclusive<false>(ir);
     __syncthreads();
     const Affine pr = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 3), er, &whole);
+    DEV_MARK(6);      // hold output + release scan
     if (tid == 0) LB::lookback_publish(chunk, 1, a, whole.b);
     if (wave == 0) LB::lookback_ask(lane, chunk, 1, a, polls);
     typename LB::Reload again;
     if (FULL) LB::phase_reload(opaque(tid), chunk, a, again);
+    DEV_MARK(7);      // publish, ask, reload issue
     if (wave == 0) {
         const double s = wave_sum(LB::lookback_take(lane, chunk, 1, a, polls));
         if (lane == 0) LB::scalars(lds)[1] = s;
     }
+    DEV_MARK(8);      // take release
     __syncthreads();
     LB::template phase_gain<FULL>(opaque(tid), a, th, pr, LB::scalars(lds)[1], lds);
     __syncthreads();
+    DEV_MARK(9);      // gain
     if (FULL) LB::phase_store_reloaded(opaque(tid), chunk, a, again, lds);
     else LB::template phase_store<FULL>(opaque(tid), chunk, a, true, lds);
+    DEV_MARK(10);     // store
 }
 
 // T = threads = 16-frame blocks per chunk (256, or 1024 for long attack / hold times); WGS = workgroups
