@@ -29,6 +29,17 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// inclusive prefix sum over the 64 lanes: four steps inside each row of 16 (row_shr 1, 2, 4, 8; lanes
+// without a source add 0), then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into rows 2 and 3
+__device__ __forceinline__ int wave_inclusive_sum(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);    // row_bcast:15
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);    // row_bcast:31
+    return x;
+}
 __device__ __forceinline__ double wave_max_f64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -1115,6 +1126,51 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
             visit(ok ? a.mid[b + threadIdx.x] : 0.f, ok);
         }
         const long long body_end = head + ((e - head) & ~3ll);
+        int clipped_mine = 0;                  // per thread (the fast path below)
+        if (build && g == 1.0) {
+            // Round 0 of mgx_master (the level gain of stages.py:80-88 is in the filter, so g is exactly 1):
+            // float32 arithmetic -- clip(v) is exact, the squares are summed 16 at a time before they join
+            // the float64 sums -- and the band samples are compacted per THREAD: each thread counts its
+            // own, one prefix sum over the wave places them, no ballot and no scalar chain per sample.
+            // (A frame past the end loads as 0: clips to 0, counts as never clipped, adds nothing.)
+            for (long long s0 = head; s0 < body_end; s0 += 4 * 1024) {
+                float x[16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long i = s0 + u * 1024 + 4ll * threadIdx.x;
+                    const float4 q = i < body_end ? *reinterpret_cast<const float4*>(a.mid + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    x[4 * u] = q.x; x[4 * u + 1] = q.y; x[4 * u + 2] = q.z; x[4 * u + 3] = q.w;
+                }
+                float sq = 0.f, lo = 0.f;
+                int mine = 0;
+                unsigned bits = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float c = __builtin_amdgcn_fmed3f(x[i], -1.0f, 1.0f);
+                    sq = fmaf(c, c, sq);
+                    const float m = fabsf(x[i]);
+                    const bool never = m <= t_never, always = m >= t_always;
+                    lo = fmaf(never ? x[i] : 0.f, x[i], lo);
+                    clipped_mine += always ? 1 : 0;
+                    const bool in_band = !never && !always;
+                    mine += in_band ? 1 : 0;
+                    bits |= (in_band ? 1u : 0u) << i;
+                }
+                acc += (double)sq;
+                low += (double)lo;
+                const int through = wave_inclusive_sum(mine);
+                int slot = filled + through - mine;
+                if (bits) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (bits & (1u << i)) {
+                            if (slot < bc.wave_cap) wave_band[slot] = x[i];
+                            ++slot;
+                        }
+                }
+                filled += __builtin_amdgcn_readlane(through, 63);
+            }
+        } else
         for (long long s0 = head; s0 < body_end; s0 += 4 * 1024) {
             float4 v[4];
             bool ok[4];
@@ -1140,7 +1196,7 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
             if (lane == 0) info->count[wave] = filled;
             const double lo = block_sum<256>(low, red);
             __syncthreads();
-            const double hi = block_sum<256>(lane == 0 ? (double)clipped : 0.0, red + 8);
+            const double hi = block_sum<256>((lane == 0 ? (double)clipped : 0.0) + (double)clipped_mine, red + 8);
             if (threadIdx.x == 0) {
                 info->unclipped_sumsq = lo;
                 info->clipped_count = hi;
