@@ -448,3 +448,39 @@ def test_pinned_and_pageable_transfers_agree():
             a.release()
             b.release()
         assert pinned.holds(ya) and np.array_equal(ya, x) and np.array_equal(yb, x)
+
+
+def test_threads_sharing_the_default_device_do_not_interleave():
+    """include/mgx.h: calls on one handle are serialised by the caller.  The process-wide default Device is
+    what every stages.main call without an explicit device uses, so two threads of an application share
+    it: Device.lock has to keep their upload -> kernels -> download sequences apart (ctypes drops the GIL
+    while a call blocks).  Four threads, different pairs and shapes, many rounds; every result must be
+    bit-identical to the one computed alone."""
+    import threading
+
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd.synth import make_pair
+
+    cfg = mg.Config(max_piece_size=2.0)
+    pairs = [make_pair(3.0 + 0.7 * i, 44100, pair=i, reference_seconds=2.5 + 0.4 * i) for i in range(4)]
+    alone = [stages.main(t, r, cfg, need_default=True, need_no_limiter=True) for t, r in pairs]
+    failures = []
+
+    def worker(i):
+        try:
+            for _ in range(6):
+                got = stages.main(*pairs[i], cfg, need_default=True, need_no_limiter=True)
+                for a, b in zip(got[:2], alone[i][:2]):
+                    if not np.array_equal(a, b):
+                        failures.append((i, float(np.abs(a - b).max())))
+                        return
+        except Exception as exc:        # noqa: BLE001 -- reported below
+            failures.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not failures, failures
