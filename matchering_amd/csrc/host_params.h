@@ -3,12 +3,13 @@
 #pragma once
 
 #include <cmath>
+#include <complex>
 #include <string>
 
 #include "../../include/mgx.h"
 #include <vector>
 
-#include "limiter_kernel.h"
+#include "limiter_general.h"
 
 namespace mgx {
 
@@ -26,8 +27,115 @@ inline Iir1 butter1(double fc, double fs) {
     return Iir1{b, -a1, b - a1 * b};
 }
 
+// scipy.signal.butter(order, fc, fs=fs) (low-pass, transfer-function form): analogue prototype poles
+// on the unit circle, scaled to the pre-warped cut-off, bilinear transform with fs = 2, numerator
+// k (z + 1)^order.  b, a: order + 1 coefficients each.
+inline void butter_tf(int order, double fc, double fs, double* b, double* a) {
+    using cd = std::complex<double>;
+    const double pi = 3.14159265358979323846;
+    const double wn = 2.0 * fc / fs;
+    const double warped = 4.0 * std::tan(pi * wn / 2.0);
+    cd den = 1.0;
+    std::vector<cd> poly(order + 1, cd(0.0));
+    poly[0] = 1.0;
+    for (int k = 0; k < order; ++k) {
+        const int m = -order + 1 + 2 * k;
+        const cd pa = -std::exp(cd(0.0, pi * m / (2.0 * order))) * warped;
+        const cd pd = (4.0 + pa) / (4.0 - pa);
+        den *= (4.0 - pa);
+        for (int i = k + 1; i >= 1; --i) poly[i] -= pd * poly[i - 1];
+    }
+    const double kd = std::pow(warped, order) * std::real(1.0 / den);
+    double binom = 1.0;
+    for (int i = 0; i <= order; ++i) {
+        a[i] = std::real(poly[i]);
+        b[i] = kd * binom;
+        binom = binom * (order - i) / (i + 1);
+    }
+}
+
+// an order-K section (limiter_general.h) from a filter of order <= K, and the powers of its state matrix
+template <int K>
+inline IirK<K> section_of(int order, const double* b, const double* a) {
+    IirK<K> f;
+    for (int i = 0; i <= K; ++i) {
+        f.b[i] = i <= order ? b[i] : 0.0;
+        f.a[i] = i <= order ? a[i] : 0.0;
+    }
+    return f;
+}
+// k x k matrices in extended precision (x87 long double on the host: 64-bit significands; the powers of
+// a state matrix whose eigenvalues sit 1e-5 from 1 lose ~1e4 in conditioning)
+using Wide = long double;
+inline void mat_mul(int k, const std::vector<Wide>& x, const std::vector<Wide>& y, std::vector<Wide>& out) {
+    std::vector<Wide> r((size_t)k * k, 0.0L);
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) {
+            Wide s = 0.0L;
+            for (int l = 0; l < k; ++l) s += x[(size_t)i * k + l] * y[(size_t)l * k + j];
+            r[(size_t)i * k + j] = s;
+        }
+    out = r;
+}
+// state matrix of the transposed direct form II section: z' = A z + B x, A[i][0] = -a[i+1], A[i][i+1] = 1
+inline std::vector<Wide> state_matrix(int k, const double* a) {
+    std::vector<Wide> m((size_t)k * k, 0.0L);
+    for (int i = 0; i < k; ++i) {
+        m[(size_t)i * k] = -(Wide)a[i + 1];
+        if (i + 1 < k) m[(size_t)i * k + i + 1] = 1.0L;
+    }
+    return m;
+}
+inline std::vector<Wide> mat_identity(int k) {
+    std::vector<Wide> r((size_t)k * k, 0.0L);
+    for (int i = 0; i < k; ++i) r[(size_t)i * k + i] = 1.0L;
+    return r;
+}
+inline std::vector<Wide> mat_power(int k, const std::vector<Wide>& m, long long e) {
+    std::vector<Wide> r = mat_identity(k), base(m);
+    while (e > 0) {
+        if (e & 1) mat_mul(k, base, r, r);
+        mat_mul(k, base, base, base);
+        e >>= 1;
+    }
+    return r;
+}
+inline void append_rounded(std::vector<double>& out, const std::vector<Wide>& m) {
+    for (Wide v : m) out.push_back((double)v);
+}
+// A^j for j = 0..16, [17][k][k]
+inline std::vector<double> block_powers(int k, const std::vector<Wide>& m) {
+    std::vector<double> out;
+    std::vector<Wide> cur = mat_identity(k);
+    for (int j = 0; j <= 16; ++j) {
+        append_rounded(out, cur);
+        mat_mul(k, m, cur, cur);
+    }
+    return out;
+}
+// (A^chunk)^m until its largest entry drops below 1e-10 (at least one, at most `cap`: empty = did not decay)
+inline std::vector<double> lookback_matrices(int k, const std::vector<Wide>& m, int chunk, int cap) {
+    const std::vector<Wide> step = mat_power(k, m, chunk);
+    std::vector<double> out;
+    std::vector<Wide> cur = mat_identity(k);
+    for (int n = 0; n < cap; ++n) {
+        Wide big = 0.0L;
+        for (Wide v : cur) big = std::fmax(big, std::fabs(v));
+        if (n > 0 && big <= 1e-10L) return out;
+        append_rounded(out, cur);
+        mat_mul(k, step, cur, cur);
+    }
+    return std::vector<double>();
+}
+
 struct LimiterParams {
     int attack, hold, hw, hb, ha;
+    // hold / release filters of order > 1 (limiter_general.h): general = max order, 0 when both are first order
+    int general = 0;
+    double hold_b[LIMITER_MAX_ORDER + 1], hold_a[LIMITER_MAX_ORDER + 1];
+    double rel_b[LIMITER_MAX_ORDER + 1], rel_a[LIMITER_MAX_ORDER + 1];
+    int hold_order = 1, rel_order = 1;
+    std::vector<double> pow_hold, pow_rel, wk_hold, wk_rel;    // [17][K][K], [17][K][K], [n][K][K], [n][K][K]
     Iir1 att, hold_f, rel_f;
     int threads;                                   // blocks per chunk the limiter kernel runs with: 256 or 1024
     LimiterBlock<256>::Geometry geo;               // (the same struct for every T)
@@ -62,14 +170,20 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
     p.hold = (int)(sr * c.hold_ms * 1e-3);
     if (p.attack < 1) return "limiter attack shorter than one sample";
     if (p.hold < 3) return "limiter hold shorter than three samples (the reference's sliding window is empty there)";
-    if (c.hold_filter_order != 1 || c.release_filter_order != 1)
-        return "hold/release filter orders other than 1 are not implemented";
+    if (c.hold_filter_order < 1 || c.release_filter_order < 1) return "hold/release filter orders must be positive";
+    if (c.hold_filter_order > LIMITER_MAX_ORDER || c.release_filter_order > LIMITER_MAX_ORDER)
+        return "hold/release filter orders above 2 are not implemented (ill-conditioned in the reference's transfer-function form: limiter_general.h)";
+    p.hold_order = c.hold_filter_order;
+    p.rel_order = c.release_filter_order;
+    p.general = (p.hold_order > 1 || p.rel_order > 1) ? (p.hold_order > p.rel_order ? p.hold_order : p.rel_order) : 0;
     const int w = (p.attack & 1) ? p.attack : p.attack + 1;
     p.hw = w - 1;
     p.hb = p.hold - 1;
     const double rho = std::exp(c.attack_filter_coefficient / p.attack);
     if (!(rho > 0.0 && rho < 1.0)) return "attack_filter_coefficient must be negative";
     p.att = Iir1{1.0 - rho, rho, rho * (1.0 - rho)};
+    // (the first-order sections also serve the general path: its attack phases read p.att only, and the
+    // geometry does not depend on them)
     p.hold_f = butter1(c.hold_filter_coefficient, sr);
     p.rel_f = butter1(c.release_filter_coefficient / c.release_ms, sr);
     // frames after which the attack smoother has forgotten its state (rho^ha <= 1e-8)
@@ -89,6 +203,21 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
     p.w_hold = lookback_weights(p.hold_f.alpha, p.geo.chunk, 1 << 16);
     p.w_rel = lookback_weights(p.rel_f.alpha, p.geo.chunk, 1 << 16);
     p.w_att = lookback_weights(p.att.alpha, p.geo.chunk, 1 << 16);
+    if (p.general) {
+        if (p.threads != 256)
+            return "hold/release filter orders above 1 together with attack/hold times that need 1024-block chunks are not implemented";
+        const int k = p.general;
+        butter_tf(p.hold_order, c.hold_filter_coefficient, sr, p.hold_b, p.hold_a);
+        butter_tf(p.rel_order, c.release_filter_coefficient / c.release_ms, sr, p.rel_b, p.rel_a);
+        for (int i = p.hold_order + 1; i <= LIMITER_MAX_ORDER; ++i) p.hold_b[i] = p.hold_a[i] = 0.0;
+        for (int i = p.rel_order + 1; i <= LIMITER_MAX_ORDER; ++i) p.rel_b[i] = p.rel_a[i] = 0.0;
+        const std::vector<Wide> mh = state_matrix(k, p.hold_a), mr = state_matrix(k, p.rel_a);
+        p.pow_hold = block_powers(k, mh);
+        p.pow_rel = block_powers(k, mr);
+        p.wk_hold = lookback_matrices(k, mh, p.geo.chunk, 1 << 14);
+        p.wk_rel = lookback_matrices(k, mr, p.geo.chunk, 1 << 14);
+        if (p.wk_hold.empty() || p.wk_rel.empty()) return "hold/release filter does not decay (unstable at this order and cut-off)";
+    }
     return "";
 }
 
@@ -112,6 +241,33 @@ inline void limiter_fill(const LimiterParams& p, float threshold, LimiterArgs& a
     a.n_hold = (int)p.w_hold.size();
     a.n_rel = (int)p.w_rel.size();
     a.n_att = (int)p.w_att.size();
+}
+
+// look-back words of a launch: [3][nchunks] of the first-order kernel (the general one uses the attack
+// row only) followed by [2][K][nchunks] state words of the general kernel
+inline long long limiter_words(const LimiterParams& p, long long nchunks) { return (3 + 2 * (long long)p.general) * nchunks; }
+
+// the general kernel's argument block; tables = device (or emulation) copies of pow_hold | pow_rel | wk_hold | wk_rel
+template <int K>
+inline GeneralArgs<K> general_fill(const LimiterParams& p, const double* tables, unsigned long long* published, long long nchunks) {
+    GeneralArgs<K> g;
+    g.hold = section_of<K>(p.hold_order, p.hold_b, p.hold_a);
+    g.rel = section_of<K>(p.rel_order, p.rel_b, p.rel_a);
+    g.pow_hold = tables;
+    g.pow_rel = g.pow_hold + p.pow_hold.size();
+    g.w_hold = g.pow_rel + p.pow_rel.size();
+    g.w_rel = g.w_hold + p.wk_hold.size();
+    g.n_hold = (int)(p.wk_hold.size() / (K * K));
+    g.n_rel = (int)(p.wk_rel.size() / (K * K));
+    g.words = published + 3 * nchunks;
+    return g;
+}
+inline std::vector<double> general_tables(const LimiterParams& p) {
+    std::vector<double> t(p.pow_hold);
+    t.insert(t.end(), p.pow_rel.begin(), p.pow_rel.end());
+    t.insert(t.end(), p.wk_hold.begin(), p.wk_hold.end());
+    t.insert(t.end(), p.wk_rel.begin(), p.wk_rel.end());
+    return t;
 }
 
 inline int ilog2_exact(int v) {

@@ -81,6 +81,8 @@ struct mgx_handle {
     DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars, conv_queue;
     DevBuf lim_published, lim_ctrl, lim_weights, round_ctr, tail_gains, band, band_info;
     std::vector<double> lim_weights_host;
+    DevBuf lim_tables;                      // general filter orders: matrix powers and look-back matrices
+    std::vector<double> lim_tables_host;
     DevBuf fir_scratch;
     std::map<const FirPlanHost*, PlanDev> plan_dev;               // uploaded plan blobs + dense operators
     std::vector<std::shared_ptr<FirPlanHost>> plans;              // keeps the host plans alive
@@ -556,11 +558,29 @@ static int limiter_state(mgx_handle* h, long long n, const mgx_config* cfg, unsi
     const std::string err = limiter_params(*cfg, lp);
     if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
     const long long nchunks = (n + lp.geo.chunk - 1) / lp.geo.chunk;
-    MGX_TRY(ensure(h, h->lim_published, (size_t)3 * nchunks * sizeof(unsigned long long)));
+    MGX_TRY(ensure(h, h->lim_published, (size_t)limiter_words(lp, nchunks) * sizeof(unsigned long long)));
     MGX_TRY(ensure_ctrl(h));
     *published = (unsigned long long*)h->lim_published.p;
-    *words = 3 * nchunks;
+    *words = limiter_words(lp, nchunks);
     *ticket = (int*)h->lim_ctrl.p;
+    return 0;
+}
+
+// hold / release filters of order 2: k_limit_general<K>, its tables uploaded when the parameters change
+template <int K>
+static int launch_limiter_general(mgx_handle* h, const LimiterArgs& a, const LimiterParams& lp) {
+    const std::vector<double> t = general_tables(lp);
+    if (h->lim_tables_host != t) {
+        MGX_TRY(ensure(h, h->lim_tables, t.size() * sizeof(double)));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipMemcpy(h->lim_tables.p, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+        h->lim_tables_host = t;
+    }
+    const GeneralArgs<K> g = general_fill<K>(lp, (const double*)h->lim_tables.p, a.published, a.nchunks);
+    const size_t lds = LimiterGeneral<K>::LDS_BYTES;
+    MGX_TRY((allow_lds(k_limit_general<K>, lds)));
+    hipLaunchKernelGGL((k_limit_general<K>), dim3((unsigned)a.nchunks), dim3(256), lds, h->stream, a, g);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -580,8 +600,8 @@ static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
 
 // everything of a limiter launch but the look-back words, ticket and error flag
 static int limiter_args(mgx_handle* h, const float* y, long long n, const mgx_config* cfg, const double* gain_dev,
-                        const double* post_dev, const int* active_dev, float* out, LimiterArgs& a, int* threads) {
-    LimiterParams lp;
+                        const double* post_dev, const int* active_dev, float* out, LimiterArgs& a, int* threads,
+                        LimiterParams& lp) {
     const std::string err = limiter_params(*cfg, lp);
     if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
     if (n < 8) return fail(MGX_ERR_ARGUMENT, "limiter input too short");
@@ -615,10 +635,11 @@ static int limiter_args(mgx_handle* h, const float* y, long long n, const mgx_co
 static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_config* cfg, const double* gain_dev,
                        const double* post_dev, const int* active_dev, float* out, bool preset_done = false) {
     LimiterArgs a;
+    LimiterParams lp;
     int threads = 256;
-    MGX_TRY(limiter_args(h, y, n, cfg, gain_dev, post_dev, active_dev, out, a, &threads));
+    MGX_TRY(limiter_args(h, y, n, cfg, gain_dev, post_dev, active_dev, out, a, &threads, lp));
     // published words preset to "unpublished", ticket and error zeroed, every launch
-    const size_t pub_bytes = (size_t)3 * a.nchunks * sizeof(unsigned long long);
+    const size_t pub_bytes = (size_t)limiter_words(lp, a.nchunks) * sizeof(unsigned long long);
     MGX_TRY(ensure(h, h->lim_published, pub_bytes));
     MGX_TRY(ensure_ctrl(h));
     a.published = (unsigned long long*)h->lim_published.p;
@@ -628,7 +649,10 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
         HIP_TRY(hipMemsetAsync(h->lim_published.p, 0xff, pub_bytes, h->stream));
         HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 4, h->stream));   // ticket only: a raised error sticks
     }
-    return launch_limiter(h, a, threads);
+    switch (lp.general) {
+        case 0: return launch_limiter(h, a, threads);
+        default: return launch_limiter_general<2>(h, a, lp);
+    }
 }
 
 // a look-back wait expired (never seen; the spin is bounded so that a lost chunk cannot hang the GPU)
@@ -709,7 +733,7 @@ int mgx_destroy(mgx_handle* h) {
     hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
-                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info,
+                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->lim_tables, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info,
                       &h->conv_queue};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);

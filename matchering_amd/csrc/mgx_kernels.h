@@ -9,7 +9,7 @@
 #include "analysis2_kernel.h"
 #include "conv2_kernel.h"
 #include "fir_plan.h"
-#include "limiter_kernel.h"
+#include "limiter_general.h"
 
 namespace mgx {
 
@@ -1643,6 +1643,128 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     if (FULL) LB::phase_store_reloaded(opaque(tid), chunk, a, again, lds);
     else LB::template phase_store<FULL>(opaque(tid), chunk, a, true, lds);
     DEV_MARK(10);     // store
+}
+
+// One chunk with hold / release filters of order up to K (limiter_general.h): the load, window, attack and
+// store phases of the first-order kernel; the two low-passes as K-state maps scanned through LDS.
+template <int K>
+__device__ __forceinline__ void limit_chunk_general(const LimiterArgs& a, const GeneralArgs<K>& g, long long chunk, float* lds) {
+    using LB = LimiterBlock<256>;
+    using LG = LimiterGeneral<K>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {
+        float pm[LB::E / 2];
+        LB::template phase_load<false>(tid, chunk, a, lds, pm);
+#pragma unroll
+        for (int j = 0; j < LB::E / 2; ++j) {
+            const float m = dpp_max8(pm[j]);
+            if ((tid & 7) == 0) LB::block_max(lds)[LB::block_of(tid, j)] = m;
+        }
+    }
+    __syncthreads();
+    typename LB::Thread th;
+    LB::template phase_hold_window<false>(tid, chunk, a, th, lds);          // (its first-order map is not used)
+    LG::scan_put(lds, tid, th.core && th.valid > 0 ? LG::block_map(g.hold, th.sh, th.valid, g.pow_hold) : LG::identity());
+    __syncthreads();
+    LG::scan_groups(lds, tid);
+    __syncthreads();
+    LG::scan_top(lds, tid);
+    __syncthreads();
+    const StateMap<K> hold_pre = LG::scan_prefix(lds, tid);
+    if (tid == 0) LG::publish(g, a.nchunks, 0, chunk, LG::scan_whole(lds).v);
+
+    // the attack path, as in limit_chunk
+    typename LB::Polls polls;
+    Affine p0;
+    {
+        const Affine m0 = LB::template phase_attack_window<false>(tid, a, th, lds);
+        const Affine i0 = wave_inclusive<false>(m0);
+        if (lane == 63) LB::wave_totals(lds, 0)[wave] = i0;
+        const Affine e0 = wave_exclusive<false>(i0);
+        __syncthreads();
+        p0 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 0), e0, nullptr);
+    }
+    if (tid == LB::T - a.gr) LB::lookback_publish(chunk, 2, a, p0.b);
+    if (wave == 1) LB::lookback_ask(lane, chunk, 2, a, polls);
+    const bool tail = LB::tail_chunk(chunk, a);
+    double att_now = 0.0;
+    if (tail) {
+        if (wave == 1) {
+            const double s = wave_sum(LB::lookback_take(lane, chunk, 2, a, polls));
+            if (lane == 0) LB::scalars(lds)[2] = s;
+        }
+        __syncthreads();
+        att_now = LB::scalars(lds)[2];
+    }
+    const Affine mb = LB::template phase_attack_forward<false>(tid, a, th, p0, att_now, lds);
+    const Affine ib = wave_inclusive<true>(mb);
+    if (lane == 0) LB::wave_totals(lds, 2)[wave] = ib;
+    const Affine eb = wave_exclusive<true>(ib);
+    __syncthreads();
+    const Affine pb = compose_waves<true, LB::WAVES>(LB::wave_totals(lds, 2), eb, nullptr);
+    LB::template phase_attack_backward<false>(tid, a, th, pb);
+
+    // carries of the hold filter (wave 0) and of the attack smoother (wave 1)
+    double* carries = LG::carries(lds);
+    if (wave == 0) {
+        double acc[K];
+        LG::take(lane, chunk, 0, g, a, acc);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double s = wave_sum(acc[k]);
+            if (lane == 0) carries[k] = s;
+        }
+    }
+    if (wave == 1 && !tail) {
+        const double s = wave_sum(LB::lookback_take(lane, chunk, 2, a, polls));
+        if (lane == 0) LB::scalars(lds)[2] = s;
+    }
+    __syncthreads();
+    double hold_carry[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) hold_carry[k] = carries[k];
+    const StateMap<K> mr = LG::phase_hold(tid, a, g, th, hold_pre, hold_carry, tail ? 0.0 : LB::scalars(lds)[2]);
+    __syncthreads();                                                          // every prefix of the hold scan has been read
+    LG::scan_put(lds, tid, mr);
+    __syncthreads();
+    LG::scan_groups(lds, tid);
+    __syncthreads();
+    LG::scan_top(lds, tid);
+    __syncthreads();
+    const StateMap<K> rel_pre = LG::scan_prefix(lds, tid);
+    if (tid == 0) LG::publish(g, a.nchunks, 1, chunk, LG::scan_whole(lds).v);
+    if (wave == 0) {
+        double acc[K];
+        LG::take(lane, chunk, 1, g, a, acc);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double s = wave_sum(acc[k]);
+            if (lane == 0) carries[K + k] = s;
+        }
+    }
+    __syncthreads();
+    double rel_carry[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) rel_carry[k] = carries[K + k];
+    LG::phase_gain(tid, g, th, rel_pre, rel_carry, lds);
+    __syncthreads();
+    LB::template phase_store<false>(tid, chunk, a, true, lds);
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void k_limit_general(LimiterArgs a, GeneralArgs<K> g) {
+    using LB = LimiterBlock<256>;
+    MGX_LDS;
+    float* lds = reinterpret_cast<float*>(mgx_smem);
+    int& ticket = *reinterpret_cast<int*>(LB::scalars(lds) + 4);
+    const bool active = a.active ? (*a.active != 0) : true;
+    if (!active) {                       // hyrax.py:83-85
+        LB::phase_store(threadIdx.x, blockIdx.x, a, false, lds);
+        return;
+    }
+    if (threadIdx.x == 0) ticket = atomicAdd(a.ticket, 1);
+    __syncthreads();
+    limit_chunk_general<K>(a, g, ticket, lds);
 }
 
 // T = threads = 16-frame blocks per chunk (256, or 1024 for long attack / hold times); WGS = workgroups

@@ -325,10 +325,117 @@ static int limit_impl(const LimiterParams& lp, const float* x, long long n, cons
     return ctrl[1] ? -2 : 0;
 }
 
+// hold / release filters of order up to K: limit_chunk_general of mgx_kernels.h, phase by phase
+template <int K>
+static int limit_general_impl(const LimiterParams& lp, const float* x, long long n, const mgx_config* cfg, double gain,
+                              double post_gain, float* out) {
+    using LB = LimiterBlock<256>;
+    using LG = LimiterGeneral<K>;
+    LimiterArgs a;
+    limiter_fill(lp, (float)cfg->threshold, a);
+    a.y = reinterpret_cast<const float2*>(x);
+    a.n = n;
+    a.out = reinterpret_cast<float2*>(out);
+    a.gain = &gain;
+    a.post_gain = &post_gain;
+    a.active = nullptr;
+    a.nchunks = (n + lp.geo.chunk - 1) / lp.geo.chunk;
+    std::vector<unsigned long long> published(limiter_words(lp, a.nchunks), LIMITER_UNPUBLISHED);
+    a.published = published.data();
+    a.w_hold = lp.w_hold.data();
+    a.w_rel = lp.w_rel.data();
+    a.w_att = lp.w_att.data();
+    int ctrl[2] = {0, 0};
+    a.ticket = &ctrl[0];
+    a.error = &ctrl[1];
+    const std::vector<double> tables = general_tables(lp);
+    const GeneralArgs<K> g = general_fill<K>(lp, tables.data(), a.published, a.nchunks);
+    std::vector<float> lds(LG::LDS_BYTES / 4 + 8);
+    std::vector<typename LB::Thread> th(LB::T);
+    std::vector<Affine> in0(LB::T), pre0(LB::T);
+    std::vector<StateMap<K>> pre(LB::T), rel_pre(LB::T), mr(LB::T);
+    auto scan = [&](const std::vector<Affine>& in, std::vector<Affine>& out_pre, bool reverse) {
+        Affine run = affine_identity();
+        for (int i = 0; i < LB::T; ++i) {
+            const int t = reverse ? LB::T - 1 - i : i;
+            out_pre[t] = run;
+            run = affine_then(run, in[t]);
+        }
+        return run;
+    };
+    auto attack_carry = [&](long long chunk) {
+        double s = 0.0;
+        for (int lane = 0; lane < 64; ++lane) {
+            typename LB::Polls p;
+            LB::lookback_ask(lane, chunk, 2, a, p);
+            s += LB::lookback_take(lane, chunk, 2, a, p);
+        }
+        return s;
+    };
+    auto state_carry = [&](long long chunk, int filter, double (&c)[K]) {
+        for (int k = 0; k < K; ++k) c[k] = 0.0;
+        for (int lane = 0; lane < 64; ++lane) {
+            double acc[K];
+            LG::take(lane, chunk, filter, g, a, acc);
+            for (int k = 0; k < K; ++k) c[k] += acc[k];
+        }
+    };
+    auto lds_scan = [&]() {          // the barrier-separated phases of the device scan
+        FOR_THREADS(LB::T) LG::scan_groups(lds.data(), tid);
+        FOR_THREADS(LB::T) LG::scan_top(lds.data(), tid);
+    };
+    for (long long chunk = 0; chunk < a.nchunks; ++chunk) {
+        FOR_THREADS(LB::T) {
+            float pm[LB::E / 2];
+            LB::phase_load(tid, chunk, a, lds.data(), pm);
+        }
+        for (int b = 0; b < LB::T; ++b) {
+            float m = 0.f;
+            for (int j = 0; j < LB::E; ++j) m = std::fmax(m, LB::plane(lds.data())[b * LB::STRIDE + j]);
+            LB::block_max(lds.data())[b] = m;
+        }
+        FOR_THREADS(LB::T) {
+            LB::phase_hold_window(tid, chunk, a, th[tid], lds.data());
+            LG::scan_put(lds.data(), tid, th[tid].core && th[tid].valid > 0
+                                              ? LG::block_map(g.hold, th[tid].sh, th[tid].valid, g.pow_hold)
+                                              : LG::identity());
+        }
+        lds_scan();
+        FOR_THREADS(LB::T) pre[tid] = LG::scan_prefix(lds.data(), tid);
+        LG::publish(g, a.nchunks, 0, chunk, LG::scan_whole(lds.data()).v);
+        FOR_THREADS(LB::T) in0[tid] = LB::phase_attack_window(tid, a, th[tid], lds.data());
+        scan(in0, pre0, false);
+        LB::lookback_publish(chunk, 2, a, pre0[LB::T - a.gr].b);
+        const bool tail = LB::tail_chunk(chunk, a);
+        const double att_carry = attack_carry(chunk);
+        double hold_carry[K], rel_carry[K];
+        state_carry(chunk, 0, hold_carry);
+        FOR_THREADS(LB::T)
+            in0[tid] = LB::phase_attack_forward(tid, a, th[tid], pre0[tid], tail ? att_carry : 0.0, lds.data());
+        scan(in0, pre0, true);
+        FOR_THREADS(LB::T) LB::phase_attack_backward(tid, a, th[tid], pre0[tid]);
+        FOR_THREADS(LB::T) mr[tid] = LG::phase_hold(tid, a, g, th[tid], pre[tid], hold_carry, tail ? 0.0 : att_carry);
+        FOR_THREADS(LB::T) LG::scan_put(lds.data(), tid, mr[tid]);
+        lds_scan();
+        FOR_THREADS(LB::T) rel_pre[tid] = LG::scan_prefix(lds.data(), tid);
+        LG::publish(g, a.nchunks, 1, chunk, LG::scan_whole(lds.data()).v);
+        state_carry(chunk, 1, rel_carry);
+        FOR_THREADS(LB::T) LG::phase_gain(tid, g, th[tid], rel_pre[tid], rel_carry, lds.data());
+        FOR_THREADS(LB::T) LB::phase_store(tid, chunk, a, true, lds.data());
+    }
+    return ctrl[1] ? -2 : 0;
+}
+
+extern "C" int emu_butter(int order, double fc, double fs, double* b, double* a) {
+    butter_tf(order, fc, fs, b, a);
+    return 0;
+}
+
 extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, double gain, double post_gain,
                          float* out, float* dbg_sl, float* dbg_sh) {
     LimiterParams lp;
     if (!limiter_params(*cfg, lp).empty()) return -1;
+    if (lp.general == 2) return limit_general_impl<2>(lp, x, n, cfg, gain, post_gain, out);
     if (lp.threads == 1024) return limit_impl<1024>(lp, x, n, cfg, gain, post_gain, out, dbg_sl, dbg_sh);
     return limit_impl<256>(lp, x, n, cfg, gain, post_gain, out, dbg_sl, dbg_sh);
 }

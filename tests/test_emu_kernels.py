@@ -196,6 +196,51 @@ def test_limiter_unusual_attack_and_hold_times(emu, lim):
     assert np.abs(out - want).max() <= 5e-6
 
 
+def test_butterworth_design_matches_scipy(emu):
+    """butter_tf (host_params.h) against scipy.signal.butter for the orders and cut-offs the limiter uses
+    (hyrax.py:55-72): 7 Hz hold, 800 / 3000 Hz release, sample rates 8 k to 192 k."""
+    from scipy import signal
+
+    emu.emu_butter.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double, c_double_p, c_double_p]
+    for order in (1, 2, 3, 4):          # (the design itself is good at any order)
+        for fc, fs in ((7.0, 44100), (800.0 / 3000.0, 44100), (7.0, 8000), (800.0 / 3000.0, 192000), (50.0, 48000)):
+            b, a = np.zeros(order + 1), np.zeros(order + 1)
+            emu.emu_butter(order, fc, float(fs), _dp(b), _dp(a))
+            wb, wa = signal.butter(order, fc, fs=fs)
+            assert np.allclose(a, wa, rtol=0, atol=1e-13), (order, fc, fs, a, wa)
+            assert np.allclose(b, wb, rtol=1e-9, atol=0), (order, fc, fs, b, wb)
+
+
+# (hold order, release order): the general kernel's K is the larger of the two
+FILTER_ORDERS = [(2, 2), (1, 2), (2, 1)]
+
+
+@pytest.mark.parametrize("orders", FILTER_ORDERS)
+def test_limiter_hold_and_release_filters_of_higher_order(emu, orders):
+    """hold_filter_order / release_filter_order > 1 (defaults.py:39-47, hyrax.py:55-72): K-state sections,
+    matrix-valued block maps and look-back (limiter_general.h), 10 s = ~125 chunks at 44.1 kHz."""
+    import matchering_amd as mg
+    from matchering_amd.synth import synth
+
+    sr = 44100
+    kw = dict(hold_filter_order=orders[0], release_filter_order=orders[1])
+    rng = np.random.RandomState(13)
+    x = synth(10.0, sr, 7).astype(np.float64)
+    x *= 1.7 / np.abs(x).max()
+    x[: sr] *= 0.3
+    x += 1e-3 * rng.randn(*x.shape)
+    y = np.ascontiguousarray(x, dtype=np.float32)
+    cfg = mg.Config(internal_sample_rate=sr, limiter=mg.LimiterConfig(**kw))
+    native = cfg.to_native()
+    out = np.zeros_like(y)
+    rc = emu.emu_limit(_fp(y), ctypes.c_longlong(y.shape[0]), ctypes.byref(native), ctypes.c_double(1.0),
+                       ctypes.c_double(1.0), _fp(out), None, None)
+    assert rc == 0
+    want = mo.limit(y.astype(np.float64), mo.params(internal_sample_rate=sr, **kw))
+    assert rms_error(out, want) <= 1e-6, rms_error(out, want)
+    assert np.abs(out - want).max() <= 1e-5
+
+
 def test_limiter_lookback_across_many_chunks(emu):
     """Default 44.1 kHz limiter on 14 s of hot material: ~85 chunks, so the release filter's carry
     is a truncated look-back over ~70 predecessor chunks and the hold filter's over 3."""

@@ -251,6 +251,43 @@ def test_limiter_unusual_attack_and_hold_times(lim):
     assert np.abs(out - want).max() <= 5e-6
 
 
+@pytest.mark.parametrize("orders", [(2, 2), (1, 2), (2, 1)])
+def test_limiter_hold_and_release_filters_of_order_two(orders):
+    """hold_filter_order / release_filter_order = 2 (defaults.py:39-47, hyrax.py:55-72): k_limit_general,
+    two-state sections with matrix-valued block maps and look-back (limiter_general.h).  20 s = 250 chunks,
+    so the release carry is a sum over ~300 predecessors' state words."""
+    import matchering_amd as mg
+    from matchering_amd import kernels
+    from matchering_amd.synth import synth
+
+    sr = 44100
+    kw = dict(hold_filter_order=orders[0], release_filter_order=orders[1])
+    rng = np.random.RandomState(13)
+    x = synth(20.0, sr, 7).astype(np.float64)
+    x *= 1.7 / np.abs(x).max()
+    x[:sr] *= 0.3
+    x += 1e-3 * rng.randn(*x.shape)
+    y = x.astype(np.float32)
+    out, active = kernels.limit(y, mg.Config(internal_sample_rate=sr, limiter=mg.LimiterConfig(**kw)))
+    want = mo.limit(y.astype(np.float64), mo.params(internal_sample_rate=sr, **kw))
+    assert active
+    assert rms_error(out, want) <= 1e-6
+    assert np.abs(out - want).max() <= 1e-5
+
+
+def test_master_with_second_order_limiter_filters():
+    """The whole path with the limiter's filters at order 2, against the oracle."""
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd.synth import make_pair
+
+    kw = dict(hold_filter_order=2, release_filter_order=2)
+    target, reference = make_pair(12.0, 44100, pair=3, reference_seconds=9.0)
+    got = stages.main(target, reference, mg.Config(max_piece_size=3.0, limiter=mg.LimiterConfig(**kw)))
+    want = mo.master(target, reference, mo.params(max_piece_size=3.0, **kw), True, False, False)
+    assert rms_error(got[0], want[0]) <= RMS_TOL
+
+
 def test_clipped_piece_sumsq():
     from matchering_amd import kernels
 
@@ -272,6 +309,10 @@ def test_fails_loudly_on_unsupported():
     with pytest.raises(MgxError):
         stages.main(t, r, mg.Config(internal_sample_rate=8000, fft_size=32768, max_piece_size=5.0,
                                     max_length=600))
+    # limiter filters of order 3 and up: ill-conditioned in the reference's own form (limiter_general.h)
+    with pytest.raises(MgxError, match="orders above 2"):
+        stages.main(t, r, mg.Config(internal_sample_rate=8000, max_piece_size=5.0,
+                                    limiter=mg.LimiterConfig(release_filter_order=3)))
 
 
 def test_process_files_end_to_end(tmp_path):
