@@ -58,55 +58,70 @@ static std::vector<double> linspace(double start, double stop, int n) {
     return v;
 }
 
-void lowess_it0(const double* y, int n, double frac, double delta, double* fit) {
+void lowess(const double* y, int n, double frac, double delta, int it, double* fit) {
     const std::vector<double> x = linspace(0.0, 1.0, n);
     int k = (int)(frac * n + 1e-10);
     k = std::min(std::max(k, 2), n);
-    std::vector<double> w(n);
-    int i = 0, last = -1, lo = 0, hi = k;
-    while (true) {
-        while (hi < n && x[i] > (x[lo] + x[hi]) / 2.0) { ++lo; ++hi; }
-        const double radius = std::max(x[i] - x[lo], x[hi - 1] - x[i]);
-        double sw = 0.0;
-        int nonzero = 0;
-        for (int j = lo; j < hi; ++j) {
-            const double d = std::fabs(x[j] - x[i]) / radius;
-            const double t = 1.0 - d * d * d;
-            w[j] = t * t * t;
-            sw += w[j];
-            nonzero += w[j] != 0.0;
-        }
-        if (sw <= 0.0 || nonzero == 1) {
-            fit[i] = y[i];
-        } else {
-            double xbar = 0.0;
-            for (int j = lo; j < hi; ++j) { w[j] /= sw; xbar += w[j] * x[j]; }
-            double dev = 0.0;
-            for (int j = lo; j < hi; ++j) dev += w[j] * (x[j] - xbar) * (x[j] - xbar);
-            double acc = 0.0;
-            for (int j = lo; j < hi; ++j)
-                acc += w[j] * (1.0 + (x[i] - xbar) * (x[j] - xbar) / dev) * y[j];
-            fit[i] = acc;
-        }
-        if (last < i - 1) {
-            const double denom = x[i] - x[last];
-            for (int j = last + 1; j < i; ++j) {
-                const double a = (x[j] - x[last]) / denom;
-                fit[j] = a * fit[i] + (1.0 - a) * fit[last];
+    std::vector<double> w(n), robust(n, 1.0);
+    for (int pass = 0; pass <= it; ++pass) {
+        int i = 0, last = -1, lo = 0, hi = k;
+        while (true) {
+            while (hi < n && x[i] > (x[lo] + x[hi]) / 2.0) { ++lo; ++hi; }
+            const double radius = std::max(x[i] - x[lo], x[hi - 1] - x[i]);
+            double sw = 0.0;
+            int nonzero = 0;
+            for (int j = lo; j < hi; ++j) {
+                const double d = std::fabs(x[j] - x[i]) / radius;
+                const double t = 1.0 - d * d * d;
+                w[j] = t * t * t * robust[j];
+                sw += w[j];
+                nonzero += w[j] != 0.0;
             }
+            if (sw <= 0.0 || nonzero == 1) {
+                fit[i] = y[i];
+            } else {
+                double xbar = 0.0;
+                for (int j = lo; j < hi; ++j) { w[j] /= sw; xbar += w[j] * x[j]; }
+                double dev = 0.0;
+                for (int j = lo; j < hi; ++j) dev += w[j] * (x[j] - xbar) * (x[j] - xbar);
+                double acc = 0.0;
+                for (int j = lo; j < hi; ++j)
+                    acc += w[j] * (1.0 + (x[i] - xbar) * (x[j] - xbar) / dev) * y[j];
+                fit[i] = acc;
+            }
+            if (last < i - 1) {
+                const double denom = x[i] - x[last];
+                for (int j = last + 1; j < i; ++j) {
+                    const double a = (x[j] - x[last]) / denom;
+                    fit[j] = a * fit[i] + (1.0 - a) * fit[last];
+                }
+            }
+            last = i;
+            const double cut = x[last] + delta;
+            int kk = last;
+            for (kk = last + 1; kk < n; ++kk) {
+                if (x[kk] > cut) break;
+                if (x[kk] == x[last]) { fit[kk] = fit[last]; last = kk; }
+            }
+            if (kk >= n) kk = n - 1;               // loop ran off the end: Python leaves kk = n-1
+            i = std::max(kk - 1, last + 1);
+            if (last >= n - 1) break;
         }
-        last = i;
-        const double cut = x[last] + delta;
-        int kk = last;
-        for (kk = last + 1; kk < n; ++kk) {
-            if (x[kk] > cut) break;
-            if (x[kk] == x[last]) { fit[kk] = fit[last]; last = kk; }
+        if (pass == it) break;
+        // robustness weights of the next pass: bisquare(|residual| / (6 median |residual|))
+        std::vector<double> r(n);
+        for (int j = 0; j < n; ++j) r[j] = std::fabs(y[j] - fit[j]);
+        std::vector<double> sorted(r);
+        std::sort(sorted.begin(), sorted.end());
+        const double median = n & 1 ? sorted[n / 2] : 0.5 * (sorted[n / 2 - 1] + sorted[n / 2]);
+        for (int j = 0; j < n; ++j) {
+            double u = median == 0.0 ? (r[j] > 0.0 ? 1.0 : 0.0) : r[j] / (6.0 * median);
+            u = std::min(u, 1.0);
+            robust[j] = (1.0 - u * u) * (1.0 - u * u);
         }
-        if (kk >= n) kk = n - 1;               // loop ran off the end: Python leaves kk = n-1
-        i = std::max(kk - 1, last + 1);
-        if (last >= n - 1) break;
     }
 }
+void lowess_it0(const double* y, int n, double frac, double delta, double* fit) { lowess(y, n, frac, delta, 0, fit); }
 
 void smooth_matching_curve(const double* curve, const FirDesignParams& p, double* smooth) {
     const int half = p.fft_size / 2;
@@ -118,7 +133,7 @@ void smooth_matching_curve(const double* curve, const FirDesignParams& p, double
     for (double& v : g_log) v = nyq * std::pow(10.0, v);
     std::vector<double> on_log(nlog), on_log_s(nlog);
     cubic_spline_nak(g_lin.data(), curve, nlin, g_log.data(), nlog, on_log.data());
-    lowess_it0(on_log.data(), nlog, p.lowess_frac, p.lowess_delta, on_log_s.data());
+    lowess(on_log.data(), nlog, p.lowess_frac, p.lowess_delta, p.lowess_it, on_log_s.data());
     cubic_spline_nak(g_log.data(), on_log_s.data(), nlog, g_lin.data(), nlin, smooth);
     smooth[0] = 0.0;                            // match_frequencies.py:72-73
     smooth[1] = curve[1];
@@ -150,7 +165,7 @@ static void fft_pow2(std::vector<std::complex<double>>& a, int sign) {
 
 void design_fir(const double* avg_target, const double* avg_reference, const FirDesignParams& p,
                 double* taps, double* curve_raw, double* curve_smooth) {
-    FirPlanHost::get(p)->design(avg_target, avg_reference, 1.0, taps, curve_raw, curve_smooth);
+    FirPlanHost::get(p)->design(avg_target, avg_reference, 1.0, p.lowess_it, taps, curve_raw, curve_smooth);
 }
 
 void design_fir_direct(const double* avg_target, const double* avg_reference, const FirDesignParams& p,

@@ -6,7 +6,7 @@
 // discrete structure (LOWESS neighbourhoods) that is simplest to keep in
 // float64 on the CPU.  Third-party routines the reference calls are restated:
 //   scipy.interpolate.interp1d(kind="cubic")  -> not-a-knot cubic spline
-//   statsmodels lowess(frac, it=0, delta)     -> lowess_it0 (Cleveland's LOWESS, no robustness passes)
+//   statsmodels lowess(frac, it, delta)       -> lowess (Cleveland's LOWESS with `it` robustness passes)
 //   numpy.fft.irfft / ifftshift, scipy.signal.windows.hann (symmetric)
 #pragma once
 
@@ -19,7 +19,7 @@ struct FirDesignParams {
     int sample_rate;
     int lin_log_oversampling;
     double lowess_frac;
-    int lowess_it;              // must be 0
+    int lowess_it;              // robustness iterations (the reference's default is 0)
     double lowess_delta;
     double min_value;
 };
@@ -29,6 +29,7 @@ struct FirDesignParams {
 void cubic_spline_nak(const double* x, const double* y, int n, const double* xq, int nq, double* out);
 
 // LOWESS with zero robustness iterations on the index grid x = linspace(0,1,n).
+void lowess(const double* y, int n, double frac, double delta, int it, double* fit);
 void lowess_it0(const double* y, int n, double frac, double delta, double* fit);
 
 // match_frequencies.py:45-75

@@ -94,7 +94,8 @@ SplineOffsets build_spline(Blob& blob, const std::vector<double>& x, const std::
 
 struct LowessOffsets {
     int n, anchors, k;
-    size_t lo, p, a0, a1, alpha;
+    size_t lo, pos, p, a0, a1, alpha;
+    double step;
 };
 
 // The index walk of LOWESS (it = 0) on x = linspace(0,1,n): which points get a regression,
@@ -103,7 +104,7 @@ LowessOffsets build_lowess(Blob& blob, int n, double frac, double delta) {
     const std::vector<double> x = np_linspace(0.0, 1.0, n);
     int k = (int)(frac * n + 1e-10);
     k = std::min(std::max(k, 2), n);
-    std::vector<int> los, a0(n, 0), a1(n, 0);
+    std::vector<int> los, poss, a0(n, 0), a1(n, 0);
     std::vector<double> rows, alpha(n, 0.0), w(k);
     int i = 0, last = -1, lo = 0, hi = k, last_anchor = -1;
     while (true) {
@@ -120,6 +121,7 @@ LowessOffsets build_lowess(Blob& blob, int n, double frac, double delta) {
         }
         const int anchor = (int)los.size();
         los.push_back(lo);
+        poss.push_back(i);
         const size_t row = rows.size();
         rows.resize(row + k, 0.0);
         if (sw <= 0.0 || nonzero == 1) {
@@ -158,6 +160,8 @@ LowessOffsets build_lowess(Blob& blob, int n, double frac, double delta) {
     o.anchors = (int)los.size();
     o.k = k;
     o.lo = blob.put(los);
+    o.pos = blob.put(poss);
+    o.step = (1.0 - 0.0) / (n - 1);
     o.p = blob.put(rows);
     o.a0 = blob.put(a0);
     o.a1 = blob.put(a1);
@@ -238,6 +242,8 @@ FirPlanView FirPlanHost::view(const void* base_ptr) const {
     v.lw.anchors = m.lw.anchors;
     v.lw.k = m.lw.k;
     v.lw.lo = (const int*)(base + m.lw.lo);
+    v.lw.pos = (const int*)(base + m.lw.pos);
+    v.lw.step = m.lw.step;
     v.lw.p = (const double*)(base + m.lw.p);
     v.lw.a0 = (const int*)(base + m.lw.a0);
     v.lw.a1 = (const int*)(base + m.lw.a1);
@@ -261,8 +267,8 @@ std::shared_ptr<FirPlanHost> FirPlanHost::get(const FirDesignParams& p) {
 }
 
 // the device phases, run as a loop over thread ids (host path of mgx_design_fir, CPU tests)
-void FirPlanHost::design(const double* avg_target, const double* avg_reference, double target_gain, double* taps,
-                         double* curve_raw, double* curve_smooth) const {
+void FirPlanHost::design(const double* avg_target, const double* avg_reference, double target_gain, int lowess_it,
+                         double* taps, double* curve_raw, double* curve_smooth) const {
     using FD = FirDesign;
     const FirPlanView pl = view(blob());
     std::vector<double> raw(pl.bins), m1(pl.bins), on_log(pl.nlog), fit(pl.lw.anchors), log_s(pl.nlog),
@@ -284,8 +290,24 @@ void FirPlanHost::design(const double* avg_target, const double* avg_reference, 
     };
     solve(pl.s1, s.raw, s.m1);
     ALL(FD::phase_eval(tid, pl.s1, s.raw, s.m1, s.on_log))
-    ALL(FD::phase_lowess_fit(tid, pl.lw, s.on_log, s.fit))
-    ALL(FD::phase_lowess_fill(tid, pl.lw, s.fit, s.log_s))
+    if (lowess_it == 0) {
+        ALL(FD::phase_lowess_fit(tid, pl.lw, s.on_log, s.fit))
+        ALL(FD::phase_lowess_fill(tid, pl.lw, s.fit, s.log_s))
+    } else {
+        std::vector<double> robust(pl.nlog), resid(pl.nlog);
+        ALL(FD::phase_robust_init(tid, pl.nlog, robust.data()))
+        for (int pass = 0; pass <= lowess_it; ++pass) {
+            ALL(FD::phase_lowess_fit_robust(tid, pl.lw, s.on_log, robust.data(), s.fit))
+            ALL(FD::phase_lowess_fill(tid, pl.lw, s.fit, s.log_s))
+            if (pass == lowess_it) break;
+            ALL(FD::phase_residuals(tid, pl.nlog, s.on_log, s.log_s, resid.data()))
+            std::vector<double> sorted(resid);                      // numpy.median: mean of the two middle values
+            std::sort(sorted.begin(), sorted.end());
+            const int n = pl.nlog;
+            const double median = n & 1 ? sorted[n / 2] : 0.5 * (sorted[n / 2 - 1] + sorted[n / 2]);
+            ALL(FD::phase_robust_weights(tid, pl.nlog, resid.data(), median, robust.data()))
+        }
+    }
     solve(pl.s2, s.log_s, s.m2);
     ALL(FD::phase_eval(tid, pl.s2, s.log_s, s.m2, s.smooth))
     ALL(FD::phase_pin(tid, s))

@@ -46,7 +46,9 @@ struct LowessTables {
     int anchors;            // fitted points
     int k;                  // row length (neighbourhood size)
     const int* lo;          // [anchors] first neighbour of each anchor
-    const double* p;        // [anchors][k] regression weights (zero padded)
+    const int* pos;         // [anchors] the anchor's own point
+    double step;            // x[j] = j * step (x = numpy.linspace(0, 1, n)), x[n-1] = 1
+    const double* p;        // [anchors][k] regression weights (zero padded), robustness weights all 1
     const int* a0;          // [n] anchor index left of (or at) each point
     const int* a1;          // [n] anchor index right of (or at) each point
     const double* alpha;    // [n] interpolation weight of a1
@@ -169,6 +171,61 @@ struct FirDesign {
         }
     }
 
+    // ---- LOWESS with robustness iterations (lowess_it > 0): the regression weights depend on the data --
+    // statsmodels' _smoothers_lowess.pyx restated (oracle/mastering_oracle.py: lowess): tricube weights
+    // times the robustness weights, the local linear fit in closed form; one anchor per thread, the
+    // neighbourhood walked four times (sum of weights, weighted mean, weighted spread, fit) instead of
+    // keeping k weights per thread.
+    static MGX_HD double lowess_x(const LowessTables& lw, int j) { return j == lw.n - 1 ? 1.0 : j * lw.step; }
+    static MGX_HD void phase_robust_init(int tid, int n, double* robust) {
+        for (int q = tid; q < n; q += T) robust[q] = 1.0;
+    }
+    static MGX_HD void phase_lowess_fit_robust(int tid, const LowessTables& lw, const double* y, const double* robust,
+                                               double* fit) {
+        for (int a = tid; a < lw.anchors; a += T) {
+            const int i = lw.pos[a], lo = lw.lo[a], hi = lo + lw.k;
+            const double xi = lowess_x(lw, i);
+            const double radius = fmax(xi - lowess_x(lw, lo), lowess_x(lw, hi - 1) - xi);
+            auto weight = [&](int j) {
+                const double d = fabs(lowess_x(lw, j) - xi) / radius;
+                const double t = 1.0 - d * d * d;
+                return t * t * t * robust[j];
+            };
+            double sw = 0.0;
+            int nonzero = 0;
+            for (int j = lo; j < hi; ++j) {
+                const double w = weight(j);
+                sw += w;
+                nonzero += w != 0.0;
+            }
+            if (sw <= 0.0 || nonzero == 1) {
+                fit[a] = y[i];
+                continue;
+            }
+            double xbar = 0.0, dev = 0.0, acc = 0.0;
+            for (int j = lo; j < hi; ++j) xbar += weight(j) / sw * lowess_x(lw, j);
+            for (int j = lo; j < hi; ++j) {
+                const double c = lowess_x(lw, j) - xbar;
+                dev += weight(j) / sw * c * c;
+            }
+            for (int j = lo; j < hi; ++j)
+                acc += weight(j) / sw * (1.0 + (xi - xbar) * (lowess_x(lw, j) - xbar) / dev) * y[j];
+            fit[a] = acc;
+        }
+    }
+    static MGX_HD void phase_residuals(int tid, int n, const double* y, const double* smooth, double* resid) {
+        for (int q = tid; q < n; q += T) resid[q] = fabs(y[q] - smooth[q]);
+    }
+    // bisquare of |residual| / (6 median), clipped at 1; a zero median leaves weights 1 (exact fit) or 0
+    static MGX_HD void phase_robust_weights(int tid, int n, const double* resid, double median, double* robust) {
+        for (int q = tid; q < n; q += T) {
+            double r = median == 0.0 ? (resid[q] > 0.0 ? 1.0 : 0.0) : resid[q] / (6.0 * median);
+            r = fmin(r, 1.0);
+            const double t = 1.0 - r * r;
+            robust[q] = t * t;
+        }
+    }
+
     // ---- pinning + inverse real FFT + shift + window (match_frequencies.py:72-73,98-99) ----
     static MGX_HD void phase_pin(int tid, FirScratch& s) {
         if (tid == 0) {
@@ -211,7 +268,7 @@ public:
     int nlog() const;
     int anchors() const;
     // runs the phases on the host: taps[F] float64 (target_gain multiplies avg_target)
-    void design(const double* avg_target, const double* avg_reference, double target_gain, double* taps,
+    void design(const double* avg_target, const double* avg_reference, double target_gain, int lowess_it, double* taps,
                 double* curve_raw, double* curve_smooth) const;
 
 private:

@@ -81,6 +81,7 @@ struct mgx_handle {
     DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars, conv_queue;
     DevBuf lim_published, lim_ctrl, lim_weights, round_ctr, tail_gains, band, band_info;
     std::vector<double> lim_weights_host;
+    DevBuf fir_robust;                      // lowess_it > 0: robustness weights and residuals, [2][2][nlog]
     DevBuf lim_tables;                      // general filter orders: matrix powers and look-back matrices
     std::vector<double> lim_tables_host;
     DevBuf fir_scratch;
@@ -195,7 +196,7 @@ static int check_config(const mgx_config* c) {
                                          "(one analysis segment must fit one CU's LDS)");
     if (c->rms_correction_steps < 0 || c->rms_correction_steps > 16)   /* CorrectionState::coeffs, the gain words */
         return fail(MGX_ERR_UNSUPPORTED, "rms_correction_steps outside [0, 16]");
-    if (c->lowess_it != 0) return fail(MGX_ERR_UNSUPPORTED, "lowess_it != 0 is not implemented");
+    if (c->lowess_it < 0 || c->lowess_it > 64) return fail(MGX_ERR_ARGUMENT, "lowess_it outside [0, 64]");
     if (!(c->threshold > c->min_value && c->threshold < 1.0 && c->min_value > 0.0))
         return fail(MGX_ERR_ARGUMENT, "threshold/min_value out of range (defaults.py:93-99)");
     if (!(c->max_piece_size > c->fft_size)) return fail(MGX_ERR_ARGUMENT, "max_piece_size must exceed fft_size samples");
@@ -408,11 +409,15 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     if (it == h->plan_dev.end()) {
         HIP_TRY(hipMalloc(&pd.blob, plan->blob_bytes()));
         HIP_TRY(hipMemcpy(pd.blob, plan->blob(), plan->blob_bytes(), hipMemcpyHostToDevice));
-        MGX_TRY(build_fir_operator(h, plan->view(pd.blob), &pd.M, &pd.band));
         h->plan_dev[plan.get()] = pd;
         h->plans.push_back(plan);
     } else {
         pd = it->second;
+    }
+    const bool robust = cfg->lowess_it > 0;      // LOWESS with robustness passes is not linear: no operator
+    if (!robust && !pd.M) {
+        MGX_TRY(build_fir_operator(h, plan->view(pd.blob), &pd.M, &pd.band));
+        h->plan_dev[plan.get()] = pd;
     }
     const FirPlanView pl = plan->view(pd.blob);
     const size_t per = (size_t)3 * pl.bins + (size_t)3 * pl.nlog + pl.lw.anchors;
@@ -457,8 +462,17 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
         h->last_taps = cfg->fft_size;
         return 0;
     }
-    hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
-                       (const int2*)pd.band, (const double*)raw, scratch);
+    if (robust) {
+        const size_t lds_scan = (size_t)FirDesign::Scan::SCRATCH * sizeof(Affine);
+        MGX_TRY(ensure(h, h->fir_robust, (size_t)4 * pl.nlog * sizeof(double)));
+        hipLaunchKernelGGL(k_fir_direct_a, dim3(2), dim3(1024), lds_scan, h->stream, pl, scratch, (const double*)raw);
+        hipLaunchKernelGGL(k_fir_lowess_robust, dim3(2), dim3(1024), 0, h->stream, pl, scratch, (double*)h->fir_robust.p,
+                           cfg->lowess_it);
+        hipLaunchKernelGGL(k_fir_b, dim3(2), dim3(1024), lds_scan, h->stream, pl, scratch);
+    } else {
+        hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
+                           (const int2*)pd.band, (const double*)raw, scratch);
+    }
     const size_t lds_taps = ((size_t)pl.bins + 1024) * sizeof(double);
     if (pl.fft < TAPS_PER_WG) return fail(MGX_ERR_UNSUPPORTED, "fft_size below 64 is not implemented");
     MGX_TRY(allow_lds(k_fir_taps, lds_taps));
@@ -733,7 +747,7 @@ int mgx_destroy(mgx_handle* h) {
     hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
-                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->lim_tables, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info,
+                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->lim_tables, &h->fir_robust, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info,
                       &h->conv_queue};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -862,7 +876,7 @@ int mgx_design_fir(const mgx_config* cfg, const double* avg_target, const double
                    double* curve_raw, double* curve_smooth) {
     if (!cfg || !avg_target || !avg_reference || !taps) return fail(MGX_ERR_ARGUMENT, "null argument");
     if (ilog2_exact(cfg->fft_size) < 0 || cfg->fft_size < 8) return fail(MGX_ERR_ARGUMENT, "bad fft_size");
-    if (cfg->lowess_it != 0) return fail(MGX_ERR_UNSUPPORTED, "lowess_it != 0 is not implemented");
+    if (cfg->lowess_it < 0 || cfg->lowess_it > 64) return fail(MGX_ERR_ARGUMENT, "lowess_it outside [0, 64]");
     FirDesignParams p{cfg->fft_size, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac,
                       cfg->lowess_it, cfg->lowess_delta, cfg->min_value};
     design_fir(avg_target, avg_reference, p, taps, curve_raw, curve_smooth);

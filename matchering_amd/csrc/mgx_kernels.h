@@ -548,6 +548,68 @@ __global__ __launch_bounds__(1024) void k_fir_unit_a(FirPlanView pl, double* scr
     fir_solve(pl.s1, s.raw, s.m1, sc);
     FirDesign::phase_eval(tid, pl.s1, s.raw, s.m1, s.on_log);
 }
+// ---- lowess_it > 0: LOWESS is no longer linear in the data, so the chain runs on the curve itself ----
+// raw curve -> spline onto the log grid.  grid = 2 (mid, side)
+__global__ __launch_bounds__(1024) void k_fir_direct_a(FirPlanView pl, double* scratch, const double* raw /* [2][bins] */) {
+    MGX_LDS;
+    Affine* sc = reinterpret_cast<Affine*>(mgx_smem);
+    const int tid = threadIdx.x, plane = blockIdx.x;
+    FirScratch s = fir_scratch(scratch, pl, plane);
+    for (int k = tid; k < pl.bins; k += 1024) s.raw[k] = raw[(size_t)plane * pl.bins + k];
+    __syncthreads();
+    fir_solve(pl.s1, s.raw, s.m1, sc);
+    FirDesign::phase_eval(tid, pl.s1, s.raw, s.m1, s.on_log);
+}
+// the k-th smallest (k from 0) of n non-negative doubles, by bisection on the bit pattern (which orders
+// them): 63 counting passes, every thread of the 1024 gets the result.  red: 17 ints of LDS
+__device__ __forceinline__ double block_select(const double* v, int n, int k, int* red) {
+    const int tid = threadIdx.x;
+    unsigned long long lo = 0ull, hi = 0x7ff0000000000000ull;
+    while (lo < hi) {
+        const unsigned long long mid = lo + ((hi - lo) >> 1);
+        int c = 0;
+        for (int q = tid; q < n; q += 1024) c += double_bits(v[q]) <= mid ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = c;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < 16; ++w) t += red[w];
+            red[16] = t;
+        }
+        __syncthreads();
+        if (red[16] >= k + 1) hi = mid;
+        else lo = mid + 1;
+        __syncthreads();                      // red[16] is rewritten in the next pass
+    }
+    return bits_double(lo);
+}
+// LOWESS with robustness iterations (fir_plan.h: phase_lowess_fit_robust ...), one workgroup per channel;
+// work: [2][2][nlog] doubles (robustness weights, residuals).  Leaves the anchors' fits of the last pass
+// in s.fit, where k_fir_b picks them up.
+__global__ __launch_bounds__(1024) void k_fir_lowess_robust(FirPlanView pl, double* scratch, double* work, int it) {
+    __shared__ int red[17];
+    const int tid = threadIdx.x, plane = blockIdx.x, n = pl.nlog;
+    FirScratch s = fir_scratch(scratch, pl, plane);
+    double* robust = work + (size_t)plane * 2 * n;
+    double* resid = robust + n;
+    FirDesign::phase_robust_init(tid, n, robust);
+    __syncthreads();
+    for (int pass = 0; pass <= it; ++pass) {
+        FirDesign::phase_lowess_fit_robust(tid, pl.lw, s.on_log, robust, s.fit);
+        __syncthreads();
+        if (pass == it) break;
+        FirDesign::phase_lowess_fill(tid, pl.lw, s.fit, s.log_s);
+        __syncthreads();
+        FirDesign::phase_residuals(tid, n, s.on_log, s.log_s, resid);
+        __syncthreads();
+        double median = block_select(resid, n, n / 2, red);                       // numpy.median
+        if (!(n & 1)) median = 0.5 * (block_select(resid, n, n / 2 - 1, red) + median);
+        FirDesign::phase_robust_weights(tid, n, resid, median, robust);
+        __syncthreads();
+    }
+}
 // M[i][col0 + c] = smooth of unit vector col0 + c, bin i
 __global__ __launch_bounds__(256) void k_fir_gather(FirPlanView pl, double* scratch, int col0, int ncols, double* M) {
     const int c = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;

@@ -158,54 +158,73 @@ def average_spectrum(pieces, fft_size):
     return (np.abs(np.fft.rfft(segs, axis=-1)) / fft_size).mean(axis=(0, 1))
 
 
-def lowess_it0(y, frac, delta):
-    """LOWESS with zero robustness iterations on the index grid
+def lowess(y, frac, delta, it=0):
+    """LOWESS with ``it`` robustness iterations on the index grid
     x = linspace(0, 1, n), as reached from dsp.py:103-106.
 
     Restated from statsmodels' ``_smoothers_lowess.pyx`` (not vendored in the
-    reference): k = int(frac*n + 1e-10) nearest neighbours, tricube weights,
-    local linear fit; points closer than ``delta`` to the last fitted point are
-    skipped and filled by linear interpolation."""
+    reference): k = int(frac*n + 1e-10) nearest neighbours, tricube weights
+    times the robustness weights, local linear fit; points closer than
+    ``delta`` to the last fitted point are skipped and filled by linear
+    interpolation.  After each pass the robustness weights become
+    bisquare(|residual| / (6 median|residual|)) (Cleveland 1979), and the fit
+    is repeated ``it`` more times."""
     y = np.asarray(y, dtype=np.float64)
     n = y.shape[0]
     x = np.linspace(0, 1, n)
     k = min(max(int(frac * n + 1e-10), 2), n)
+    robust = np.ones(n)
     fit = np.zeros(n)
-    i, last, lo, hi = 0, -1, 0, k
-    while True:
-        # slide the k-neighbourhood [lo, hi) to the right while that brings it closer
-        while hi < n and x[i] > (x[lo] + x[hi]) / 2.0:
-            lo += 1
-            hi += 1
-        radius = max(x[i] - x[lo], x[hi - 1] - x[i])
-        xs = x[lo:hi]
-        w = np.abs(xs - x[i]) / radius
-        w = (1.0 - w * w * w) ** 3
-        sw = w.sum()
-        if sw <= 0.0 or np.count_nonzero(w) == 1:
-            fit[i] = y[i]
-        else:
-            w = w / sw
-            xbar = float(np.sum(w * xs))
-            dev = float(np.sum(w * (xs - xbar) ** 2))
-            p = w * (1.0 + (x[i] - xbar) * (xs - xbar) / dev)
-            fit[i] = float(np.sum(p * y[lo:hi]))
-        if last < i - 1:
-            a = (x[last + 1 : i] - x[last]) / (x[i] - x[last])
-            fit[last + 1 : i] = a * fit[i] + (1.0 - a) * fit[last]
-        last = i
-        cut = x[last] + delta
-        kk = last
-        for kk in range(last + 1, n):
-            if x[kk] > cut:
+    for _ in range(it + 1):
+        fit = np.zeros(n)
+        i, last, lo, hi = 0, -1, 0, k
+        while True:
+            # slide the k-neighbourhood [lo, hi) to the right while that brings it closer
+            while hi < n and x[i] > (x[lo] + x[hi]) / 2.0:
+                lo += 1
+                hi += 1
+            radius = max(x[i] - x[lo], x[hi - 1] - x[i])
+            xs = x[lo:hi]
+            w = np.abs(xs - x[i]) / radius
+            w = (1.0 - w * w * w) ** 3 * robust[lo:hi]
+            sw = w.sum()
+            if sw <= 0.0 or np.count_nonzero(w) == 1:
+                fit[i] = y[i]
+            else:
+                w = w / sw
+                xbar = float(np.sum(w * xs))
+                dev = float(np.sum(w * (xs - xbar) ** 2))
+                p = w * (1.0 + (x[i] - xbar) * (xs - xbar) / dev)
+                fit[i] = float(np.sum(p * y[lo:hi]))
+            if last < i - 1:
+                a = (x[last + 1 : i] - x[last]) / (x[i] - x[last])
+                fit[last + 1 : i] = a * fit[i] + (1.0 - a) * fit[last]
+            last = i
+            cut = x[last] + delta
+            kk = last
+            for kk in range(last + 1, n):
+                if x[kk] > cut:
+                    break
+                if x[kk] == x[last]:
+                    fit[kk] = fit[last]
+                    last = kk
+            i = max(kk - 1, last + 1)
+            if last >= n - 1:
                 break
-            if x[kk] == x[last]:
-                fit[kk] = fit[last]
-                last = kk
-        i = max(kk - 1, last + 1)
-        if last >= n - 1:
-            break
+        # robustness weights for the next pass
+        r = np.abs(y - fit)
+        med = np.median(r)
+        if med == 0.0:
+            r = (r > 0).astype(np.float64)
+        else:
+            r = r / (6.0 * med)
+        r = np.minimum(r, 1.0)
+        robust = (1.0 - r * r) ** 2
     return fit
+
+
+def lowess_it0(y, frac, delta):
+    return lowess(y, frac, delta, 0)
 
 
 def smooth_matching_curve(h, cfg):
@@ -216,8 +235,7 @@ def smooth_matching_curve(h, cfg):
     g_lin = nyq * np.linspace(0, 1, half + 1)
     g_log = nyq * np.logspace(np.log10(4 / cfg.fft_size), 0, half * cfg.lin_log_oversampling + 1)
     h_log = interpolate.interp1d(g_lin, h, "cubic")(g_log)
-    assert cfg.lowess_it == 0, "the oracle restates LOWESS for it=0 only (defaults.py:76)"
-    h_log_s = lowess_it0(h_log, cfg.lowess_frac, cfg.lowess_delta)
+    h_log_s = lowess(h_log, cfg.lowess_frac, cfg.lowess_delta, cfg.lowess_it)
     out = interpolate.interp1d(g_log, h_log_s, "cubic", fill_value="extrapolate")(g_lin)
     out[0] = 0
     out[1] = h[1]

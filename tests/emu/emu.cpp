@@ -455,6 +455,10 @@ extern "C" int emu_design_fir_direct(const mgx_config* cfg, const double* avg_ta
     design_fir_direct(avg_target, avg_reference, p, taps, curve_raw, curve_smooth);
     return 0;
 }
+extern "C" int emu_lowess_robust(const double* y, int n, double frac, double delta, int it, double* fit) {
+    lowess(y, n, frac, delta, it, fit);
+    return 0;
+}
 extern "C" int emu_lowess(const double* y, int n, double frac, double delta, double* fit) {
     lowess_it0(y, n, frac, delta, fit);
     return 0;

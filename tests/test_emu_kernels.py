@@ -196,6 +196,43 @@ def test_limiter_unusual_attack_and_hold_times(emu, lim):
     assert np.abs(out - want).max() <= 5e-6
 
 
+def test_host_lowess_with_robustness_iterations(emu):
+    """fir_design.cpp: lowess() against the compiled statsmodels' known answers for 1..3 robustness passes."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "lowess_robust_kat.npz"))
+    y = np.ascontiguousarray(g["y"], dtype=np.float64)
+    for it in (1, 2, 3):
+        fit = np.zeros_like(y)
+        emu.emu_lowess_robust(_dp(y), ctypes.c_int(len(y)), ctypes.c_double(float(g["frac"])),
+                              ctypes.c_double(float(g["delta"])), ctypes.c_int(it), _dp(fit))
+        assert np.abs(fit - g[f"fit{it}"]).max() <= 1e-11
+
+
+@pytest.mark.parametrize("it", [1, 3])
+def test_fir_design_phases_with_lowess_iterations(emu, it):
+    """The device phase functions of the FIR design (fir_plan.h) run on the host with Config.lowess_it > 0
+    -- per-anchor weighted regressions with robustness weights, residuals, median, bisquare -- against the
+    oracle's design (match_frequencies.py:45-101)."""
+    import matchering_amd as mg
+
+    fft = 1024
+    rng = np.random.RandomState(3)
+    bins = fft // 2 + 1
+    k = np.arange(bins)
+    a_t = (1.0 / (1.0 + k / 40.0) + 0.02 * rng.rand(bins)) * fft
+    a_r = (1.2 / (1.0 + k / 25.0) + 0.02 * rng.rand(bins)) * fft
+    a_r[100] *= 8.0                                  # a resonance the robust passes discount
+    a_r[300:304] *= 0.1
+    cfg = mg.Config(fft_size=fft, lowess_it=it)
+    native = cfg.to_native()
+    taps, raw, smooth = np.zeros(fft), np.zeros(bins), np.zeros(bins)
+    assert emu.emu_design_fir(ctypes.byref(native), _dp(a_t), _dp(a_r), _dp(taps), _dp(raw), _dp(smooth)) == 0
+    p = mo.params(fft_size=fft, lowess_it=it)
+    want_smooth = mo.smooth_matching_curve(a_r / np.maximum(p.min_value, a_t), p)
+    assert np.abs(smooth - want_smooth).max() <= 1e-9 * np.abs(want_smooth).max()
+    p0 = mo.params(fft_size=fft)
+    assert np.abs(want_smooth - mo.smooth_matching_curve(a_r / np.maximum(p.min_value, a_t), p0)).max() > 1e-3
+
+
 def test_butterworth_design_matches_scipy(emu):
     """butter_tf (host_params.h) against scipy.signal.butter for the orders and cut-offs the limiter uses
     (hyrax.py:55-72): 7 Hz hold, 800 / 3000 Hz release, sample rates 8 k to 192 k."""

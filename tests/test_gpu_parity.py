@@ -525,3 +525,22 @@ def test_threads_sharing_the_default_device_do_not_interleave():
     for th in threads:
         th.join()
     assert not failures, failures
+
+
+@pytest.mark.parametrize("it", [1, 3])
+def test_master_with_lowess_robustness_iterations(it):
+    """Config.lowess_it > 0 (defaults.py:76, dsp.py:103-106): LOWESS is then not linear in the curve, so the
+    design runs the chain on the curve itself (k_fir_direct_a, k_fir_lowess_robust, k_fir_b) instead of one
+    operator product.  Against the oracle, whose LOWESS is pinned to the compiled statsmodels for it = 1..3;
+    then the same Config with it = 0 (its operator is built on first need) must still agree."""
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd.synth import make_pair
+
+    target, reference = make_pair(10.0, 44100, pair=4, reference_seconds=8.0)
+    for passes in (it, 0):
+        cfg = mg.Config(max_piece_size=2.0, fft_size=2048, lowess_it=passes)
+        got = stages.main(target, reference, cfg, need_default=True, need_no_limiter=True)
+        want = mo.master(target, reference, mo.params(max_piece_size=2.0, fft_size=2048, lowess_it=passes), True, True, False)
+        for mine, ref in zip(got[:2], want[:2]):
+            assert rms_error(mine, ref) <= RMS_TOL, (passes, rms_error(mine, ref))

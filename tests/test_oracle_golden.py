@@ -88,6 +88,16 @@ def test_lowess_known_answer(golden):
     assert np.abs(fit - g["fit"]).max() <= TIGHT
 
 
+def test_lowess_with_robustness_iterations_known_answer(golden):
+    """Config.lowess_it > 0 (defaults.py:76): the restatement against the compiled statsmodels' outputs for
+    1, 2 and 3 robustness passes (tests/golden/make_lowess_robust.py; the input carries outliers)."""
+    g = golden("lowess_robust_kat")
+    for it in (1, 2, 3):
+        fit = mo.lowess(g["y"], float(g["frac"]), float(g["delta"]), it)
+        assert np.abs(fit - g[f"fit{it}"]).max() <= TIGHT
+    assert np.abs(g["fit1"] - mo.lowess_it0(g["y"], float(g["frac"]), float(g["delta"]))).max() > 1e-2
+
+
 def test_limiter_never_exceeds_threshold(runs):
     # invariant from hyrax.py:87,97,99: gain <= 1/rectified
     for name in ("cd_default", "hot_lowrate"):
