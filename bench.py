@@ -43,7 +43,7 @@ PIPELINE_BYTES = {"8min_full": 72, "8min_fir_only": 64, "4min_x8_full": 72, "96k
 KERNEL_BYTES = {"convolve": 16,    # S3: read 8 + write 8 (the mid plane's 4 B are booked to S4)
                 "limit": 16}       # read 8 + write 8 per launch of the one-pass limiter (S5's 24 B model
                                    # counts a second read that this kernel takes from the L2 / Infinity Cache)
-KERNEL_NAMES = {"convolve": "k_conv (overlap-save FIR)", "limit": "k_limit3 (Hyrax limiter, one pass)"}
+KERNEL_NAMES = {"convolve": "k_conv (overlap-save FIR)", "limit": "k_limit (Hyrax limiter, one pass)"}
 WORKLOADS = sorted(PIPELINE_BYTES)
 
 
