@@ -22,6 +22,13 @@ SHAPES = [(7.3, 44100, 4096), (31.0, 44100, 4096), (3.1, 96000, 16384), (12.0, 4
           (64.0, 44100, 4096)]
 
 
+# what a Config may vary beyond the shape: LOWESS robustness passes (no operator), second-order limiter filters
+# (k_limit_general), long attack / hold times (1024-block chunks)
+VARIANTS = [dict(), dict(), dict(lowess_it=2),
+            dict(limiter=dict(hold_filter_order=2, release_filter_order=2)),
+            dict(limiter=dict(attack=8.0, hold=2.0))]
+
+
 def worker(lane, deadline, stats, lock):
     dev = Device(0)
     rng = np.random.RandomState(lane)
@@ -30,10 +37,14 @@ def worker(lane, deadline, stats, lock):
         k = int(rng.randint(len(SHAPES)))
         seconds, rate, fft = SHAPES[k]
         t, r = make_pair(seconds, rate, pair=k)
-        cfg = mg.Config(internal_sample_rate=rate, fft_size=fft, max_piece_size=min(15.0, seconds / 2.5))
+        v = int(rng.randint(len(VARIANTS)))
+        extra = dict(VARIANTS[v])
+        if "limiter" in extra:
+            extra["limiter"] = mg.LimiterConfig(**extra["limiter"])
+        cfg = mg.Config(internal_sample_rate=rate, fft_size=fft, max_piece_size=min(15.0, seconds / 2.5), **extra)
         need = (bool(rng.randint(2)), True, bool(rng.randint(2)))
         out = stages.main(t, r, cfg, *need, device=dev)
-        key = (k,)
+        key = (k, v)
         ref = first.setdefault(key, {})
         for i, o in enumerate(out):
             if o is None:
