@@ -160,6 +160,17 @@ int mgx_limit(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cf
 /* dsp.py:89-90 amplify on interleaved frames: out = x * gain */
 int mgx_scale(mgx_handle* h, const float* x_dev, int64_t n, double gain, float* out_dev);
 
+/* Integer PCM at the boundary.  The reference reads and writes files through soundfile
+ * (loader.py:35 sf.read, saver.py:27-33 sf.write), i.e. libsndfile converts between the file's integer
+ * samples and floats on the host.  These two entry points do that conversion in HBM, so that the integer
+ * samples -- half the bytes of float32 at 16 bits -- are what crosses PCIe: `samples` counts single
+ * samples (2 per stereo frame), interleaved as in the file; bits = 16 (int16), 24 (three bytes per
+ * sample, little-endian, packed) or 32 (int32).  Scaling as libsndfile: decode x = v / 2^(bits-1);
+ * encode v = rint(x * (2^(bits-1) - 1)), clipped to the integer range, evaluated in float64.  Queued on
+ * the handle's stream. */
+int mgx_pcm_decode(mgx_handle* h, const void* pcm_dev, int64_t samples, int32_t bits, float* out_dev);
+int mgx_pcm_encode(mgx_handle* h, const float* x_dev, int64_t samples, int32_t bits, void* pcm_dev);
+
 /* Album mode (the use of the FIR broadcast): stages.main with the matching-EQ FIR
  * GIVEN instead of designed from this pair's spectra -- `fir_dev` = [2][fft_size] float32 in HBM, mid
  * taps then side taps, e.g. the table mgx_last_fir returns on the rank that designed it, after

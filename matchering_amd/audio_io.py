@@ -9,6 +9,12 @@ AIFF: big-endian PCM 8/16/24/32, AIFF-C `fl32` / `fl64` / `sowt`); FLAC, OGG and
 soundfile or ffmpeg.  Scaling
 follows libsndfile: integers are read as ``x / 2**(bits-1)`` and written as
 ``rint(x * (2**(bits-1) - 1))`` (clipped to the integer range instead of wrapping).
+
+Integer PCM can also pass through undecoded (``load(..., pcm=True)``, integer arrays given to ``save``):
+the samples then cross PCIe as the file holds them and are converted on the GPU (``mgx_pcm_decode`` /
+``mgx_pcm_encode``, same scaling).  Such an array is int16 (n, channels) or int32 (n, channels) on the
+way in, and on the way out also uint8 (n, channels * 3) for packed little-endian 24-bit samples;
+``pcm_to_float`` turns any of them into the floats the default path returns.
 """
 
 import os
@@ -45,80 +51,166 @@ def check_format(extension, subtype=None):
 # ---------------------------------------------------------------------------
 # RIFF/WAVE codec
 # ---------------------------------------------------------------------------
-def read_wav(path):
-    """(frames, channels) float64 in [-1, 1) and the sample rate."""
+def _wav_layout(path):
+    """Header walk of a RIFF/WAVE file: (format code, channels, rate, block size, bits, data offset, data bytes)."""
     with open(path, "rb") as fh:
-        blob = fh.read()
-    if len(blob) < 12 or blob[:4] != b"RIFF" or blob[8:12] != b"WAVE":
-        raise RuntimeError("Format not recognised: not a RIFF/WAVE file")
-    fmt, data, pos = None, None, 12
-    while pos + 8 <= len(blob):
-        tag, size = blob[pos:pos + 4], struct.unpack("<I", blob[pos + 4:pos + 8])[0]
-        body = blob[pos + 8:pos + 8 + size]
-        if tag == b"fmt ":
-            fmt = body
-        elif tag == b"data":
-            data = body
-            if fmt is not None:
+        head = fh.read(12)
+        if len(head) < 12 or head[:4] != b"RIFF" or head[8:12] != b"WAVE":
+            raise RuntimeError("Format not recognised: not a RIFF/WAVE file")
+        size_of_file = os.fstat(fh.fileno()).st_size
+        fmt, pos = None, 12
+        while pos + 8 <= size_of_file:
+            fh.seek(pos)
+            tag_size = fh.read(8)
+            if len(tag_size) < 8:
                 break
-        pos += 8 + size + (size & 1)
-    if fmt is None or data is None or len(fmt) < 16:
-        raise RuntimeError("Format not recognised: missing fmt or data chunk")
-    code, channels, rate, _, block, bits = struct.unpack("<HHIIHH", fmt[:16])
-    if code == _EXTENSIBLE and len(fmt) >= 26:
-        code = struct.unpack("<H", fmt[24:26])[0]           # first two bytes of the sub-format GUID
-    if channels < 1 or block < 1:
-        raise RuntimeError("Format not recognised: bad channel count")
-    frames = len(data) // block
-    raw = np.frombuffer(data, dtype=np.uint8, count=frames * block)
+            tag, size = tag_size[:4], struct.unpack("<I", tag_size[4:])[0]
+            if tag == b"fmt ":
+                fmt = fh.read(size)
+            elif tag == b"data":
+                if fmt is None:                 # a data chunk ahead of fmt: keep looking for fmt, come back
+                    data_at, data_size = pos + 8, size
+                    pos += 8 + size + (size & 1)
+                    while pos + 8 <= size_of_file and fmt is None:
+                        fh.seek(pos)
+                        t2 = fh.read(8)
+                        tag2, size2 = t2[:4], struct.unpack("<I", t2[4:])[0]
+                        if tag2 == b"fmt ":
+                            fmt = fh.read(size2)
+                        pos += 8 + size2 + (size2 & 1)
+                    pos, size = data_at - 8, data_size
+                if fmt is None or len(fmt) < 16:
+                    break
+                code, channels, rate, _, block, bits = struct.unpack("<HHIIHH", fmt[:16])
+                if code == _EXTENSIBLE and len(fmt) >= 26:
+                    code = struct.unpack("<H", fmt[24:26])[0]       # first two bytes of the sub-format GUID
+                if channels < 1 or block < 1:
+                    raise RuntimeError("Format not recognised: bad channel count")
+                return code, channels, int(rate), block, bits, pos + 8, min(size, size_of_file - pos - 8)
+            pos += 8 + size + (size & 1)
+    raise RuntimeError("Format not recognised: missing fmt or data chunk")
+
+
+def pcm_to_float(array, dtype=np.float32):
+    """Integer PCM as ``load(..., pcm=True)`` returns it -> floats in [-1, 1): ``v / 2**(bits-1)``, exact
+    in float32 up to 24 bits.  Float arrays pass through."""
+    dtype = np.dtype(dtype).type
+    if array.dtype == np.int16:
+        out = array.astype(dtype)
+        out *= dtype(1.0 / 32768.0)
+        return out
+    if array.dtype == np.int32:
+        return (array.astype(np.float64) * (1.0 / 2147483648.0)).astype(dtype)
+    if array.dtype == np.uint8:                            # packed little-endian 24-bit
+        frames = array.shape[0]
+        b = array.reshape(-1, 3)
+        v = b[:, 0].astype(np.int32)
+        v |= b[:, 1].astype(np.int32) << 8
+        v |= b[:, 2].astype(np.int8).astype(np.int32) << 16            # the top byte carries the sign
+        out = v.astype(dtype)
+        out *= dtype(1.0 / 8388608.0)
+        return out.reshape(frames, -1)
+    return array
+
+
+def read_wav(path, pcm=False):
+    """(frames, channels) samples and the sample rate.  Floats in [-1, 1): float32 for integer files up to
+    24 bits (exact), float64 for 32-bit integer and for DOUBLE files, float32 for FLOAT files.  With
+    ``pcm=True`` files of 16 or 32-bit integers come back undecoded (module docstring)."""
+    code, channels, rate, block, bits, offset, nbytes = _wav_layout(path)
+    frames = nbytes // block
+    raw = np.fromfile(path, dtype=np.uint8, count=frames * block, offset=offset)
     if code == _FLOAT and bits in (32, 64):
-        out = raw.view("<f4" if bits == 32 else "<f8").astype(np.float64)
+        out = raw.view("<f4" if bits == 32 else "<f8")
     elif code == _PCM and bits == 8:
-        out = (raw.astype(np.float64) - 128.0) / 128.0
-    elif code == _PCM and bits in (16, 32):
-        out = raw.view("<i2" if bits == 16 else "<i4").astype(np.float64) / float(1 << (bits - 1))
+        out = (raw.astype(np.float32) - 128.0) / 128.0
+    elif code == _PCM and bits == 16:
+        out = raw.view("<i2").reshape(frames, channels)
+        if not pcm:
+            out = pcm_to_float(out)
+    elif code == _PCM and bits == 32:
+        out = raw.view("<i4").reshape(frames, channels)
+        if not pcm:
+            out = pcm_to_float(out, np.float64)
     elif code == _PCM and bits == 24:
-        b = raw.reshape(-1, 3).astype(np.int32)
-        v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
-        v = np.where(v & 0x800000, v - (1 << 24), v)
-        out = v.astype(np.float64) / float(1 << 23)
+        out = pcm_to_float(raw.reshape(frames, channels * 3))       # (decoded here: three-byte samples do not
+                                                                    # lend themselves to the checks in between)
     else:
         raise RuntimeError(f"Format not recognised: WAVE format tag {code} with {bits} bits")
-    return out.reshape(frames, channels), int(rate)
+    return out.reshape(frames, -1) if out.dtype == np.uint8 else out.reshape(frames, channels), rate
+
+
+def _quantise(array, bits):
+    """rint(x * (2**(bits-1) - 1)) clipped to the integer range, in float64 blocks (bounded temporaries)."""
+    top = float((1 << (bits - 1)) - 1)
+    flat = np.ascontiguousarray(array).reshape(-1)
+    out = np.empty(flat.shape[0], dtype=np.int16 if bits <= 16 else np.int32)
+    step = 1 << 20
+    for i in range(0, flat.shape[0], step):
+        q = flat[i:i + step].astype(np.float64)
+        q *= top
+        np.rint(q, out=q)
+        np.clip(q, -top - 1.0, top, out=q)
+        out[i:i + step] = q
+    return out
+
+
+def _pack24(q, big_endian=False):
+    """int32 samples -> packed 3-byte samples (uint8, three per sample)."""
+    b = np.empty((q.shape[0], 3), dtype=np.uint8)
+    lo, mid, hi = (q & 0xFF), ((q >> 8) & 0xFF), ((q >> 16) & 0xFF)
+    if big_endian:
+        b[:, 0], b[:, 1], b[:, 2] = hi, mid, lo
+    else:
+        b[:, 0], b[:, 1], b[:, 2] = lo, mid, hi
+    return b
+
+
+def _pcm_matches(array, bits):
+    return (bits == 16 and array.dtype == np.int16) or (bits == 32 and array.dtype == np.int32) or \
+           (bits == 24 and array.dtype == np.uint8)
 
 
 def write_wav(path, array, sample_rate, subtype):
-    array = np.asarray(array, dtype=np.float64)
+    """``array``: floats (n, channels), or integer PCM already quantised for this ``subtype`` (int16 for
+    PCM_16, int32 for PCM_32, uint8 (n, channels * 3) for PCM_24: what the device encoder hands back)."""
+    array = np.asarray(array)
     if array.ndim == 1:
         array = array[:, None]
-    frames, channels = array.shape
+    frames = array.shape[0]
     if subtype in ("FLOAT", "DOUBLE"):
         code, bits = _FLOAT, 32 if subtype == "FLOAT" else 64
-        payload = array.astype("<f4" if bits == 32 else "<f8").tobytes()
+        channels = array.shape[1]
+        payload = np.ascontiguousarray(array, dtype="<f4" if bits == 32 else "<f8")
     elif subtype == "PCM_U8":
-        code, bits = _PCM, 8
-        payload = np.clip(np.rint(array * 127.0) + 128.0, 0, 255).astype(np.uint8).tobytes()
+        code, bits, channels = _PCM, 8, array.shape[1]
+        payload = np.clip(np.rint(array.astype(np.float64) * 127.0) + 128.0, 0, 255).astype(np.uint8)
     elif subtype in ("PCM_16", "PCM_24", "PCM_32"):
         code, bits = _PCM, int(subtype[4:])
-        top = float((1 << (bits - 1)) - 1)
-        q = np.clip(np.rint(array * top), -top - 1.0, top).astype(np.int64)
-        if bits == 24:
-            u = (q & 0xFFFFFF).astype(np.uint32).reshape(-1)
-            b = np.empty((u.size, 3), dtype=np.uint8)
-            b[:, 0], b[:, 1], b[:, 2] = u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF
-            payload = b.tobytes()
+        if _pcm_matches(array, bits):
+            channels = array.shape[1] // 3 if bits == 24 else array.shape[1]
+            payload = np.ascontiguousarray(array)
+        elif array.dtype.kind in "iu":
+            raise TypeError(f"integer samples of type {array.dtype} cannot be written as {subtype}")
         else:
-            payload = q.astype("<i2" if bits == 16 else "<i4").tobytes()
+            channels = array.shape[1]
+            q = _quantise(array, bits)
+            payload = _pack24(q) if bits == 24 else q.astype("<i2" if bits == 16 else "<i4", copy=False)
     else:
         raise TypeError(f"WAV format does not have {subtype} subtype")
     block = channels * bits // 8
+    size = frames * block
     fmt = struct.pack("<HHIIHH", code, channels, int(sample_rate), int(sample_rate) * block, block, bits)
-    chunks = b"fmt " + struct.pack("<I", len(fmt)) + fmt
+    head = b"fmt " + struct.pack("<I", len(fmt)) + fmt
     if code == _FLOAT:
-        chunks += b"fact" + struct.pack("<II", 4, frames)
-    chunks += b"data" + struct.pack("<I", len(payload)) + payload + (b"\x00" if len(payload) & 1 else b"")
+        head += b"fact" + struct.pack("<II", 4, frames)
+    head += b"data" + struct.pack("<I", size)
+    pad = size & 1
     with open(path, "wb") as fh:
-        fh.write(b"RIFF" + struct.pack("<I", 4 + len(chunks)) + b"WAVE" + chunks)
+        fh.write(b"RIFF" + struct.pack("<I", 4 + len(head) + size + pad) + b"WAVE" + head)
+        fh.write(memoryview(payload).cast("B"))
+        if pad:
+            fh.write(b"\x00")
 
 
 # ---------------------------------------------------------------------------
@@ -199,7 +291,7 @@ def read_aiff(path):
 
 
 def write_aiff(path, array, sample_rate, subtype):
-    array = np.asarray(array, dtype=np.float64)
+    array = pcm_to_float(np.asarray(array), np.float64)          # (integer PCM is little-endian: decode, re-encode)
     if array.ndim == 1:
         array = array[:, None]
     frames, channels = array.shape
@@ -209,13 +301,9 @@ def write_aiff(path, array, sample_rate, subtype):
         coding = (b"fl32", b"32-bit floating point") if bits == 32 else (b"fl64", b"64-bit floating point")
     elif subtype in ("PCM_S8", "PCM_16", "PCM_24", "PCM_32"):
         bits = 8 if subtype == "PCM_S8" else int(subtype[4:])
-        top = float((1 << (bits - 1)) - 1)
-        q = np.clip(np.rint(array * top), -top - 1.0, top).astype(np.int64)
+        q = _quantise(array, bits)
         if bits == 24:
-            u = (q & 0xFFFFFF).astype(np.uint32).reshape(-1)
-            b = np.empty((u.size, 3), dtype=np.uint8)
-            b[:, 0], b[:, 1], b[:, 2] = (u >> 16) & 0xFF, (u >> 8) & 0xFF, u & 0xFF
-            payload = b.tobytes()
+            payload = _pack24(q, big_endian=True).tobytes()
         else:
             payload = q.astype({8: "i1", 16: ">i2", 32: ">i4"}[bits]).tobytes()
         coding = None
@@ -236,27 +324,30 @@ def write_aiff(path, array, sample_rate, subtype):
         fh.write(b"FORM" + struct.pack(">I", 4 + len(chunks)) + form + chunks)
 
 
-def _read(path):
-    if _sf is not None:
-        return _sf.read(path, always_2d=True)
+def _read(path, pcm=False):
     with open(path, "rb") as fh:
         magic = fh.read(12)
+    if magic[:4] == b"RIFF" and magic[8:12] == b"WAVE" and (pcm or _sf is None):
+        return read_wav(path, pcm)
+    if _sf is not None:
+        return _sf.read(path, always_2d=True)
     if magic[:4] == b"FORM" and magic[8:12] in (b"AIFF", b"AIFC"):
         return read_aiff(path)
-    return read_wav(path)
+    return read_wav(path, pcm)
 
 
 # ---------------------------------------------------------------------------
 # matchering.loader.load / matchering.saver.save
 # ---------------------------------------------------------------------------
-def load(file: str, file_type: str, temp_folder: str):
-    """loader.py:30-47: returns ``(sound (n, channels) float64, sample_rate)``; raises
-    ``ModuleError(4001 | 4101)`` when the file cannot be decoded (after trying ffmpeg)."""
+def load(file: str, file_type: str, temp_folder: str, pcm: bool = False):
+    """loader.py:30-47: returns ``(sound (n, channels) floats, sample_rate)``; raises
+    ``ModuleError(4001 | 4101)`` when the file cannot be decoded (after trying ffmpeg).  ``pcm=True``
+    (what ``process`` passes) leaves WAVE files of 16 or 32-bit integers undecoded (module docstring)."""
     file_type = file_type.upper()
     sound, sample_rate = None, None
     debug(f"reading {file_type} from '{file}'")
     try:
-        sound, sample_rate = _read(file)
+        sound, sample_rate = _read(file, pcm)
     except (RuntimeError, OSError) as e:
         debug(e)
         if "unknown format" in str(e) or "Format not recognised" in str(e):
@@ -291,9 +382,12 @@ def _load_with_ffmpeg(file, file_type, temp_folder):
 def save(file: str, result: np.ndarray, sample_rate: int, subtype: str, name: str = "result") -> None:
     """saver.py:27-33."""
     debug(f"writing the {name} as {subtype} at {sample_rate} Hz to '{file}'")
-    if _sf is not None:
-        _sf.write(file, result, sample_rate, subtype)
-    elif os.path.splitext(file)[1][1:].upper() in ("AIFF", "AIF", "AIFC"):
+    extension = os.path.splitext(file)[1][1:].upper()
+    if np.asarray(result).dtype.kind in "iu" and extension in ("WAV", "WAVE"):
+        write_wav(file, result, sample_rate, subtype)              # quantised on the GPU already
+    elif _sf is not None:
+        _sf.write(file, pcm_to_float(np.asarray(result), np.float64), sample_rate, subtype)
+    elif extension in ("AIFF", "AIF", "AIFC"):
         write_aiff(file, result, sample_rate, subtype)
     else:
         write_wav(file, result, sample_rate, subtype)

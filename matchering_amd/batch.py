@@ -115,14 +115,17 @@ def lane_device(device_index, lane):
         return _lane_devices[key]
 
 
-def _device_worker(device_index, lane, config, needs, master):
-    """A callable mastering one (target, reference) array pair on the lane's own device handle."""
+def _device_worker(device_index, lane, config, needs, master, encodings=None):
+    """A callable mastering one (target, reference) array pair on the lane's own device handle.
+    ``encodings``: stages.main's (integer PCM renderings straight from the GPU)."""
     if master is not None:                         # tests inject a stand-in for the GPU
-        return lambda pair: master(pair[0], pair[1], config, *needs)
+        if encodings is None or not any(encodings):
+            return lambda pair: master(pair[0], pair[1], config, *needs)
+        return lambda pair: master(pair[0], pair[1], config, *needs, encodings=encodings)
     from .stages import main
 
     dev = lane_device(device_index, lane)
-    return lambda pair: main(pair[0], pair[1], config, *needs, device=dev)
+    return lambda pair: main(pair[0], pair[1], config, *needs, device=dev, encodings=encodings)
 
 
 def master_many(pairs, config=None, need_default=True, need_no_limiter=False,
@@ -194,6 +197,12 @@ def master_album(targets, reference, config=None, rank=None, world_size=None, de
     return results
 
 
+def _wanted_encodings(results):
+    from .core import _wanted_encodings as of_results
+
+    return of_results(results)
+
+
 def _needs_of(results):
     return (any(r.use_limiter for r in results),
             any(not r.use_limiter and not r.normalize for r in results),
@@ -207,9 +216,10 @@ def _load_job(job, config):
     from .utils import get_temp_folder
 
     temp_folder = config.temp_folder if config.temp_folder else get_temp_folder(job["results"])
-    target, rate_t = load(job["target"], "target", temp_folder)
+    # (pcm=True: 16/32-bit WAVE samples stay integers up to the GPU, as in core.process)
+    target, rate_t = load(job["target"], "target", temp_folder, pcm=True)
     target, rate_t = check(target, rate_t, config, "target")
-    reference, rate_r = load(job["reference"], "reference", temp_folder)
+    reference, rate_r = load(job["reference"], "reference", temp_folder, pcm=True)
     reference, rate_r = check(reference, rate_r, config, "reference")
     if not config.allow_equality:
         check_equality(target, reference)
@@ -252,9 +262,10 @@ def process_batch(jobs, config=None, rank=None, world_size=None, device_index=No
             def run(item):
                 index, arrays = item
                 needs = _needs_of(jobs[index]["results"])
-                if needs not in workers:
-                    workers[needs] = _device_worker(device_index, lane, config, needs, master)
-                return workers[needs](arrays)
+                key = (needs, _wanted_encodings(jobs[index]["results"]))
+                if key not in workers:
+                    workers[key] = _device_worker(device_index, lane, config, needs, master, key[1])
+                return workers[key](arrays)
             return run
 
         pool = _Lanes(worker_for, max(1, lanes))

@@ -6,7 +6,7 @@ around the one call that runs on the GPU.
           --_write_results--> files (+ optional previews)
 """
 
-from .audio_io import load, save
+from .audio_io import load, pcm_to_float, save
 from .checker import check, check_equality
 from .config import Config
 from .log import Code, ModuleError, debug, debug_line, info
@@ -29,11 +29,26 @@ def _wanted_renderings(results):
     return limited, plain, normalized
 
 
+def _wanted_encodings(results):
+    """Per rendering, the PCM subtype the GPU can quantise to directly: every file made from that rendering
+    is a WAVE file of one and the same integer subtype (saver.py:27-33 would quantise on the host)."""
+    import os
+
+    from .stages import PCM_BITS
+
+    wanted = [set(), set(), set()]
+    for item in results:
+        slot = 0 if item.use_limiter else (2 if item.normalize else 1)
+        wave = os.path.splitext(item.file)[1][1:].upper() in ("WAV", "WAVE")
+        wanted[slot].add(item.subtype if wave and item.subtype in PCM_BITS else None)
+    return tuple(next(iter(w)) if len(w) == 1 else None for w in wanted)
+
+
 def _read_pair(target_path, reference_path, config, temp_folder):
     """Load and check both tracks (core.py:52-74); raises ModuleError with the reference's codes."""
     tracks = []
     for path, role in ((target_path, "target"), (reference_path, "reference")):
-        audio, rate = load(path, role, temp_folder)
+        audio, rate = load(path, role, temp_folder, pcm=True)     # 16/32-bit WAVE: decoded on the GPU
         tracks.append(check(audio, rate, config, role))
     (target, target_rate), (reference, reference_rate) = tracks
     if not config.allow_equality:
@@ -67,16 +82,20 @@ def process(target: str, reference: str, results: list, config: Config = None,
     temp_folder = config.temp_folder or get_temp_folder(results)
 
     target_audio, reference_audio = _read_pair(target, reference, config, temp_folder)
-    renderings = main(target_audio, reference_audio, config, *_wanted_renderings(results))
+    previews = bool(preview_target or preview_result)
+    # (previews are cut from float frames: with them the renderings stay float and the files are quantised
+    # on the host)
+    encodings = None if previews else _wanted_encodings(results)
+    renderings = main(target_audio, reference_audio, config, *_wanted_renderings(results), encodings=encodings)
     del reference_audio
 
     debug_line()
     info(Code.INFO_EXPORTING)
     _write_results(results, renderings, config.internal_sample_rate)
 
-    if preview_target or preview_result:
+    if previews:
         mastered = next(audio for audio in renderings if audio is not None)
-        create_preview(target_audio, mastered, config, preview_target, preview_result)
+        create_preview(pcm_to_float(target_audio), mastered, config, preview_target, preview_result)
 
     debug_line()
     info(Code.INFO_COMPLETED)

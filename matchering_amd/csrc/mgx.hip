@@ -974,6 +974,28 @@ int mgx_scale(mgx_handle* h, const float* x_dev, int64_t n, double gain, float* 
     return 0;
 }
 
+int mgx_pcm_decode(mgx_handle* h, const void* pcm_dev, int64_t samples, int32_t bits, float* out_dev) {
+    if (!h || !pcm_dev || !out_dev) return fail(MGX_ERR_ARGUMENT, "null argument");
+    if (bits != 16 && bits != 24 && bits != 32) return fail(MGX_ERR_ARGUMENT, "PCM width must be 16, 24 or 32 bits");
+    if (samples <= 0) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    const unsigned grid = (unsigned)std::min<long long>((samples / 4 + 255) / 256 + 1, 8192);
+    hipLaunchKernelGGL(k_pcm_decode, dim3(grid), dim3(256), 0, h->stream, pcm_dev, (long long)samples, bits, out_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mgx_pcm_encode(mgx_handle* h, const float* x_dev, int64_t samples, int32_t bits, void* pcm_dev) {
+    if (!h || !pcm_dev || !x_dev) return fail(MGX_ERR_ARGUMENT, "null argument");
+    if (bits != 16 && bits != 24 && bits != 32) return fail(MGX_ERR_ARGUMENT, "PCM width must be 16, 24 or 32 bits");
+    if (samples <= 0) return 0;
+    HIP_TRY(hipSetDevice(h->device));
+    const unsigned grid = (unsigned)std::min<long long>((samples / 4 + 255) / 256 + 1, 8192);
+    hipLaunchKernelGGL(k_pcm_encode, dim3(grid), dim3(256), 0, h->stream, x_dev, (long long)samples, bits, pcm_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ---- the boundary: stages.main ----------------------------------------------
 } // extern "C"
 static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target, const float* reference_dev,

@@ -1707,6 +1707,93 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     DEV_MARK(10);     // store
 }
 
+// ---- PCM at the boundary (loader.py:35 / saver.py:27-33: what soundfile does on the host) ------------
+// Files hold integer samples; moving those over PCIe instead of float32 halves (16 bit) the bytes either
+// way.  Scaling follows libsndfile: read x = v / 2^(bits-1) (exact in float32 up to 24 bits), write
+// v = rint(x * (2^(bits-1) - 1)) clipped to the integer range, computed in float64 so that the result is
+// the one the host codec (audio_io.write_wav) produces from the same float32 sample.  24-bit samples are
+// packed little-endian, three bytes each: a thread moves four of them as three 32-bit words.
+__global__ __launch_bounds__(256) void k_pcm_decode(const void* pcm, long long samples, int bits, float* out) {
+    const long long stride = (long long)gridDim.x * 256;
+    if (bits == 16) {
+        const short* in = static_cast<const short*>(pcm);
+        for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < samples; i += stride * 4) {
+            if (i + 4 <= samples) {
+                const short4 v = *reinterpret_cast<const short4*>(in + i);
+                *reinterpret_cast<float4*>(out + i) = make_float4(v.x * (1.f / 32768.f), v.y * (1.f / 32768.f),
+                                                                  v.z * (1.f / 32768.f), v.w * (1.f / 32768.f));
+            } else {
+                for (long long k = i; k < samples; ++k) out[k] = in[k] * (1.f / 32768.f);
+            }
+        }
+    } else if (bits == 32) {
+        const int* in = static_cast<const int*>(pcm);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < samples; i += stride)
+            out[i] = (float)((double)in[i] * (1.0 / 2147483648.0));
+    } else {                                     // 24 bits packed: samples 4q .. 4q+3 = bytes 12q .. 12q+11
+        const unsigned* in = static_cast<const unsigned*>(pcm);
+        const unsigned char* bytes = static_cast<const unsigned char*>(pcm);
+        const long long quads = samples / 4;
+        for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += stride) {
+            const unsigned w0 = in[3 * q], w1 = in[3 * q + 1], w2 = in[3 * q + 2];
+            const int v0 = (int)(w0 << 8) >> 8;
+            const int v1 = (int)(((w0 >> 24) | (w1 << 8)) << 8) >> 8;
+            const int v2 = (int)(((w1 >> 16) | (w2 << 16)) << 8) >> 8;
+            const int v3 = (int)w2 >> 8;
+            *reinterpret_cast<float4*>(out + 4 * q) = make_float4(v0 * (1.f / 8388608.f), v1 * (1.f / 8388608.f),
+                                                                  v2 * (1.f / 8388608.f), v3 * (1.f / 8388608.f));
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (int)(samples - 4 * quads)) {
+            const long long k = 4 * quads + threadIdx.x;
+            const int v = (int)(((unsigned)bytes[3 * k] | ((unsigned)bytes[3 * k + 1] << 8) | ((unsigned)bytes[3 * k + 2] << 16)) << 8) >> 8;
+            out[k] = v * (1.f / 8388608.f);
+        }
+    }
+}
+__device__ __forceinline__ int pcm_quantise(float x, double top) {
+    const double q = rint((double)x * top);
+    return (int)fmin(fmax(q, -top - 1.0), top);
+}
+__global__ __launch_bounds__(256) void k_pcm_encode(const float* x, long long samples, int bits, void* pcm) {
+    const long long stride = (long long)gridDim.x * 256;
+    const double top = (double)((1ll << (bits - 1)) - 1);
+    if (bits == 16) {
+        short* out = static_cast<short*>(pcm);
+        for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < samples; i += stride * 4) {
+            if (i + 4 <= samples) {
+                const float4 v = *reinterpret_cast<const float4*>(x + i);
+                short4 o;
+                o.x = (short)pcm_quantise(v.x, top); o.y = (short)pcm_quantise(v.y, top);
+                o.z = (short)pcm_quantise(v.z, top); o.w = (short)pcm_quantise(v.w, top);
+                *reinterpret_cast<short4*>(out + i) = o;
+            } else {
+                for (long long k = i; k < samples; ++k) out[k] = (short)pcm_quantise(x[k], top);
+            }
+        }
+    } else if (bits == 32) {
+        int* out = static_cast<int*>(pcm);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < samples; i += stride)
+            out[i] = pcm_quantise(x[i], top);
+    } else {
+        unsigned* out = static_cast<unsigned*>(pcm);
+        unsigned char* bytes = static_cast<unsigned char*>(pcm);
+        const long long quads = samples / 4;
+        for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < quads; q += stride) {
+            const float4 v = *reinterpret_cast<const float4*>(x + 4 * q);
+            const unsigned a = (unsigned)pcm_quantise(v.x, top) & 0xFFFFFFu, b = (unsigned)pcm_quantise(v.y, top) & 0xFFFFFFu;
+            const unsigned c = (unsigned)pcm_quantise(v.z, top) & 0xFFFFFFu, d = (unsigned)pcm_quantise(v.w, top) & 0xFFFFFFu;
+            out[3 * q] = a | (b << 24);
+            out[3 * q + 1] = (b >> 8) | (c << 16);
+            out[3 * q + 2] = (c >> 16) | (d << 8);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (int)(samples - 4 * quads)) {
+            const long long k = 4 * quads + threadIdx.x;
+            const unsigned v = (unsigned)pcm_quantise(x[k], top);
+            bytes[3 * k] = (unsigned char)v; bytes[3 * k + 1] = (unsigned char)(v >> 8); bytes[3 * k + 2] = (unsigned char)(v >> 16);
+        }
+    }
+}
+
 // One chunk with hold / release filters of order up to K (limiter_general.h): the load, window, attack and
 // store phases of the first-order kernel; the two low-passes as K-state maps scanned through LDS.
 template <int K>

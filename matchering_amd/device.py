@@ -86,6 +86,17 @@ def _size_class(nbytes):
     return size if size <= (1 << 24) else -(-nbytes // (1 << 24)) * (1 << 24)
 
 
+def pcm_bits(array):
+    """Width of the integer PCM samples an array holds (16, 24, 32), 0 for a float array."""
+    if array.dtype == np.int16:
+        return 16
+    if array.dtype == np.int32:
+        return 32
+    if array.dtype == np.uint8:
+        return 24
+    return 0
+
+
 class DeviceBuffer:
     """An HBM allocation owned by a Device.  ``release`` (or garbage collection) hands the block back to
     the device's free list -- hipMalloc / hipFree of a 170 MB block cost milliseconds and hipFree waits
@@ -171,8 +182,8 @@ class Device:
         ``pinned.empty`` go by DMA straight from where they are; any other array is moved into a
         pinned block by four host threads, chunk by chunk, each chunk's DMA queued as it lands (about
         twice the rate of a pageable hipMemcpy).  The source must not be written before ``synchronize``
-        or the next blocking call on this device."""
-        host = np.ascontiguousarray(array, dtype=dtype)
+        or the next blocking call on this device.  ``dtype=None`` keeps the array's own type."""
+        host = np.ascontiguousarray(array) if dtype is None else np.ascontiguousarray(array, dtype=dtype)
         buf = DeviceBuffer(self, max(host.nbytes, 1))
         if host.nbytes == 0:
             return buf
@@ -201,6 +212,37 @@ class Device:
         if out.nbytes:
             check(library().mgx_memcpy_d2h_async(self.handle, out.ctypes.data_as(ctypes.c_void_p),
                                                  ctypes.c_void_p(ptr), out.nbytes))
+        if wait:
+            self.synchronize()
+        return out
+
+    # ---- integer PCM at the boundary (mgx_pcm_decode / mgx_pcm_encode) ---------------------------
+    def upload_frames(self, array):
+        """(n, channels) audio -> float32 frames in HBM.  Float arrays are uploaded as float32; integer
+        arrays are what a PCM file holds (``audio_io.PCM_DTYPES``: int16, int32 with the sample in the high
+        bits, or uint8 (n, channels * 3) of packed 24-bit samples): they cross PCIe as they are and become
+        ``v / 2**(bits - 1)`` on the device."""
+        bits = pcm_bits(array)
+        if bits == 0:
+            return self.upload(array)
+        raw = self.upload(array, dtype=None)
+        samples = array.size // 3 if bits == 24 else array.size
+        out = DeviceBuffer(self, max(samples * 4, 1))
+        check(library().mgx_pcm_decode(self.handle, ctypes.c_void_p(raw.ptr), samples, bits, ctypes.c_void_p(out.ptr)))
+        raw.release()           # (recycled by later work on this stream only, which is ordered behind the decode)
+        return out
+
+    def download_pcm(self, buf, frames, channels, bits, wait=True):
+        """float32 frames in HBM -> integer PCM on the host (pinned): int16 / int32 (n, channels), or uint8
+        (n, channels * 3) for packed 24-bit.  Quantised on the device as libsndfile would on the host."""
+        samples = frames * channels
+        nbytes = samples * bits // 8
+        pcm = DeviceBuffer(self, max(nbytes, 1))
+        check(library().mgx_pcm_encode(self.handle, ctypes.c_void_p(buf.ptr), samples, bits, ctypes.c_void_p(pcm.ptr)))
+        shape, dtype = {16: ((frames, channels), np.int16), 32: ((frames, channels), np.int32),
+                        24: ((frames, channels * 3), np.uint8)}[bits]
+        out = self.download(pcm, shape, dtype, wait=False)
+        pcm.release()
         if wait:
             self.synchronize()
         return out

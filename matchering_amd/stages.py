@@ -18,18 +18,29 @@ from .log import Code, debug, debug_line, info
 from .utils import to_db
 
 
+PCM_BITS = {"PCM_16": 16, "PCM_24": 24, "PCM_32": 32}
+
+
 def _as_frames(array, name):
+    """(n, 2) frames as they will cross PCIe: float32, or the integer PCM of a file as it is (int16 / int32,
+    audio_io): those are decoded on the device."""
     array = np.asarray(array)
     if array.ndim != 2 or array.shape[1] != 2:
         raise ValueError(f"{name} must have shape (n, 2), got {array.shape}")
+    if array.dtype in (np.int16, np.int32):
+        return np.ascontiguousarray(array)
     return np.ascontiguousarray(array, dtype=np.float32)
 
 
 def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default: bool = True,
-         need_no_limiter: bool = False, need_no_limiter_normalized: bool = False, device=None, fir=None):
+         need_no_limiter: bool = False, need_no_limiter_normalized: bool = False, device=None, fir=None,
+         encodings=None):
     # (``device``: the handle to run on, default the process-wide one; ``fir``: a DeviceBuffer with a
-    # matching FIR to apply instead of designing one -- batch.master_album.  Both are additions to the
-    # reference's signature, keyword-only in spirit.)
+    # matching FIR to apply instead of designing one -- batch.master_album; ``encodings``: per output,
+    # None for float32 frames or "PCM_16" / "PCM_24" / "PCM_32" for the integer samples a file of that
+    # subtype holds, quantised on the device (saver.py:27-33 does it on the host) -- int16 / int32 (n, 2),
+    # or uint8 (n, 6) for packed 24-bit.  All additions to the reference's signature, keyword-only in
+    # spirit.  ``target`` / ``reference`` may be int16 or int32 PCM as read from a file.)
     dev = device if device is not None else default_device()
     target = _as_frames(target, "target")
     reference = _as_frames(reference, "reference")
@@ -41,8 +52,8 @@ def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default
     debug(f"analysis pieces: at most {config.max_piece_size} frames "
           f"({config.max_piece_size / config.internal_sample_rate:.2f} s) each")
     with dev.lock:
-        t_dev = dev.upload(target)
-        r_dev = dev.upload(reference)
+        t_dev = dev.upload_frames(target)
+        r_dev = dev.upload_frames(reference)
         outs = [dev.alloc(n * 8) if need else None
                 for need in (need_default, need_no_limiter, need_no_limiter_normalized)]
         try:
@@ -67,7 +78,11 @@ def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default
             if need_default and not report.limiter_active:
                 debug("the result stays under the threshold: the limiter passes it through")
             # queued one behind the other, then ONE wait; the arrays live in pinned host memory
-            results = tuple(dev.download(b, (n, 2), wait=False) if b is not None else None for b in outs)
+            formats = encodings if encodings is not None else (None, None, None)
+            results = tuple(None if b is None
+                            else dev.download(b, (n, 2), wait=False) if fmt is None
+                            else dev.download_pcm(b, n, 2, PCM_BITS[fmt], wait=False)
+                            for b, fmt in zip(outs, formats))
             dev.synchronize()
         finally:
             for b in (t_dev, r_dev, *outs):

@@ -544,3 +544,51 @@ def test_master_with_lowess_robustness_iterations(it):
         want = mo.master(target, reference, mo.params(max_piece_size=2.0, fft_size=2048, lowess_it=passes), True, True, False)
         for mine, ref in zip(got[:2], want[:2]):
             assert rms_error(mine, ref) <= RMS_TOL, (passes, rms_error(mine, ref))
+
+
+def test_pcm_decode_and_encode_on_the_device_match_the_host_codec():
+    """mgx_pcm_decode / mgx_pcm_encode (loader.py:35, saver.py:27-33 on the GPU) against audio_io's numpy
+    codec, bit for bit: 16, 24 (packed) and 32-bit samples, lengths that leave every kind of tail, values
+    beyond full scale (clipped, not wrapped) and exactly on rounding ties."""
+    from matchering_amd import audio_io
+    from matchering_amd.device import default_device
+
+    dev = default_device()
+    rng = np.random.RandomState(8)
+    for frames in (1, 2, 3, 5, 1023, 100003):
+        x = (0.5 * rng.randn(frames, 2)).astype(np.float32)
+        x[rng.randint(frames), 0] = 1.7
+        x[rng.randint(frames), 1] = -2.5
+        x[0, 0] = np.float32(0.5 / 32767.0)                       # a tie at 16 bits: rint goes to even
+        for bits in (16, 24, 32):
+            q = audio_io._quantise(x, bits)
+            want = audio_io._pack24(q).reshape(frames, 6) if bits == 24 else q.reshape(frames, 2)
+            with dev.lock:
+                buf = dev.upload(x)
+                got = dev.download_pcm(buf, frames, 2, bits)
+                buf.release()
+            assert got.dtype == want.dtype and np.array_equal(got, want), (frames, bits)
+            if bits != 24:                                        # and back: what a file of these samples decodes to
+                with dev.lock:
+                    back = dev.upload_frames(want)
+                    floats = dev.download(back, (frames, 2))
+                    back.release()
+                assert np.array_equal(floats, audio_io.pcm_to_float(want, np.float32))
+
+
+def test_master_on_pcm_frames_equals_master_on_their_floats():
+    """stages.main fed int16 frames (a PCM_16 file as it is) and asked for PCM_16 / PCM_24 / float renderings:
+    bit-identical to the float path with the host codec around it."""
+    import matchering_amd as mg
+    from matchering_amd import audio_io, stages
+    from matchering_amd.synth import make_pair
+
+    t, r = make_pair(6.0, 44100, pair=6, reference_seconds=5.0)
+    ti = audio_io._quantise(0.6 * t, 16).reshape(t.shape)
+    ri = audio_io._quantise(0.8 * r, 16).reshape(r.shape)
+    cfg = mg.Config(max_piece_size=2.0)
+    plain = stages.main(audio_io.pcm_to_float(ti), audio_io.pcm_to_float(ri), cfg, True, True, True)
+    coded = stages.main(ti, ri, cfg, True, True, True, encodings=("PCM_16", "PCM_24", None))
+    assert coded[0].dtype == np.int16 and np.array_equal(coded[0], audio_io._quantise(plain[0], 16).reshape(-1, 2))
+    assert coded[1].dtype == np.uint8 and np.array_equal(coded[1], audio_io._pack24(audio_io._quantise(plain[1], 24)).reshape(-1, 6))
+    assert coded[2].dtype == np.float32 and np.array_equal(coded[2], plain[2])

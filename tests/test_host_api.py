@@ -264,8 +264,9 @@ def test_process_file_pipeline_on_cpu(tmp_path, monkeypatch):
     calls = {}
 
     def oracle_main(target, reference, config, need_default=True, need_no_limiter=False,
-                    need_no_limiter_normalized=False):
+                    need_no_limiter_normalized=False, encodings=None):
         calls["needs"] = (need_default, need_no_limiter, need_no_limiter_normalized)
+        assert encodings is None                       # previews were asked for: the renderings stay float
         ocfg = mo.params(max_piece_size=config.max_piece_size / config.internal_sample_rate)
         out = mo.master(np.asarray(target, dtype=np.float64), np.asarray(reference, dtype=np.float64), ocfg,
                         need_default, need_no_limiter, need_no_limiter_normalized)
@@ -327,6 +328,9 @@ def test_stages_main_host_glue_with_a_stand_in_device():
             self.buffers.append(b)
             return b
 
+        def upload_frames(self, array):
+            return self.upload(audio_io.pcm_to_float(np.asarray(array)))
+
         def alloc(self, nbytes):
             b = Buf(nbytes=nbytes)
             self.buffers.append(b)
@@ -376,3 +380,126 @@ def test_stages_main_host_glue_with_a_stand_in_device():
     assert "correction round 4" in text and "level match" in text and "scaled back" in text
     with pytest.raises(ValueError):
         stages.main(t[:, :1], r, mg.Config(), device=dev)
+
+
+def test_pcm_files_pass_through_undecoded(tmp_path):
+    """audio_io: ``load(..., pcm=True)`` hands 16- and 32-bit WAVE samples over as the file holds them (they
+    are decoded on the GPU, mgx_pcm_decode), ``pcm_to_float`` is the decoding the default path applies, and
+    ``save`` writes integer arrays that are already quantised for the subtype byte for byte as it writes
+    the floats they came from."""
+    rng = np.random.RandomState(4)
+    x = np.clip(0.4 * rng.randn(5003, 2), -1.2, 1.2).astype(np.float32)
+    for subtype, dtype in (("PCM_16", np.int16), ("PCM_32", np.int32), ("PCM_24", np.float32)):
+        path = str(tmp_path / f"{subtype}.wav")
+        audio_io.write_wav(path, x, 44100, subtype)
+        plain, rate = audio_io.load(path, "target", str(tmp_path))
+        raw, _ = audio_io.load(path, "target", str(tmp_path), pcm=True)
+        assert rate == 44100 and raw.dtype == dtype and raw.shape == x.shape
+        assert np.array_equal(audio_io.pcm_to_float(raw, plain.dtype), plain)
+        if subtype == "PCM_16":         # written at scale 32767, read at 32768 (libsndfile): up to 1.5 steps
+            assert np.abs(plain - np.clip(x, -1, 1)).max() <= 1.6 / (1 << 15)
+    # integer samples in, the same file out
+    for subtype, bits in (("PCM_16", 16), ("PCM_24", 24), ("PCM_32", 32)):
+        q = audio_io._quantise(x, bits)
+        ints = q.reshape(x.shape) if bits != 24 else audio_io._pack24(q).reshape(x.shape[0], 6)
+        a, b = str(tmp_path / f"a{bits}.wav"), str(tmp_path / f"b{bits}.wav")
+        audio_io.save(a, x, 44100, subtype)
+        audio_io.save(b, ints, 44100, subtype)
+        assert open(a, "rb").read() == open(b, "rb").read()
+    with pytest.raises(TypeError):
+        audio_io.write_wav(str(tmp_path / "bad.wav"), np.zeros((4, 2), np.int16), 44100, "PCM_24")
+
+
+def test_check_on_integer_pcm_matches_check_on_floats():
+    """checker.check / check_equality / count_max_peaks on int16 PCM (what process now feeds them) against
+    the same samples as floats: same peak, same count of samples on the peak (numpy.isclose semantics,
+    dsp.py:49-54), same warnings, same verdict on equality."""
+    from matchering_amd import checker
+    from matchering_amd.log import ModuleError
+
+    def reference_count(array):                     # dsp.py:49-54 verbatim semantics
+        m = np.abs(array).max()
+        return m, int(np.count_nonzero(np.isclose(array, m) | np.isclose(array, -m)))
+
+    rng = np.random.RandomState(2)
+    for trial in range(60):
+        n = int(rng.randint(50, 4000))
+        ints = (np.clip(0.6 * rng.randn(n, 2), -1, 1) * 32767).astype(np.int16)
+        if trial % 3 == 0:
+            ints[rng.randint(n, size=20), rng.randint(2, size=20)] = ints.max()     # a limited-looking track
+        floats = ints.astype(np.float64) / 32768.0
+        got, want = checker.count_max_peaks(ints), reference_count(floats)
+        assert got[1] == want[1] and abs(got[0] - want[0]) <= 1e-15
+        got32 = checker.count_max_peaks(floats.astype(np.float32))
+        assert got32[1] == reference_count(floats.astype(np.float32))[1]
+    cfg = mg.Config(fft_size=64)
+    seen = []
+    mg.log(warning_handler=lambda text: seen.append(("int", str(text))))
+    clipped = np.full((4000, 2), 32767, np.int16)
+    clipped[::2] = -32768
+    out, rate = checker.check(clipped[:, :1], 44100, cfg, "target")            # mono PCM: duplicated, stays PCM
+    assert out.dtype == np.int16 and out.shape == (4000, 2) and rate == 44100
+    mg.log(warning_handler=lambda text: seen.append(("float", str(text))))
+    checker.check(clipped[:, :1].astype(np.float64) / 32768.0, 44100, cfg, "target")
+    mg.log()
+    assert [t for k, t in seen if k == "int"] == [t for k, t in seen if k == "float"] != []
+    a = (1000 * rng.randn(300000, 2)).astype(np.int16)
+    with pytest.raises(ModuleError):
+        checker.check_equality(a, a.copy())
+    b = a.copy()
+    b[-1, 1] += 1
+    checker.check_equality(a, b)                                               # one count apart: not equal
+    checker.check_equality(a, a[:-1])
+
+
+def test_process_keeps_pcm_integer_end_to_end(tmp_path, monkeypatch):
+    """core.process on PCM_16 files without previews: the loader's int16 frames reach stages.main as they
+    are, the renderings are asked for in the Results' own integer subtype when every file made from one
+    rendering agrees on it, and those integers are what lands in the files."""
+    from matchering_amd import core
+    from matchering_amd.synth import make_pair
+
+    rate = 44100
+    t, r = make_pair(4.0, rate, pair=5, reference_seconds=3.0)
+    audio_io.write_wav(str(tmp_path / "t.wav"), 0.5 * t, rate, "PCM_16")
+    audio_io.write_wav(str(tmp_path / "r.wav"), 0.5 * r, rate, "PCM_16")
+    seen = {}
+
+    def fake_main(target, reference, config, need_default=True, need_no_limiter=False,
+                  need_no_limiter_normalized=False, encodings=None):
+        seen["dtypes"] = (target.dtype, reference.dtype)
+        seen["encodings"] = encodings
+        seen["needs"] = (need_default, need_no_limiter, need_no_limiter_normalized)
+        base = audio_io.pcm_to_float(target)
+        outs = []
+        for need, fmt, gain in zip(seen["needs"], encodings, (0.9, 1.1, 1.0)):
+            if not need:
+                outs.append(None)
+            elif fmt is None:
+                outs.append(base * gain)
+            else:
+                bits = int(fmt[4:])
+                q = audio_io._quantise(base * gain, bits)
+                outs.append(audio_io._pack24(q).reshape(-1, 6) if bits == 24 else q.reshape(base.shape))
+        seen["outs"] = outs
+        return tuple(outs)
+
+    monkeypatch.setattr(core, "main", fake_main)
+    mg.process(str(tmp_path / "t.wav"), str(tmp_path / "r.wav"),
+               [mg.pcm16(str(tmp_path / "a.wav")), mg.pcm16(str(tmp_path / "b.wav")),
+                mg.Result(str(tmp_path / "c.wav"), "PCM_24", use_limiter=False, normalize=False),
+                mg.Result(str(tmp_path / "d.aiff"), "PCM_16", use_limiter=False, normalize=False),
+                mg.Result(str(tmp_path / "e.wav"), "PCM_24", use_limiter=False)],
+               config=mg.Config(max_piece_size=2))
+    assert seen["dtypes"] == (np.int16, np.int16)
+    # limited: two PCM_16 WAVE files -> PCM_16; plain: a WAVE and an AIFF file -> float; normalised: PCM_24
+    assert seen["encodings"] == ("PCM_16", None, "PCM_24") and seen["needs"] == (True, True, True)
+    raw, _ = audio_io.read_wav(str(tmp_path / "a.wav"), pcm=True)
+    assert np.array_equal(raw, seen["outs"][0])
+    assert open(str(tmp_path / "a.wav"), "rb").read() == open(str(tmp_path / "b.wav"), "rb").read()
+    got, _ = audio_io.read_wav(str(tmp_path / "c.wav"))
+    assert np.abs(got - np.clip(seen["outs"][1], -1, 1)).max() <= 1.6 / (1 << 23)
+    got, _ = audio_io.read_aiff(str(tmp_path / "d.aiff"))
+    assert np.abs(got - np.clip(seen["outs"][1], -1, 1)).max() <= 1.6 / (1 << 15)
+    got, _ = audio_io.read_wav(str(tmp_path / "e.wav"))
+    assert np.array_equal(got, audio_io.pcm_to_float(seen["outs"][2]))
