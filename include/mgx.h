@@ -168,6 +168,10 @@ int mgx_scale(mgx_handle* h, const float* x_dev, int64_t n, double gain, float* 
  * sample, little-endian, packed) or 32 (int32).  Scaling as libsndfile: decode x = v / 2^(bits-1);
  * encode v = rint(x * (2^(bits-1) - 1)), clipped to the integer range, evaluated in float64.  Queued on
  * the handle's stream. */
+/* dsp.py:49-54 count_max_peaks on interleaved float32 samples in HBM: the largest magnitude and the number
+ * of samples numpy.isclose (rtol 1e-5, atol 1e-8) puts on it, either sign -- what checker.py:118-130 looks
+ * at to warn about clipped or already limited targets.  Waits for the result. */
+int mgx_peak_count(mgx_handle* h, const float* x_dev, int64_t samples, double* peak, int64_t* count);
 int mgx_pcm_decode(mgx_handle* h, const void* pcm_dev, int64_t samples, int32_t bits, float* out_dev);
 int mgx_pcm_encode(mgx_handle* h, const float* x_dev, int64_t samples, int32_t bits, void* pcm_dev);
 

@@ -103,6 +103,7 @@ SYMBOLS = {
     "mgx_limit": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.POINTER(MgxConfig), ctypes.c_double,
                                  ctypes.c_double, _VP, c_int32_p]),
     "mgx_scale": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_double, _VP]),
+    "mgx_peak_count": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, c_double_p, ctypes.POINTER(ctypes.c_int64)]),
     "mgx_pcm_decode": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int32, _VP]),
     "mgx_pcm_encode": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int32, _VP]),
     "mgx_last_fir": (ctypes.c_int, [_VP, ctypes.POINTER(_VP), c_int32_p]),

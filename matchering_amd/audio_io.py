@@ -12,9 +12,9 @@ follows libsndfile: integers are read as ``x / 2**(bits-1)`` and written as
 
 Integer PCM can also pass through undecoded (``load(..., pcm=True)``, integer arrays given to ``save``):
 the samples then cross PCIe as the file holds them and are converted on the GPU (``mgx_pcm_decode`` /
-``mgx_pcm_encode``, same scaling).  Such an array is int16 (n, channels) or int32 (n, channels) on the
-way in, and on the way out also uint8 (n, channels * 3) for packed little-endian 24-bit samples;
-``pcm_to_float`` turns any of them into the floats the default path returns.
+``mgx_pcm_encode``, same scaling).  Such an array is int16 (n, channels), int32 (n, channels), or uint8
+(n, channels * 3) for packed little-endian 24-bit samples; ``pcm_to_float`` turns any of them into the
+floats the default path returns.
 """
 
 import os
@@ -91,6 +91,20 @@ def _wav_layout(path):
     raise RuntimeError("Format not recognised: missing fmt or data chunk")
 
 
+def unpack24(array):
+    """Packed little-endian 24-bit samples, uint8 (n, channels * 3) -> int32 (n, channels) with the sample in
+    the three high bytes (the value at scale 2**31): one strided copy."""
+    frames = array.shape[0]
+    wide = np.zeros((array.size // 3, 4), dtype=np.uint8)
+    wide[:, 1:] = np.asarray(array).reshape(-1, 3)
+    return wide.view("<i4").reshape(frames, -1)
+
+
+def pcm_channels(array):
+    """Channel count of (n, channels) audio, or of packed 24-bit PCM (n, channels * 3) uint8."""
+    return array.shape[1] // 3 if array.dtype == np.uint8 else array.shape[1]
+
+
 def pcm_to_float(array, dtype=np.float32):
     """Integer PCM as ``load(..., pcm=True)`` returns it -> floats in [-1, 1): ``v / 2**(bits-1)``, exact
     in float32 up to 24 bits.  Float arrays pass through."""
@@ -100,26 +114,28 @@ def pcm_to_float(array, dtype=np.float32):
         out *= dtype(1.0 / 32768.0)
         return out
     if array.dtype == np.int32:
-        return (array.astype(np.float64) * (1.0 / 2147483648.0)).astype(dtype)
+        out = array.astype(np.float64)
+        out *= 1.0 / 2147483648.0
+        return out.astype(dtype, copy=False)
     if array.dtype == np.uint8:                            # packed little-endian 24-bit
-        frames = array.shape[0]
-        b = array.reshape(-1, 3)
-        v = b[:, 0].astype(np.int32)
-        v |= b[:, 1].astype(np.int32) << 8
-        v |= b[:, 2].astype(np.int8).astype(np.int32) << 16            # the top byte carries the sign
-        out = v.astype(dtype)
+        out = (unpack24(array) >> 8).astype(dtype)
         out *= dtype(1.0 / 8388608.0)
-        return out.reshape(frames, -1)
+        return out
     return array
 
 
 def read_wav(path, pcm=False):
     """(frames, channels) samples and the sample rate.  Floats in [-1, 1): float32 for integer files up to
     24 bits (exact), float64 for 32-bit integer and for DOUBLE files, float32 for FLOAT files.  With
-    ``pcm=True`` files of 16 or 32-bit integers come back undecoded (module docstring)."""
+    ``pcm=True`` files of 16, 24 or 32-bit integers come back undecoded, as a read-only view of the file
+    (module docstring; 24-bit samples packed, uint8 (frames, channels * 3))."""
     code, channels, rate, block, bits, offset, nbytes = _wav_layout(path)
     frames = nbytes // block
-    raw = np.fromfile(path, dtype=np.uint8, count=frames * block, offset=offset)
+    if pcm and code == _PCM and bits in (16, 24, 32) and frames > 0:
+        # undecoded samples are only read (checks, staging for the upload): map the file instead of copying it
+        raw = np.memmap(path, dtype=np.uint8, mode="r", offset=offset, shape=(frames * block,))
+    else:
+        raw = np.fromfile(path, dtype=np.uint8, count=frames * block, offset=offset)
     if code == _FLOAT and bits in (32, 64):
         out = raw.view("<f4" if bits == 32 else "<f8")
     elif code == _PCM and bits == 8:
@@ -133,8 +149,10 @@ def read_wav(path, pcm=False):
         if not pcm:
             out = pcm_to_float(out, np.float64)
     elif code == _PCM and bits == 24:
-        out = pcm_to_float(raw.reshape(frames, channels * 3))       # (decoded here: three-byte samples do not
-                                                                    # lend themselves to the checks in between)
+        out = raw.reshape(frames, channels * 3)                    # packed: three bytes per sample
+        if not pcm:                                                # 24 bits are exact in float32
+            out = (unpack24(out) >> 8).astype(np.float32)
+            out *= np.float32(1.0 / 8388608.0)
     else:
         raise RuntimeError(f"Format not recognised: WAVE format tag {code} with {bits} bits")
     return out.reshape(frames, -1) if out.dtype == np.uint8 else out.reshape(frames, channels), rate
@@ -342,7 +360,7 @@ def _read(path, pcm=False):
 def load(file: str, file_type: str, temp_folder: str, pcm: bool = False):
     """loader.py:30-47: returns ``(sound (n, channels) floats, sample_rate)``; raises
     ``ModuleError(4001 | 4101)`` when the file cannot be decoded (after trying ffmpeg).  ``pcm=True``
-    (what ``process`` passes) leaves WAVE files of 16 or 32-bit integers undecoded (module docstring)."""
+    (what ``process`` passes) leaves WAVE files of 16, 24 or 32-bit integers undecoded (module docstring)."""
     file_type = file_type.upper()
     sound, sample_rate = None, None
     debug(f"reading {file_type} from '{file}'")
@@ -354,7 +372,7 @@ def load(file: str, file_type: str, temp_folder: str, pcm: bool = False):
             sound, sample_rate = _load_with_ffmpeg(file, file_type, temp_folder)
     if sound is None or sample_rate is None:
         raise ModuleError(Code.ERROR_TARGET_LOADING if file_type == "TARGET" else Code.ERROR_REFERENCE_LOADING)
-    debug(f"{file_type}: {sound.shape[0]} frames, {sound.shape[1]} channel(s) at {sample_rate} Hz")
+    debug(f"{file_type}: {sound.shape[0]} frames, {pcm_channels(sound)} channel(s) at {sample_rate} Hz")
     return sound, sample_rate
 
 

@@ -12,7 +12,7 @@ from math import gcd
 
 import numpy as np
 
-from .audio_io import pcm_to_float
+from .audio_io import pcm_channels, pcm_to_float, unpack24
 from .config import Config
 from .log import Code, ModuleError, debug, info, warning
 from .utils import time_str
@@ -58,8 +58,10 @@ def _resample(array, sample_rate, required):
         return resample_poly(array, int(required) // g, int(sample_rate) // g, axis=0)
 
 
-def check(array: np.ndarray, sample_rate: int, config: Config, name: str):
-    """checker.py:90-137: returns the validated ``(array (n, 2), internal_sample_rate)``."""
+def check(array: np.ndarray, sample_rate: int, config: Config, name: str, peaks=None):
+    """checker.py:90-137: returns the validated ``(array (n, 2), internal_sample_rate)``.  ``array`` may be
+    integer PCM as a file holds it (audio_io); ``peaks`` = ``count_max_peaks`` of the track when the caller
+    has it already (``process`` takes it on the GPU, ``mgx_peak_count``) -- the samples are then not read."""
     name = name.upper()
     target = name == "TARGET"
     length = array.shape[0]
@@ -71,10 +73,14 @@ def check(array: np.ndarray, sample_rate: int, config: Config, name: str):
         raise ModuleError(Code.ERROR_TARGET_LENGTH_IS_TOO_SMALL if target
                           else Code.ERROR_REFERENCE_LENGTH_LENGTH_TOO_SMALL)
 
-    if array.shape[1] == 1:
+    channels = pcm_channels(array)
+    if array.dtype == np.uint8 and (channels != 2 or sample_rate != config.internal_sample_rate
+                                    or (target and peaks is None)):
+        array = unpack24(array)                                         # packed samples: only as they are, or not
+    if channels == 1:
         info(Code.INFO_TARGET_IS_MONO if target else Code.INFO_REFERENCE_IS_MONO)
         array = np.repeat(array, repeats=2, axis=1)                     # dsp.py:45-46
-    elif array.shape[1] != 2:
+    elif channels != 2:
         raise ModuleError(Code.ERROR_TARGET_NUM_OF_CHANNELS_IS_EXCEEDED if target
                           else Code.ERROR_REFERENCE_NUM_OF_CHANNELS_IS_EXCEEDED)
 
@@ -88,7 +94,7 @@ def check(array: np.ndarray, sample_rate: int, config: Config, name: str):
         sample_rate = config.internal_sample_rate
 
     if target:
-        max_value, max_count = count_max_peaks(array)
+        max_value, max_count = peaks if peaks is not None else count_max_peaks(array)
         if max_count > config.clipping_samples_threshold:
             if np.isclose(max_value, 1.0):
                 warning(Code.WARNING_TARGET_IS_CLIPPING)

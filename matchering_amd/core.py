@@ -6,7 +6,7 @@ around the one call that runs on the GPU.
           --_write_results--> files (+ optional previews)
 """
 
-from .audio_io import load, pcm_to_float, save
+from .audio_io import load, pcm_channels, pcm_to_float, save
 from .checker import check, check_equality
 from .config import Config
 from .log import Code, ModuleError, debug, debug_line, info
@@ -44,23 +44,59 @@ def _wanted_encodings(results):
     return tuple(next(iter(w)) if len(w) == 1 else None for w in wanted)
 
 
+def _gpu():
+    """The default device, or None where there is none (the CPU tests put a stand-in behind ``main``)."""
+    try:
+        from .device import default_device
+
+        return default_device()
+    except Exception:       # noqa: BLE001 -- no library, no GPU: the host-side checks do all of it
+        return None
+
+
 def _read_pair(target_path, reference_path, config, temp_folder):
-    """Load and check both tracks (core.py:52-74); raises ModuleError with the reference's codes."""
-    tracks = []
+    """Load and check both tracks (core.py:52-74); raises ModuleError with the reference's codes.  Integer
+    PCM tracks that need no channel or rate conversion go to the GPU at once: they are decoded there, the
+    target's peak statistics (checker.py:118-130) are taken there, and ``main`` receives them resident."""
+    from .device import DeviceFrames
+
+    dev = _gpu()
+    tracks, resident = [], []
     for path, role in ((target_path, "target"), (reference_path, "reference")):
-        audio, rate = load(path, role, temp_folder, pcm=True)     # 16/32-bit WAVE: decoded on the GPU
-        tracks.append(check(audio, rate, config, role))
+        audio, rate = load(path, role, temp_folder, pcm=True)    # 16/24/32-bit WAVE: decoded on the GPU
+        peaks, frames = None, None
+        direct = (dev is not None and audio.dtype.kind in "iu" and pcm_channels(audio) == 2
+                  and rate == config.internal_sample_rate and audio.shape[0] > 0)
+        if direct:
+            with dev.lock:
+                frames = DeviceFrames(dev.upload_frames(audio), audio.shape[0])
+                if role == "target":
+                    peaks = dev.peak_count(frames, 2 * audio.shape[0])
+        try:
+            tracks.append(check(audio, rate, config, role, peaks=peaks))
+        except Exception:
+            for f in resident + [frames]:
+                if f is not None:
+                    f.release()
+            raise
+        resident.append(frames)
     (target, target_rate), (reference, reference_rate) = tracks
-    if not config.allow_equality:
-        check_equality(target, reference)
-    consistent = (
-        target_rate == reference_rate == config.internal_sample_rate
-        and target.shape[1] == reference.shape[1] == 2
-        and min(target.shape[0], reference.shape[0]) > config.fft_size
-    )
-    if not consistent:
-        raise ModuleError(Code.ERROR_VALIDATION)
-    return target, reference
+    try:
+        if not config.allow_equality:
+            check_equality(target, reference)
+        consistent = (
+            target_rate == reference_rate == config.internal_sample_rate
+            and pcm_channels(target) == pcm_channels(reference) == 2
+            and min(target.shape[0], reference.shape[0]) > config.fft_size
+        )
+        if not consistent:
+            raise ModuleError(Code.ERROR_VALIDATION)
+    except Exception:
+        for f in resident:
+            if f is not None:
+                f.release()
+        raise
+    return target, reference, resident
 
 
 def _write_results(results, renderings, sample_rate):
@@ -81,12 +117,14 @@ def process(target: str, reference: str, results: list, config: Config = None,
         raise RuntimeError("The result list is empty")
     temp_folder = config.temp_folder or get_temp_folder(results)
 
-    target_audio, reference_audio = _read_pair(target, reference, config, temp_folder)
+    target_audio, reference_audio, resident = _read_pair(target, reference, config, temp_folder)
     previews = bool(preview_target or preview_result)
     # (previews are cut from float frames: with them the renderings stay float and the files are quantised
     # on the host)
     encodings = None if previews else _wanted_encodings(results)
-    renderings = main(target_audio, reference_audio, config, *_wanted_renderings(results), encodings=encodings)
+    renderings = main(resident[0] if resident[0] is not None else target_audio,
+                      resident[1] if resident[1] is not None else reference_audio,
+                      config, *_wanted_renderings(results), encodings=encodings)      # (releases the resident frames)
     del reference_audio
 
     debug_line()

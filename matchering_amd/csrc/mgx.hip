@@ -81,6 +81,7 @@ struct mgx_handle {
     DevBuf y, mid, block_peak, filt, taps, partial, cstate, scalars, conv_queue;
     DevBuf lim_published, lim_ctrl, lim_weights, round_ctr, tail_gains, band, band_info;
     std::vector<double> lim_weights_host;
+    DevBuf peak_words;                      // mgx_peak_count: {bits of the maximum, count}
     DevBuf fir_robust;                      // lowess_it > 0: robustness weights and residuals, [2][2][nlog]
     DevBuf lim_tables;                      // general filter orders: matrix powers and look-back matrices
     std::vector<double> lim_tables_host;
@@ -747,7 +748,7 @@ int mgx_destroy(mgx_handle* h) {
     hipStreamSynchronize(h->stream);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
-                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->lim_tables, &h->fir_robust, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info,
+                      &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->lim_tables, &h->fir_robust, &h->peak_words, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info,
                       &h->conv_queue};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -971,6 +972,30 @@ int mgx_scale(mgx_handle* h, const float* x_dev, int64_t n, double gain, float* 
     hipLaunchKernelGGL(k_scale_outputs, dim3(grid), dim3(256), 0, h->stream, (const float2*)x_dev, (long long)n,
                        (const double*)nullptr, gain, (const double*)nullptr, (float2*)out_dev, (float2*)nullptr);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int mgx_peak_count(mgx_handle* h, const float* x_dev, int64_t samples, double* peak, int64_t* count) {
+    if (!h || !x_dev || !peak || !count) return fail(MGX_ERR_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    MGX_TRY(ensure(h, h->peak_words, 64));
+    MGX_TRY(ensure_pinned(h, (size_t)1 << 16));
+    unsigned long long* words = (unsigned long long*)h->peak_words.p;
+    HIP_TRY(hipMemsetAsync(words, 0, 16, h->stream));
+    if (samples > 0) {
+        const unsigned grid = (unsigned)std::min<long long>((samples / 4 + 255) / 256 + 1, 4096);
+        hipLaunchKernelGGL(k_peak_max, dim3(grid), dim3(256), 0, h->stream, x_dev, (long long)samples, words);
+        hipLaunchKernelGGL(k_peak_count, dim3(grid), dim3(256), 0, h->stream, x_dev, (long long)samples, words);
+        HIP_TRY(hipGetLastError());
+    }
+    unsigned long long* host = (unsigned long long*)h->pinned;
+    HIP_TRY(hipMemcpyAsync(host, words, 16, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const unsigned bits = (unsigned)host[0];
+    float f;
+    std::memcpy(&f, &bits, 4);
+    *peak = (double)f;
+    *count = (int64_t)host[1];
     return 0;
 }
 

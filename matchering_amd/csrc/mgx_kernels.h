@@ -1794,6 +1794,42 @@ __global__ __launch_bounds__(256) void k_pcm_encode(const float* x, long long sa
     }
 }
 
+// dsp.py:49-54 count_max_peaks on frames in HBM: the largest magnitude, then how many samples numpy.isclose
+// would put on it (|x - m| <= 1e-8 + 1e-5 m, either sign), evaluated in float64 like numpy does on the
+// float32 values.  out[0] = bits of the maximum (a non-negative float orders like its bit pattern),
+// out[1] = the count; both zeroed by the caller.
+__global__ __launch_bounds__(256) void k_peak_max(const float* x, long long samples, unsigned long long* out) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < samples; i += (long long)gridDim.x * 1024) {
+        if (i + 4 <= samples) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        } else {
+            for (long long k = i; k < samples; ++k) m = fmaxf(m, fabsf(x[k]));
+        }
+    }
+    const float b = block_max<256>(m, red);
+    if (threadIdx.x == 0) atomicMax(out, (unsigned long long)__float_as_uint(b));
+}
+__global__ __launch_bounds__(256) void k_peak_count(const float* x, long long samples, unsigned long long* out) {
+    __shared__ double red[4];
+    const double peak = (double)__uint_as_float((unsigned)out[0]);
+    const double tol = 1e-8 + 1e-5 * peak;
+    int c = 0;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < samples; i += (long long)gridDim.x * 1024) {
+        if (i + 4 <= samples) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i);
+            c += (fabs(fabs((double)v.x) - peak) <= tol) + (fabs(fabs((double)v.y) - peak) <= tol) +
+                 (fabs(fabs((double)v.z) - peak) <= tol) + (fabs(fabs((double)v.w) - peak) <= tol);
+        } else {
+            for (long long k = i; k < samples; ++k) c += fabs(fabs((double)x[k]) - peak) <= tol;
+        }
+    }
+    const double total = block_sum<256>((double)c, red);
+    if (threadIdx.x == 0 && total > 0.0) atomicAdd(out + 1, (unsigned long long)total);
+}
+
 // One chunk with hold / release filters of order up to K (limiter_general.h): the load, window, attack and
 // store phases of the first-order kernel; the two low-passes as K-state maps scanned through LDS.
 template <int K>

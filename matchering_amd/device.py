@@ -97,6 +97,21 @@ def pcm_bits(array):
     return 0
 
 
+class DeviceFrames:
+    """(frames, 2) float32 audio resident in HBM: what ``stages.main`` accepts in place of a numpy array when
+    the caller has uploaded (and looked at) a track already -- ``core.process`` does, for the checks."""
+
+    def __init__(self, buf, frames):
+        self.buf, self.frames = buf, int(frames)
+
+    @property
+    def shape(self):
+        return (self.frames, 2)
+
+    def release(self):
+        self.buf.release()
+
+
 class DeviceBuffer:
     """An HBM allocation owned by a Device.  ``release`` (or garbage collection) hands the block back to
     the device's free list -- hipMalloc / hipFree of a 170 MB block cost milliseconds and hipFree waits
@@ -231,6 +246,14 @@ class Device:
         check(library().mgx_pcm_decode(self.handle, ctypes.c_void_p(raw.ptr), samples, bits, ctypes.c_void_p(out.ptr)))
         raw.release()           # (recycled by later work on this stream only, which is ordered behind the decode)
         return out
+
+    def peak_count(self, buf, samples):
+        """dsp.py:49-54 count_max_peaks of float32 samples in HBM: (largest magnitude, samples on it)."""
+        peak, count = ctypes.c_double(), ctypes.c_int64()
+        ptr = buf.ptr if hasattr(buf, "ptr") else buf.buf.ptr
+        check(library().mgx_peak_count(self.handle, ctypes.c_void_p(ptr), int(samples), ctypes.byref(peak),
+                                       ctypes.byref(count)))
+        return peak.value, count.value
 
     def download_pcm(self, buf, frames, channels, bits, wait=True):
         """float32 frames in HBM -> integer PCM on the host (pinned): int16 / int32 (n, channels), or uint8

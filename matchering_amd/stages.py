@@ -13,7 +13,7 @@ device-side values.
 import numpy as np
 
 from .config import Config
-from .device import default_device
+from .device import DeviceFrames, default_device
 from .log import Code, debug, debug_line, info
 from .utils import to_db
 
@@ -23,8 +23,14 @@ PCM_BITS = {"PCM_16": 16, "PCM_24": 24, "PCM_32": 32}
 
 def _as_frames(array, name):
     """(n, 2) frames as they will cross PCIe: float32, or the integer PCM of a file as it is (int16 / int32,
-    audio_io): those are decoded on the device."""
+    or packed 24-bit uint8 (n, 6), audio_io): those are decoded on the device."""
+    if isinstance(array, DeviceFrames):                  # uploaded by the caller already
+        return array
     array = np.asarray(array)
+    if array.dtype == np.uint8:                          # packed 24-bit PCM
+        if array.ndim != 2 or array.shape[1] != 6:
+            raise ValueError(f"{name} must hold (n, 2) packed 24-bit frames, got {array.shape}")
+        return np.ascontiguousarray(array)
     if array.ndim != 2 or array.shape[1] != 2:
         raise ValueError(f"{name} must have shape (n, 2), got {array.shape}")
     if array.dtype in (np.int16, np.int32):
@@ -52,8 +58,8 @@ def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default
     debug(f"analysis pieces: at most {config.max_piece_size} frames "
           f"({config.max_piece_size / config.internal_sample_rate:.2f} s) each")
     with dev.lock:
-        t_dev = dev.upload_frames(target)
-        r_dev = dev.upload_frames(reference)
+        t_dev = target.buf if isinstance(target, DeviceFrames) else dev.upload_frames(target)
+        r_dev = reference.buf if isinstance(reference, DeviceFrames) else dev.upload_frames(reference)
         outs = [dev.alloc(n * 8) if need else None
                 for need in (need_default, need_no_limiter, need_no_limiter_normalized)]
         try:

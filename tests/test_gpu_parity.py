@@ -592,3 +592,70 @@ def test_master_on_pcm_frames_equals_master_on_their_floats():
     assert coded[0].dtype == np.int16 and np.array_equal(coded[0], audio_io._quantise(plain[0], 16).reshape(-1, 2))
     assert coded[1].dtype == np.uint8 and np.array_equal(coded[1], audio_io._pack24(audio_io._quantise(plain[1], 24)).reshape(-1, 6))
     assert coded[2].dtype == np.float32 and np.array_equal(coded[2], plain[2])
+
+
+def test_peak_statistics_on_the_device_match_count_max_peaks():
+    """mgx_peak_count (dsp.py:49-54 on the GPU) against checker.count_max_peaks, which is checked against the
+    reference's own expression on the CPU: random frames, a clipped track, a limited-looking track (many
+    samples within numpy.isclose's tolerance of the peak), silence."""
+    from matchering_amd import checker
+    from matchering_amd.device import default_device
+
+    dev = default_device()
+    rng = np.random.RandomState(21)
+    cases = []
+    for frames in (1, 7, 4099, 250001):
+        cases.append((0.3 * rng.randn(frames, 2)).astype(np.float32))
+    clipped = np.clip(1.5 * rng.randn(100000, 2), -1, 1).astype(np.float32)
+    limited = (0.7 * np.tanh(3 * rng.randn(100000, 2))).astype(np.float32)
+    limited[np.abs(limited) > 0.69] = np.float32(0.69) * np.sign(limited[np.abs(limited) > 0.69])
+    limited[::97] *= np.float32(1 - 4e-6)                     # inside the relative tolerance of the peak
+    cases += [clipped, limited, np.zeros((1000, 2), np.float32)]
+    for x in cases:
+        with dev.lock:
+            buf = dev.upload(x)
+            got = dev.peak_count(buf, x.size)
+            buf.release()
+        want = checker.count_max_peaks(x)
+        assert got[1] == want[1] and got[0] == float(want[0]), (x.shape, got, want)
+
+
+def test_process_pcm_files_stay_integer_up_to_the_gpu(tmp_path):
+    """mg.process on PCM_16 and PCM_24 WAVE files without previews: samples are mapped from the files, decoded
+    on the GPU (mgx_pcm_decode), the target's peak statistics come from the GPU (mgx_peak_count: the clipped
+    target below must draw the warning the host-side check gives for the decoded samples -- "clipping" at 24
+    bits, "a limiter was applied" at 16, where full scale reads back as 32767/32768), and the files are
+    written from integers quantised on the GPU.  Against the oracle run on the decoded inputs, to a quantisation step and a half."""
+    import matchering_amd as mg
+    from matchering_amd import audio_io, checker
+    from matchering_amd.synth import make_pair
+
+    sr = 44100
+    t, r = make_pair(8.0, sr, pair=11, reference_seconds=6.0)
+    t = np.clip(1.3 * t / np.abs(t).max(), -1, 1)            # clipped on purpose
+    for subtype, step in (("PCM_16", 1.0 / (1 << 15)), ("PCM_24", 1.0 / (1 << 23))):
+        tp, rp = str(tmp_path / f"t_{subtype}.wav"), str(tmp_path / f"r_{subtype}.wav")
+        audio_io.write_wav(tp, t, sr, subtype)
+        audio_io.write_wav(rp, 0.8 * r, sr, subtype)
+        out, plain = str(tmp_path / f"o_{subtype}.wav"), str(tmp_path / f"p_{subtype}.wav")
+        warnings = []
+        mg.log(warning_handler=lambda text: warnings.append(str(text).split(":")[0]), show_codes=True)
+        try:
+            mg.process(tp, rp, [mg.Result(out, subtype), mg.Result(plain, subtype, use_limiter=False, normalize=False)],
+                       config=mg.Config(max_piece_size=2.0))
+        finally:
+            mg.log()
+        ti, _ = audio_io.read_wav(tp)
+        ri, _ = audio_io.read_wav(rp)
+        expected = []
+        mg.log(warning_handler=lambda text: expected.append(str(text).split(":")[0]), show_codes=True)
+        try:
+            checker.check(ti, sr, mg.Config(max_piece_size=2.0), "target")
+        finally:
+            mg.log()
+        assert warnings == expected != [], (warnings, expected)
+        want = mo.master(ti.astype(np.float64), ri.astype(np.float64), mo.params(max_piece_size=2.0), True, True, False)
+        got, _ = audio_io.read_wav(out)
+        assert np.abs(got - np.clip(want[0], -1, 1)).max() <= 1.6 * step + 2e-6
+        got, _ = audio_io.read_wav(plain)
+        assert np.abs(got - np.clip(want[1], -1, 1)).max() <= 1.6 * step + 2e-6

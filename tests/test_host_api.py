@@ -268,7 +268,8 @@ def test_process_file_pipeline_on_cpu(tmp_path, monkeypatch):
         calls["needs"] = (need_default, need_no_limiter, need_no_limiter_normalized)
         assert encodings is None                       # previews were asked for: the renderings stay float
         ocfg = mo.params(max_piece_size=config.max_piece_size / config.internal_sample_rate)
-        out = mo.master(np.asarray(target, dtype=np.float64), np.asarray(reference, dtype=np.float64), ocfg,
+        out = mo.master(audio_io.pcm_to_float(np.asarray(target), np.float64),
+                        audio_io.pcm_to_float(np.asarray(reference), np.float64), ocfg,
                         need_default, need_no_limiter, need_no_limiter_normalized)
         calls["out"] = out
         return out
@@ -389,12 +390,12 @@ def test_pcm_files_pass_through_undecoded(tmp_path):
     the floats they came from."""
     rng = np.random.RandomState(4)
     x = np.clip(0.4 * rng.randn(5003, 2), -1.2, 1.2).astype(np.float32)
-    for subtype, dtype in (("PCM_16", np.int16), ("PCM_32", np.int32), ("PCM_24", np.float32)):
+    for subtype, dtype in (("PCM_16", np.int16), ("PCM_32", np.int32), ("PCM_24", np.uint8)):
         path = str(tmp_path / f"{subtype}.wav")
         audio_io.write_wav(path, x, 44100, subtype)
         plain, rate = audio_io.load(path, "target", str(tmp_path))
         raw, _ = audio_io.load(path, "target", str(tmp_path), pcm=True)
-        assert rate == 44100 and raw.dtype == dtype and raw.shape == x.shape
+        assert rate == 44100 and raw.dtype == dtype and audio_io.pcm_channels(raw) == 2 and raw.shape[0] == x.shape[0]
         assert np.array_equal(audio_io.pcm_to_float(raw, plain.dtype), plain)
         if subtype == "PCM_16":         # written at scale 32767, read at 32768 (libsndfile): up to 1.5 steps
             assert np.abs(plain - np.clip(x, -1, 1)).max() <= 1.6 / (1 << 15)
