@@ -34,6 +34,8 @@ import os
 import queue
 import sys
 import threading
+
+import numpy as np
 from concurrent.futures import ThreadPoolExecutor
 
 from .config import Config
@@ -197,6 +199,26 @@ def master_album(targets, reference, config=None, rank=None, world_size=None, de
     return results
 
 
+def _peaks_on_the_lane(target, device_index, lane, config, master):
+    """The part of checker.check that ``_load_job`` left out for an integer PCM target: upload it on the
+    lane's device, take count_max_peaks there (mgx_peak_count), warn as the reference would; the resident
+    frames go on to stages.main.  With a stand-in for the GPU the statistics are taken on the host."""
+    from .audio_io import unpack24
+    from .checker import count_max_peaks, peak_warnings
+
+    if master is not None:
+        peak_warnings(count_max_peaks(unpack24(target) if target.dtype == np.uint8 else target), config)
+        return target
+    from .device import DeviceFrames
+
+    dev = lane_device(device_index, lane)
+    with dev.lock:
+        frames = DeviceFrames(dev.upload_frames(target), target.shape[0])
+        peaks = dev.peak_count(frames, 2 * target.shape[0])
+    peak_warnings(peaks, config)
+    return frames
+
+
 def _wanted_encodings(results):
     from .core import _wanted_encodings as of_results
 
@@ -210,24 +232,27 @@ def _needs_of(results):
 
 
 def _load_job(job, config):
-    """Load + check both files of a job (core.py:52-74), on a host thread."""
-    from .audio_io import load
-    from .checker import check, check_equality
+    """Load + check both files of a job (core.py:52-74), on a host thread.  Returns (target, reference,
+    deferred): with ``deferred`` the target is integer PCM that goes to the GPU as it is, and its peak
+    statistics (checker.py:118-130) are left to the lane that masters it (``mgx_peak_count``)."""
+    from .audio_io import load, pcm_channels
+    from .checker import LATER, check, check_equality
     from .utils import get_temp_folder
 
     temp_folder = config.temp_folder if config.temp_folder else get_temp_folder(job["results"])
-    # (pcm=True: 16/32-bit WAVE samples stay integers up to the GPU, as in core.process)
+    # (pcm=True: 16/24/32-bit WAVE samples stay integers up to the GPU, as in core.process)
     target, rate_t = load(job["target"], "target", temp_folder, pcm=True)
-    target, rate_t = check(target, rate_t, config, "target")
+    deferred = (target.dtype.kind in "iu" and pcm_channels(target) == 2 and rate_t == config.internal_sample_rate)
+    target, rate_t = check(target, rate_t, config, "target", peaks=LATER if deferred else None)
     reference, rate_r = load(job["reference"], "reference", temp_folder, pcm=True)
     reference, rate_r = check(reference, rate_r, config, "reference")
     if not config.allow_equality:
         check_equality(target, reference)
     if (not (rate_t == rate_r == config.internal_sample_rate)
-            or not (target.shape[1] == reference.shape[1] == 2)
+            or not (pcm_channels(target) == pcm_channels(reference) == 2)
             or not (target.shape[0] > config.fft_size and reference.shape[0] > config.fft_size)):
         raise ModuleError(Code.ERROR_VALIDATION)
-    return target, reference
+    return target, reference, deferred
 
 
 def _save_job(job, triple, config):
@@ -260,12 +285,14 @@ def process_batch(jobs, config=None, rank=None, world_size=None, device_index=No
             workers = {}
 
             def run(item):
-                index, arrays = item
+                index, (target, reference, deferred) = item
                 needs = _needs_of(jobs[index]["results"])
                 key = (needs, _wanted_encodings(jobs[index]["results"]))
                 if key not in workers:
                     workers[key] = _device_worker(device_index, lane, config, needs, master, key[1])
-                return workers[key](arrays)
+                if deferred:
+                    target = _peaks_on_the_lane(target, device_index, lane, config, master)
+                return workers[key]((target, reference))
             return run
 
         pool = _Lanes(worker_for, max(1, lanes))

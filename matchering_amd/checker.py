@@ -58,10 +58,25 @@ def _resample(array, sample_rate, required):
         return resample_poly(array, int(required) // g, int(sample_rate) // g, axis=0)
 
 
+LATER = object()      # check(..., peaks=LATER): the caller will hand the peak statistics to peak_warnings itself
+
+
+def peak_warnings(peaks, config: Config) -> None:
+    """checker.py:118-130: a target with many samples on its peak is clipped (peak at full scale) or has been
+    through a limiter already."""
+    max_value, max_count = peaks
+    if max_count > config.clipping_samples_threshold:
+        if np.isclose(max_value, 1.0):
+            warning(Code.WARNING_TARGET_IS_CLIPPING)
+        elif max_count > config.limited_samples_threshold:
+            warning(Code.WARNING_TARGET_LIMITER_IS_APPLIED)
+
+
 def check(array: np.ndarray, sample_rate: int, config: Config, name: str, peaks=None):
     """checker.py:90-137: returns the validated ``(array (n, 2), internal_sample_rate)``.  ``array`` may be
     integer PCM as a file holds it (audio_io); ``peaks`` = ``count_max_peaks`` of the track when the caller
-    has it already (``process`` takes it on the GPU, ``mgx_peak_count``) -- the samples are then not read."""
+    has it already (``process`` takes it on the GPU, ``mgx_peak_count``) -- the samples are then not read --
+    or ``LATER`` when it will call ``peak_warnings`` itself."""
     name = name.upper()
     target = name == "TARGET"
     length = array.shape[0]
@@ -74,8 +89,10 @@ def check(array: np.ndarray, sample_rate: int, config: Config, name: str, peaks=
                           else Code.ERROR_REFERENCE_LENGTH_LENGTH_TOO_SMALL)
 
     channels = pcm_channels(array)
-    if array.dtype == np.uint8 and (channels != 2 or sample_rate != config.internal_sample_rate
-                                    or (target and peaks is None)):
+    converting = channels != 2 or sample_rate != config.internal_sample_rate
+    if converting and peaks is LATER:
+        peaks = None                                                    # (taken below, on the converted track)
+    if array.dtype == np.uint8 and (converting or (target and peaks is None)):
         array = unpack24(array)                                         # packed samples: only as they are, or not
     if channels == 1:
         info(Code.INFO_TARGET_IS_MONO if target else Code.INFO_REFERENCE_IS_MONO)
@@ -93,13 +110,8 @@ def check(array: np.ndarray, sample_rate: int, config: Config, name: str, peaks=
             info(Code.INFO_REFERENCE_IS_RESAMPLED)
         sample_rate = config.internal_sample_rate
 
-    if target:
-        max_value, max_count = peaks if peaks is not None else count_max_peaks(array)
-        if max_count > config.clipping_samples_threshold:
-            if np.isclose(max_value, 1.0):
-                warning(Code.WARNING_TARGET_IS_CLIPPING)
-            elif max_count > config.limited_samples_threshold:
-                warning(Code.WARNING_TARGET_LIMITER_IS_APPLIED)
+    if target and peaks is not LATER:
+        peak_warnings(peaks if peaks is not None else count_max_peaks(array), config)
     return array, sample_rate
 
 

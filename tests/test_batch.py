@@ -93,7 +93,7 @@ def test_process_batch_files_two_ranks(tmp_path):
     jobs = []
     for b, (t, r) in enumerate(_pairs(4, seconds=2.0, rate=rate)):
         tp, rp = str(tmp_path / f"t{b}.wav"), str(tmp_path / f"r{b}.wav")
-        kind = "PCM_16" if b == 1 else "FLOAT"          # job 1: integer files stay integers up to the device
+        kind = {1: "PCM_16", 2: "PCM_24"}.get(b, "FLOAT")     # jobs 1, 2: integer files stay integers up to the device
         audio_io.write_wav(tp, t, rate, kind)
         audio_io.write_wav(rp, r, rate, kind)
         jobs.append({"target": tp, "reference": rp,
@@ -109,7 +109,7 @@ def test_process_batch_files_two_ranks(tmp_path):
         want = _oracle_master(t, r, cfg, True, True, False)
         got, _ = audio_io.read_wav(str(tmp_path / f"out{b}.wav"))
         plain, _ = audio_io.read_wav(str(tmp_path / f"plain{b}.wav"))
-        step = 1.6 / 32768 if b == 1 else 1e-6
+        step = {1: 1.6 / 32768, 2: 1.6 / (1 << 23) + 1e-6}.get(b, 1e-6)
         assert np.abs(got - want[0]).max() <= step and np.abs(plain - want[1]).max() <= 1e-6
 
 
