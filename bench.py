@@ -300,12 +300,42 @@ def main():
                                       "note": "pageable numpy in -> pinned numpy out through stages.main, one pair, "
                                               "best of 3 calls"}
             line["pcie_inclusive_batch"] = host_to_host_batch(mg, make_pair)
+            try:
+                line["file_to_file"] = file_to_file(mg, wl.host_pair)
+            except Exception as exc:        # noqa: BLE001 -- an unwritable temp folder must not lose the measurement
+                line["file_to_file"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and ranks.world == 1:
             line["cpu_baseline"] = cpu_baseline(wl, name)
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
     if ranks.rank == 0:
         print(json.dumps(line))
     ranks.finish()
+
+
+def file_to_file(mg, pair):
+    """mg.process (core.py:32-121) on the workload's pair as PCM_16 WAVE files: load, checks, the GPU path,
+    one PCM_16 result file.  Integer samples cross PCIe as they are and are decoded / quantised on the GPU
+    (mgx_pcm_decode, mgx_peak_count, mgx_pcm_encode).  Never the headline value."""
+    import shutil
+    import tempfile
+
+    from matchering_amd import audio_io
+
+    target, reference = pair
+    folder = tempfile.mkdtemp(prefix="mgx_bench_")
+    try:
+        tp, rp, op = (os.path.join(folder, n) for n in ("target.wav", "reference.wav", "result.wav"))
+        audio_io.write_wav(tp, 0.7 * target, 44100, "PCM_16")
+        audio_io.write_wav(rp, 0.9 * reference, 44100, "PCM_16")
+        took = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            mg.process(tp, rp, [mg.pcm16(op)])
+            took.append(time.perf_counter() - t0)
+    finally:
+        shutil.rmtree(folder, ignore_errors=True)
+    return {"value": round(target.shape[0] / min(took) / 1e6, 2), "unit": "Msamples/s", "ms": round(min(took) * 1e3, 2),
+            "note": "mg.process on the pair as PCM_16 WAVE files -> one PCM_16 file, best of 3 calls (page cache warm)"}
 
 
 def host_to_host_batch(mg, make_pair, pairs=8, seconds=240.0, lanes=2):
