@@ -892,12 +892,13 @@ __global__ __launch_bounds__(1024) void k_fir_b(FirPlanView pl, double* scratch)
     FirDesign::phase_pin(tid, s);
 }
 // irfft + ifftshift + Hann (match_frequencies.py:98-99) as a direct cosine sum in float64.  grid =
-// (F / TAPS_PER_WG, 2); a workgroup computes TAPS_PER_WG taps (the lanes of a wave), its TAP_SLICES
+// (F / TAPS_PER_WG, 2); a workgroup computes TAPS_PER_WG taps (half the lanes of a wave), its TAP_SLICES
 // waves each summing a slice of the bins.  cos(2 pi k m / F) for the consecutive k of a slice comes from
 // a rotation: start and step are exact table values, the steps in between cost four float64
 // operations each and add ~1e-14 of error over a slice -- no cosine table in LDS (filling 32 KB of
 // it per workgroup was most of this kernel's time) and no gather through the L2.
-constexpr int TAPS_PER_WG = 64, TAP_SLICES = 1024 / TAPS_PER_WG;
+constexpr int TAPS_PER_WG = 32, TAP_SLICES = 1024 / TAPS_PER_WG;     // (F / 32 workgroups: every CU gets one at F = 4096 x 2 channels;
+                                                                  // with 64 taps each the kernel ran on half the chip, 16 vs 11 us)
 __global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double* scratch, float* taps /* [2][F] */) {
     MGX_LDS;
     double* sm = reinterpret_cast<double*>(mgx_smem);       // [bins]
