@@ -23,6 +23,28 @@ def test_wav_round_trip_any_shape(tmp_path_factory, frames, channels, rate, subt
     assert np.abs(y - x).max() <= SUBTYPES[subtype]
 
 
+@settings(max_examples=40, deadline=None)
+@given(frames=st.integers(1, 2000), channels=st.integers(1, 2), subtype=st.sampled_from(["PCM_16", "PCM_24", "PCM_32"]),
+       seed=st.integers(0, 2 ** 16), gain=st.floats(0.1, 1.6))
+def test_integer_pcm_passes_through_the_codec_untouched(tmp_path_factory, frames, channels, subtype, seed, gain):
+    """``read_wav(pcm=True)`` hands over what the file holds, ``pcm_to_float`` decodes it exactly like the default
+    path, and writing those integers back gives the same bytes (what the GPU's quantiser relies on): any
+    shape, values beyond full scale included (clipped on writing, never wrapped)."""
+    rng = np.random.RandomState(seed)
+    x = (gain * rng.randn(frames, channels)).astype(np.float32)
+    folder = tmp_path_factory.mktemp("pcm")
+    a, b = str(folder / "a.wav"), str(folder / "b.wav")
+    audio_io.write_wav(a, x, 44100, subtype)
+    raw, _ = audio_io.read_wav(a, pcm=True)
+    floats, _ = audio_io.read_wav(a)
+    assert raw.dtype.kind in "iu" and audio_io.pcm_channels(raw) == channels and raw.shape[0] == frames
+    assert np.array_equal(audio_io.pcm_to_float(raw, floats.dtype), floats)
+    assert np.abs(floats).max() <= 1.0
+    audio_io.write_wav(b, np.array(raw), 44100, subtype)
+    with open(a, "rb") as fa, open(b, "rb") as fb:
+        assert fa.read() == fb.read()
+
+
 @settings(max_examples=60, deadline=None)
 @given(count=st.integers(0, 200), world=st.integers(1, 16))
 def test_sharding_is_a_balanced_partition(count, world):
