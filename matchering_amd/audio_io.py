@@ -131,7 +131,7 @@ def read_wav(path, pcm=False):
     (module docstring; 24-bit samples packed, uint8 (frames, channels * 3))."""
     code, channels, rate, block, bits, offset, nbytes = _wav_layout(path)
     frames = nbytes // block
-    if pcm and code == _PCM and bits in (16, 24, 32) and frames > 0:
+    if pcm and frames > 0 and ((code == _PCM and bits in (16, 24, 32)) or (code == _FLOAT and bits == 32)):
         # undecoded samples are only read (checks, staging for the upload): map the file instead of copying it
         raw = np.memmap(path, dtype=np.uint8, mode="r", offset=offset, shape=(frames * block,))
     else:

@@ -242,7 +242,8 @@ def _load_job(job, config):
     temp_folder = config.temp_folder if config.temp_folder else get_temp_folder(job["results"])
     # (pcm=True: 16/24/32-bit WAVE samples stay integers up to the GPU, as in core.process)
     target, rate_t = load(job["target"], "target", temp_folder, pcm=True)
-    deferred = (target.dtype.kind in "iu" and pcm_channels(target) == 2 and rate_t == config.internal_sample_rate)
+    deferred = ((target.dtype.kind in "iu" or target.dtype == np.float32) and pcm_channels(target) == 2
+                and rate_t == config.internal_sample_rate)
     target, rate_t = check(target, rate_t, config, "target", peaks=LATER if deferred else None)
     reference, rate_r = load(job["reference"], "reference", temp_folder, pcm=True)
     reference, rate_r = check(reference, rate_r, config, "reference")

@@ -6,6 +6,8 @@ around the one call that runs on the GPU.
           --_write_results--> files (+ optional previews)
 """
 
+import numpy as np
+
 from .audio_io import load, pcm_channels, pcm_to_float, save
 from .checker import check, check_equality
 from .config import Config
@@ -56,8 +58,9 @@ def _gpu():
 
 def _read_pair(target_path, reference_path, config, temp_folder):
     """Load and check both tracks (core.py:52-74); raises ModuleError with the reference's codes.  Integer
-    PCM tracks that need no channel or rate conversion go to the GPU at once: they are decoded there, the
-    target's peak statistics (checker.py:118-130) are taken there, and ``main`` receives them resident."""
+    PCM and float32 tracks that need no channel or rate conversion go to the GPU at once: they are decoded
+    there, the target's peak statistics (checker.py:118-130) are taken there, and ``main`` receives them
+    resident."""
     from .device import DeviceFrames
 
     dev = _gpu()
@@ -65,8 +68,9 @@ def _read_pair(target_path, reference_path, config, temp_folder):
     for path, role in ((target_path, "target"), (reference_path, "reference")):
         audio, rate = load(path, role, temp_folder, pcm=True)    # 16/24/32-bit WAVE: decoded on the GPU
         peaks, frames = None, None
-        direct = (dev is not None and audio.dtype.kind in "iu" and pcm_channels(audio) == 2
-                  and rate == config.internal_sample_rate and audio.shape[0] > 0)
+        # (integer PCM, or float32 frames as a FLOAT file holds them)
+        direct = (dev is not None and (audio.dtype.kind in "iu" or audio.dtype == np.float32)
+                  and pcm_channels(audio) == 2 and rate == config.internal_sample_rate and audio.shape[0] > 0)
         if direct:
             with dev.lock:
                 frames = DeviceFrames(dev.upload_frames(audio), audio.shape[0])
