@@ -23,8 +23,10 @@ def synth(seconds: float, sample_rate: int = 44100, seed: int = 1,
     rng = np.random.RandomState(seed)
     x = 0.35 * rng.randn(n, 2)
     b, a = signal.butter(2, min(corner, 0.2 * sample_rate), fs=sample_rate)
+    xt = np.ascontiguousarray(x.T)                   # (one channel contiguous at a time: same arithmetic, less striding)
     for _ in range(3):
-        x = signal.lfilter(b, a, x, axis=0)
+        xt = signal.lfilter(b, a, xt, axis=1)
+    x = np.ascontiguousarray(xt.T)
     t = np.arange(n) / sample_rate
     x += 0.2 * np.sin(2 * np.pi * 220.0 * t)[:, None] * np.array([1.0, 0.7])
     x += 3e-4 * rng.randn(n, 2)
