@@ -193,6 +193,145 @@ struct Analysis2Block {
 };
 
 // ---------------------------------------------------------------------------
+// fft_size = 2 N', N' = the longest transform a workgroup's LDS holds: a segment's spectra from two
+// transforms of N' points instead of one of 2 N'.  A REAL sequence r of 2 N' points packs as
+// y[n] = r[2n] + j r[2n+1]; with Y = FFT_N'(y), A = (Y_k + conj Y_{N'-k})/2 and B = (Y_k - conj Y_{N'-k})/(2j)
+// are the spectra of the even and of the odd samples, and
+//     R_k = A + w^k B,   R_{N'-k} = conj(A - w^k B),   w = exp(-j pi / N'),   k = 0 .. N'/2
+// (R_{N'} comes out of k = 0).  A and B are exactly what the two-for-one code above forms from a bin and its
+// mirror, so a segment is: transform of the mid samples, magnitudes |A +- w^k B| into the accumulators of
+// bins k and N'-k; the same for the side samples.  Frames are read twice (the second time from the L2).
+template <int LOG2H>
+struct AnalysisDouble {
+    using AB = Analysis2Block<LOG2H>;
+    using F = Fft2<LOG2H>;
+    static constexpr int N = F::N;                 // N' (complex points per transform); the segment has 2 N frames
+    static constexpr int T = F::T;
+    static constexpr int R0 = F::R0;
+    static constexpr int RL = F::RL;
+    static constexpr int S0 = F::S(0);
+    static constexpr int CNT0 = F::CNT(0);
+    using Persist = typename AB::Persist;
+
+    struct Thread {
+        double sumsq;
+        float peak;
+        float lo[2][RL / 2 + 1];       // [mid | side][q]: bin k of (row, q); [RL/2]: bin N'/2 on thread 0
+        float hi[2][RL / 2];           // bin N' - k
+    };
+    static MGX_HD void init(Thread& t) {
+        t.sumsq = 0.0;
+        t.peak = 0.f;
+        MGX_UNROLL
+        for (int c = 0; c < 2; ++c) {
+            MGX_UNROLL
+            for (int q = 0; q <= RL / 2; ++q) t.lo[c][q] = 0.f;
+            MGX_UNROLL
+            for (int q = 0; q < RL / 2; ++q) t.hi[c][q] = 0.f;
+        }
+    }
+    // frames of one segment -> packed mid (SIDE = false: also the level statistics) or side samples, pass 0 -> LDS
+    template <bool SIDE>
+    static MGX_HD void phase_load(int tid, long long start, const AnalysisArgs& a, const Persist& ps, Thread& t,
+                                  float2* lds) {
+        if (!AB::active0(tid)) return;
+        typename F::Tw0Full tw;
+        F::expand_tw0(ps.tw0, tw);
+        const MemView src = mem_view(a.x, a.n * 8);
+        MGX_UNROLL
+        for (int c = 0; c < CNT0; ++c) {
+            const unsigned lane = ((unsigned)start + 2u * (unsigned)(tid + c * T)) * 8u;
+            float2 f0[R0], f1[R0];
+            MGX_UNROLL
+            for (int j = 0; j < R0; ++j) {
+                f0[j] = ld_f2(src, lane, (unsigned)(j * S0 * 16));
+                f1[j] = ld_f2(src, lane, (unsigned)(j * S0 * 16 + 8));
+            }
+            float2 v[R0];
+            float ss = 0.f;
+            MGX_UNROLL
+            for (int j = 0; j < R0; ++j) {
+                float m0, s0, m1, s1;
+                AB::to_ms(f0[j], m0, s0);
+                AB::to_ms(f1[j], m1, s1);
+                v[j] = SIDE ? make_float2(s0, s1) : make_float2(m0, m1);
+                if (!SIDE) {
+                    ss = fmaf(m0, m0, fmaf(m1, m1, ss));
+                    t.peak = fmaxf(t.peak, fmaxf(fmaxf(fabsf(f0[j].x), fabsf(f0[j].y)), fmaxf(fabsf(f1[j].x), fabsf(f1[j].y))));
+                }
+            }
+            if (!SIDE) t.sumsq += (double)ss;
+            F::fwd0_store(v, tid, c, tw, lds);
+        }
+    }
+    // last forward pass on the thread's row; bins go back to LDS in position order (as Analysis2Block)
+    static MGX_HD void phase_row(int tid, float2* lds) {
+        if (!F::has_row(tid)) return;
+        float2 v[RL], w[RL];
+        F::load_row(v, tid, lds);
+        dft_regs<RL, false>(v);
+        MGX_UNROLL
+        for (int q = 0; q < RL; ++q) w[q] = v[bitrev(q, F::lr(F::LAST))];
+        F::store_row(w, tid, lds);
+    }
+    // own lower half + mirror row's upper half -> |A + w^k B| (bin k) and |A - w^k B| (bin N' - k)
+    template <bool SIDE>
+    static MGX_HD void phase_magnitudes(int tid, Thread& t, const float2* lds) {
+        if (!F::has_row(tid)) return;
+        float2 z[RL / 2 + 2], m[RL / 2];
+        F::template load_row_part<0, RL / 2 + 2>(z, tid, lds);
+        F::template load_row_part<RL / 2, RL / 2>(m, F::mirror_row(tid), lds);
+        const bool r0 = tid == 0;
+        const int k0 = F::frequency_at(tid * RL);
+        MGX_UNROLL
+        for (int q = 0; q < RL / 2; ++q) {
+            const float2 a = m[RL / 2 - 1 - q];
+            const float2 b = q == 0 ? z[0] : m[RL / 2 - q];
+            const float2 zm = make_float2(r0 ? b.x : a.x, r0 ? b.y : a.y);
+            // 2A = Z + conj Zm, 2B = (Z - conj Zm) / j
+            const float ax = z[q].x + zm.x, ay = z[q].y - zm.y;
+            const float bx = z[q].y + zm.y, by = -(z[q].x - zm.x);
+            const int k = k0 + q * F::L;
+            float sn, cs;
+            sincos_pi((float)k * (1.0f / (float)N), sn, cs);              // w^k = cs - j sn
+            const float wx = fmaf(cs, bx, sn * by), wy = fmaf(cs, by, -sn * bx);
+            const float px = ax + wx, py = ay + wy, mx = ax - wx, my = ay - wy;
+            t.lo[SIDE][q] += 0.5f * fast_sqrt(fmaf(px, px, py * py));
+            t.hi[SIDE][q] += 0.5f * fast_sqrt(fmaf(mx, mx, my * my));
+        }
+        // k = N'/2 mirrors into itself: A = Re Y, B = Im Y, w^k = -j: |A - jB| = |Y| (meaningful on thread 0 only)
+        t.lo[SIDE][RL / 2] += fast_sqrt(fmaf(z[RL / 2].x, z[RL / 2].x, z[RL / 2].y * z[RL / 2].y));
+    }
+    // frames outside whole segments: RMS (optional) and peak only
+    static MGX_HD void phase_loose_frames(int tid, long long begin, long long end, bool count_rms, const AnalysisArgs& a,
+                                          Thread& t) {
+        for (long long f = begin + tid; f < end; f += T) {
+            const float2 lr = a.x[f];
+            float m, s;
+            AB::to_ms(lr, m, s);
+            if (count_rms) t.sumsq += (double)(m * m);
+            t.peak = fmaxf(t.peak, fmaxf(fabsf(lr.x), fabsf(lr.y)));
+        }
+    }
+    // bins k and N' - k of (row, q < RL/2); wg_spec rows have N' + 1 bins
+    static MGX_HD void phase_write_spectrum(int tid, int wg, const AnalysisArgs& a, const Thread& t) {
+        if (!F::has_row(tid)) return;
+        float* mid = a.wg_spec + (size_t)wg * 2 * (N + 1);
+        float* side = mid + (N + 1);
+        const int k0 = F::frequency_at(tid * RL);
+        MGX_UNROLL
+        for (int q = 0; q < RL / 2; ++q) {
+            const int k = k0 + q * F::L;
+            mid[k] = t.lo[0][q];
+            side[k] = t.lo[1][q];
+            mid[N - k] = t.hi[0][q];
+            side[N - k] = t.hi[1][q];
+        }
+        if (tid == 0) { mid[N / 2] = t.lo[0][RL / 2]; side[N / 2] = t.lo[1][RL / 2]; }
+    }
+};
+
+// ---------------------------------------------------------------------------
 // Scalar epilogue of the analysis (host restatement used by the CPU emulation; the device
 // version is k_levels in mgx_kernels.h).  match_levels.py:62-71,93-103.
 // ---------------------------------------------------------------------------

@@ -192,9 +192,9 @@ static int check_config(const mgx_config* c) {
     if (!c) return fail(MGX_ERR_ARGUMENT, "config is null");
     if (c->internal_sample_rate <= 0) return fail(MGX_ERR_ARGUMENT, "internal_sample_rate must be positive");
     if (ilog2_exact(c->fft_size) < 0) return fail(MGX_ERR_ARGUMENT, "fft_size must be a power of two");
-    if (c->fft_size < 64 || c->fft_size > 16384)
-        return fail(MGX_ERR_UNSUPPORTED, "fft_size outside [64, 16384] is not implemented "
-                                         "(one analysis segment must fit one CU's LDS)");
+    if (c->fft_size < 64 || c->fft_size > 32768)
+        return fail(MGX_ERR_UNSUPPORTED, "fft_size outside [64, 32768] is not implemented "
+                                         "(an analysis segment is one or two transforms that fit one CU's LDS)");
     if (c->rms_correction_steps < 0 || c->rms_correction_steps > 16)   /* CorrectionState::coeffs, the gain words */
         return fail(MGX_ERR_UNSUPPORTED, "rms_correction_steps outside [0, 16]");
     if (c->lowess_it < 0 || c->lowess_it > 64) return fail(MGX_ERR_ARGUMENT, "lowess_it outside [0, 64]");
@@ -224,6 +224,7 @@ static int analysis_workgroups_per_cu(int log2f) {
 #define CASE(L) case L: lds = analysis_lds_bytes<L>(); threads = Fft2<L>::T; break;
         CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
+        case 15: lds = analysis_lds_bytes<14>(); threads = Fft2<14>::T; break;       // two 16384-point transforms per segment
         default: return 1;
     }
     const int by_lds = (int)((size_t)160 * 1024 / lds), by_waves = 2048 / threads;
@@ -305,7 +306,8 @@ static int analysis_args(mgx_handle* h, const float* x, long long n, const mgx_c
     a.wg_sumsq = (double*)w.wg_sumsq.p;
     a.wg_peak = (float*)w.wg_peak.p;
     a.wg_spec = (float*)w.wg_spec.p;
-    return get_twiddles(h, ilog2_exact(cfg->fft_size), &a.tw);
+    // (fft_size 32768 runs on 16384-point transforms: AnalysisDouble)
+    return get_twiddles(h, std::min(14, ilog2_exact(cfg->fft_size)), &a.tw);
 }
 
 // one launch for one track (second == nullptr) or for the target and the reference of a pair
@@ -324,6 +326,13 @@ static int run_analysis(mgx_handle* h, const mgx_config* cfg, const float* x0, l
 #define CASE(L) case L: MGX_TRY(launch_analysis<L>(h, a0, a1, w0.nwg, nwg)); break;
         CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
+        case 15: {
+            const size_t lds = analysis_lds_bytes<14>();
+            MGX_TRY(allow_lds(k_analyze_double<14>, lds));
+            hipLaunchKernelGGL(k_analyze_double<14>, dim3(nwg), dim3(Fft2<14>::T), lds, h->stream, a0, a1, w0.nwg);
+            HIP_TRY(hipGetLastError());
+            break;
+        }
         default: return fail(MGX_ERR_UNSUPPORTED, "fft_size not supported by the analysis kernel");
     }
     return 0;
@@ -415,8 +424,10 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     } else {
         pd = it->second;
     }
-    const bool robust = cfg->lowess_it > 0;      // LOWESS with robustness passes is not linear: no operator
-    if (!robust && !pd.M) {
+    // no operator when LOWESS is not linear (robustness passes), nor when it would not be worth its size:
+    // bins^2 doubles are 2.1 GB at fft_size 32768
+    const bool robust = cfg->lowess_it > 0, direct = robust || plan->bins() > 8193;
+    if (!direct && !pd.M) {
         MGX_TRY(build_fir_operator(h, plan->view(pd.blob), &pd.M, &pd.band));
         h->plan_dev[plan.get()] = pd;
     }
@@ -463,12 +474,16 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
         h->last_taps = cfg->fft_size;
         return 0;
     }
-    if (robust) {
+    if (direct) {
         const size_t lds_scan = (size_t)FirDesign::Scan::SCRATCH * sizeof(Affine);
-        MGX_TRY(ensure(h, h->fir_robust, (size_t)4 * pl.nlog * sizeof(double)));
         hipLaunchKernelGGL(k_fir_direct_a, dim3(2), dim3(1024), lds_scan, h->stream, pl, scratch, (const double*)raw);
-        hipLaunchKernelGGL(k_fir_lowess_robust, dim3(2), dim3(1024), 0, h->stream, pl, scratch, (double*)h->fir_robust.p,
-                           cfg->lowess_it);
+        if (robust) {
+            MGX_TRY(ensure(h, h->fir_robust, (size_t)4 * pl.nlog * sizeof(double)));
+            hipLaunchKernelGGL(k_fir_lowess_robust, dim3(2), dim3(1024), 0, h->stream, pl, scratch,
+                               (double*)h->fir_robust.p, cfg->lowess_it);
+        } else {
+            hipLaunchKernelGGL(k_fir_lowess, dim3((pl.lw.anchors + 15) / 16, 2), dim3(1024), 0, h->stream, pl, scratch);
+        }
         hipLaunchKernelGGL(k_fir_b, dim3(2), dim3(1024), lds_scan, h->stream, pl, scratch);
     } else {
         hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,

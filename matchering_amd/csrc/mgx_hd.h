@@ -188,6 +188,16 @@ MGX_HD void st_stream(float2* p, float2 v) {
 #endif
 }
 
+// sin(pi x), cos(pi x)
+MGX_HD void sincos_pi(float x, float& sn, float& cs) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_HOST_EMU)
+    sincospif(x, &sn, &cs);
+#else
+    sn = (float)sin(3.14159265358979323846 * (double)x);
+    cs = (float)cos(3.14159265358979323846 * (double)x);
+#endif
+}
+
 // sqrt to 1 ulp (v_sqrt_f32) for magnitudes; the library sqrtf adds a denormal-safe refinement
 // sequence that costs ~15 instructions
 MGX_HD float fast_sqrt(float x) {

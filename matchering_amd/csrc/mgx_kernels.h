@@ -342,6 +342,68 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
     }
 }
 
+// fft_size = 2 * Fft2<LOG2H>::N (analysis2_kernel.h, AnalysisDouble): the same grid layout and outputs, two
+// transforms per segment
+template <int LOG2H>
+__global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) void k_analyze_double(AnalysisArgs a0,
+                                                                                                    AnalysisArgs a1,
+                                                                                                    int nwg0) {
+    using AD = AnalysisDouble<LOG2H>;
+    using F = Fft2<LOG2H>;
+    MGX_LDS;
+    float2* lds = reinterpret_cast<float2*>(mgx_smem);
+    float2* mid_table = lds + F::LDS_ELEMS;
+    double* dscratch = reinterpret_cast<double*>(mid_table + F::MID_TABLE);
+    float* fscratch = reinterpret_cast<float*>(dscratch + 8);
+    const bool second = (int)blockIdx.x >= nwg0;                 // uniform
+    const AnalysisArgs& a = second ? a1 : a0;
+    const int tid = threadIdx.x, wg = second ? blockIdx.x - nwg0 : blockIdx.x;
+    const int d = wg / a.chunks_per_piece, ch = wg % a.chunks_per_piece;
+    typename AD::Thread th;
+    AD::init(th);
+    typename AD::Persist ps;
+    AD::AB::load_persist(tid, a.tw, mid_table, ps);
+    __syncthreads();
+    int s0, s1;
+    AD::AB::chunk_segments(a, ch, s0, s1);
+    for (int s = s0; s < s1; ++s) {
+        const long long start = (long long)d * a.piece + (long long)s * 2 * F::N;
+        AD::template phase_load<false>(tid, start, a, ps, th, lds);
+        lds_barrier();
+        if (F::P == 3) {
+            AD::AB::phase_fwd_mid(tid, lds, mid_table);
+            lds_barrier();
+        }
+        AD::phase_row(tid, lds);
+        lds_barrier();
+        AD::template phase_magnitudes<false>(tid, th, lds);
+        lds_barrier();
+        AD::template phase_load<true>(tid, start, a, ps, th, lds);
+        lds_barrier();
+        if (F::P == 3) {
+            AD::AB::phase_fwd_mid(tid, lds, mid_table);
+            lds_barrier();
+        }
+        AD::phase_row(tid, lds);
+        lds_barrier();
+        AD::template phase_magnitudes<true>(tid, th, lds);
+        lds_barrier();
+    }
+    if (ch == a.chunks_per_piece - 1) {
+        AD::phase_loose_frames(tid, (long long)d * a.piece + (long long)a.segs_per_piece * 2 * F::N,
+                               (long long)(d + 1) * a.piece, true, a, th);
+        if (d == a.divisions - 1)
+            AD::phase_loose_frames(tid, (long long)a.divisions * a.piece, a.n, false, a, th);
+    }
+    AD::phase_write_spectrum(tid, wg, a, th);
+    const double ss = block_sum<F::T>(th.sumsq, dscratch);
+    const float pk = block_max<F::T>(th.peak, fscratch);
+    if (tid == 0) {
+        a.wg_sumsq[wg] = ss;
+        a.wg_peak[wg] = pk;
+    }
+}
+
 // ---- piece statistics -> decisions (match_levels.py:62-71,93-103), one 1024-thread workgroup ----
 // Step 1: wave w sums the chunk partials of pieces w, w+16, ... (lanes = chunks) into LDS.
 // Step 2: thread d owns piece d: rms, mean of squares, rms >= average, RMS of the loud ones.

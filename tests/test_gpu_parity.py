@@ -190,6 +190,29 @@ def test_master_long_fir_96k():
         assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
+def test_master_fft_size_32768():
+    """fft_size 32768, the largest supported: analysis segments of two 16384-point transforms
+    (k_analyze_double), the FIR designed on the curve itself (the raw -> smooth operator would be 2 GB), 32 k
+    taps convolved in eight partitions.  192 kHz, where such a size is at home, full pipeline against the
+    oracle; then fft_size 65536 must be refused."""
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd._native import MgxError
+    from matchering_amd.synth import make_pair
+
+    sr = 192000
+    t, r = make_pair(2.0, sr, pair=14, reference_seconds=1.7)
+    kw = dict(internal_sample_rate=sr, fft_size=32768, max_piece_size=0.6)
+    res, res_nl, res_nln = stages.main(t, r, mg.Config(**kw), need_default=True, need_no_limiter=True,
+                                       need_no_limiter_normalized=True)
+    want = mo.master(t, r, mo.params(**kw), True, True, True)
+    for mine, ref in zip((res, res_nl, res_nln), want):
+        assert rms_error(mine, ref) <= RMS_TOL
+        assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    with pytest.raises(MgxError, match="fft_size"):
+        stages.main(t, r, mg.Config(internal_sample_rate=sr, fft_size=65536, max_piece_size=0.6))
+
+
 def test_convolution_identity_and_linearity():
     from matchering_amd import kernels
 
@@ -307,7 +330,7 @@ def test_fails_loudly_on_unsupported():
 
     t, r = build_inputs(CASES["hot_lowrate"])
     with pytest.raises(MgxError):
-        stages.main(t, r, mg.Config(internal_sample_rate=8000, fft_size=32768, max_piece_size=5.0,
+        stages.main(t, r, mg.Config(internal_sample_rate=8000, fft_size=65536, max_piece_size=9.0,
                                     max_length=600))
     # limiter filters of order 3 and up: ill-conditioned in the reference's own form (limiter_general.h)
     with pytest.raises(MgxError, match="orders above 2"):
