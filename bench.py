@@ -13,7 +13,7 @@ Workloads (BASELINE.json configs):
                               the configuration the 40 %-of-roofline target is stated on
   8min_fir_only   configs[1]  the same pair, limiter bypassed (``result_no_limiter`` only)
   4min_x8_full    configs[3]  one GPU's share of "64 four-minute pairs over 8 GPUs": eight pairs per step,
-                              submitted to two device handles (two HIP streams) -- the default for N > 1
+                              submitted to three device handles (three HIP streams) -- the default for N > 1
   96k_16k_full    configs[4]  one 4-minute 96 kHz pair with a 16384-tap FIR (partitioned overlap-save)
 With N ranks every rank masters its own pairs (pairs are independent: no data-path collective, weak
 scaling); the FIR tables are all-gathered over RCCL after the timed region, the only traffic that
@@ -128,7 +128,11 @@ class Workload:
         self.sample_rate, self.fft, self.seconds, self.pairs = 44100, 4096, 480.0, 1
         if name == "4min_x8_full":
             self.seconds, self.pairs = 240.0, 8
-            self.lanes.append(Device(index))
+            # three device handles: a pair's latency-bound stretches (FIR design, level decisions, the limiter's
+            # look-back waits) are filled by the other pairs' kernels -- 2.62 / 2.07 / 1.86 ms with 1 / 2 / 3
+            # handles (tools/lanes_sweep.py); more than six could leave the correction tail's resident grids
+            # waiting for each other
+            self.lanes += [Device(index), Device(index)]
         elif name == "96k_16k_full":
             self.sample_rate, self.fft, self.seconds = 96000, 16384, 240.0
         self.cfg = mg.Config(internal_sample_rate=self.sample_rate, fft_size=self.fft)
@@ -158,7 +162,7 @@ class Workload:
 
     def describe(self):
         if self.name == "4min_x8_full":
-            what = "8 x 240 s stereo 44100 Hz pairs per GPU (config #4's per-GPU share), two device handles"
+            what = "8 x 240 s stereo 44100 Hz pairs per GPU (config #4's per-GPU share), three device handles"
         else:
             what = f"{self.seconds:.0f} s stereo {self.sample_rate} Hz pair per GPU"
         tail = "full pipeline incl. Hyrax limiter" if self.want_limiter else "matching-EQ FIR only (limiter bypassed)"

@@ -105,6 +105,12 @@ _lane_devices = {}
 _lane_devices_lock = threading.Lock()
 
 
+# More lanes than this are not used: k_correction_tail keeps its <= 128 workgroups resident together (48 KB of
+# LDS each: 768 fit the chip), and the tails of seven pairs dispatched side by side could each hold part of
+# the slots and wait for the rest.
+MAX_LANES = 6
+
+
 def lane_device(device_index, lane):
     """The device handle of lane ``lane`` on GPU ``device_index``: created once per process and kept --
     with it its FIR plans, workspaces and recycled HBM blocks, which a batch should not pay for twice."""
@@ -131,7 +137,7 @@ def _device_worker(device_index, lane, config, needs, master, encodings=None):
 
 
 def master_many(pairs, config=None, need_default=True, need_no_limiter=False,
-                need_no_limiter_normalized=False, device_index=0, lanes=2, master=None, on_result=None):
+                need_no_limiter_normalized=False, device_index=0, lanes=3, master=None, on_result=None):
     """``stages.main`` over a list of (target, reference) arrays on ONE GPU, ``lanes`` pairs in flight.
 
     Returns the list of result triples in the order of ``pairs``.  Results are bit-identical to
@@ -149,7 +155,8 @@ def master_many(pairs, config=None, need_default=True, need_no_limiter=False,
         else:
             out[index] = value
 
-    pool = _Lanes(lambda lane: _device_worker(device_index, lane, config, needs, master), max(1, min(lanes, len(pairs) or 1)))
+    pool = _Lanes(lambda lane: _device_worker(device_index, lane, config, needs, master),
+                  max(1, min(lanes, MAX_LANES, len(pairs) or 1)))
     for i, pair in enumerate(pairs):
         pool.submit(i, pair, done)
     pool.close()
@@ -265,7 +272,7 @@ def _save_job(job, triple, config):
         save(wanted.file, chosen, config.internal_sample_rate, wanted.subtype)
 
 
-def process_batch(jobs, config=None, rank=None, world_size=None, device_index=None, lanes=2, io_threads=4,
+def process_batch(jobs, config=None, rank=None, world_size=None, device_index=None, lanes=3, io_threads=4,
                   master=None):
     """``process`` for a list of jobs, this rank's share only.
 
@@ -296,7 +303,8 @@ def process_batch(jobs, config=None, rank=None, world_size=None, device_index=No
                 return workers[key]((target, reference))
             return run
 
-        pool = _Lanes(worker_for, max(1, lanes))
+        lanes = min(max(1, lanes), MAX_LANES)
+        pool = _Lanes(worker_for, lanes)
         # Host memory stays bounded whatever the batch size: at most `io_threads` decoded pairs wait for
         # the lanes (the loaders are started one by one as their predecessors are consumed, and the lane
         # queue is bounded), and at most `lanes + io_threads` mastered triples wait for their writers.
