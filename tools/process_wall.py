@@ -22,7 +22,11 @@ def main():
     ap.add_argument("--seconds", type=float, default=480.0)
     ap.add_argument("--subtype", default="PCM_16")
     ap.add_argument("--runs", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=0,
+                    help="instead: this many pairs through batch.process_batch (three lanes, four I/O threads)")
     args = ap.parse_args()
+    if args.batch:
+        return batch_wall(args)
 
     import matchering_amd as mg
     from matchering_amd import audio_io, core
@@ -65,6 +69,33 @@ def main():
     for p in (tp, rp, op):
         os.remove(p)
     os.rmdir(folder)
+
+
+def batch_wall(args):
+    """Files to files for a batch: loaders, three lanes on the GPU and writers overlap."""
+    import matchering_amd as mg
+    from matchering_amd import audio_io, batch
+    from matchering_amd.synth import make_pair
+
+    folder = tempfile.mkdtemp(prefix="mgx_wall_")
+    jobs, frames = [], 0
+    for k in range(args.batch):
+        target, reference = make_pair(args.seconds, 44100, pair=k % 4)
+        tp, rp, op = (os.path.join(folder, f"{n}{k}.wav") for n in ("target", "reference", "result"))
+        audio_io.write_wav(tp, target * 0.7, 44100, args.subtype)
+        audio_io.write_wav(rp, reference * 0.9, 44100, args.subtype)
+        jobs.append({"target": tp, "reference": rp, "results": [mg.Result(op, args.subtype)]})
+        frames += target.shape[0]
+    print(f"{args.batch} pairs of {args.seconds:.0f} s at 44.1 kHz, {args.subtype} in, {args.subtype} out")
+    for run in range(args.runs):
+        t0 = time.perf_counter()
+        batch.process_batch(jobs, mg.Config(), rank=0, world_size=1)
+        total = time.perf_counter() - t0
+        print(f"run {run}: total {total * 1e3:8.1f} ms = {frames / total / 1e6:7.1f} M frames/s "
+              f"({total / args.batch * 1e3:.1f} ms per pair)")
+    import shutil
+
+    shutil.rmtree(folder, ignore_errors=True)
 
 
 if __name__ == "__main__":
