@@ -211,3 +211,26 @@ def test_gpu_process_batch_two_ranks_share_the_gpu(tmp_path):
         got, _ = audio_io.read_wav(str(tmp_path / f"out{k}.wav"))
         want = mo.master(t, r, mo.params(max_piece_size=2.0), True, False, False)[0]
         assert float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2))) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_six_lanes_side_by_side():
+    """batch.MAX_LANES device handles at once, asked for more: the correction tails' resident grids of six
+    pairs fit the chip side by side, so nothing waits for a workgroup that cannot
+    start; a bounded wait that expired would surface as MgxError.  Results bit-identical to single runs,
+    three batches in a row."""
+    from matchering_amd import stages
+
+    cfg = mg.Config(max_piece_size=3.0)
+    pairs = []
+    for b in range(12):
+        t = (0.5 * synth(12.0 + 0.5 * (b % 3), 44100, 1 + 2 * (b % 4))).astype(np.float32)
+        r = np.clip(2.5 * synth(9.0, 44100, 2 + 2 * (b % 4)), -1, 1).astype(np.float32)
+        pairs.append((t, r))
+    single = [stages.main(t, r, cfg, need_default=True) for t, r in pairs[:4]]
+    for _ in range(3):
+        many = batch.master_many(pairs, cfg, need_default=True, lanes=16)
+        for b, triple in enumerate(many):
+            if b < 4:
+                assert np.array_equal(triple[0], single[b][0])
+            assert np.isfinite(triple[0]).all() and np.abs(triple[0]).max() <= 1.0
