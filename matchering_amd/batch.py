@@ -9,11 +9,12 @@ axis shards without any data-path collective:
   LOCAL_RANK -- and no rank ever talks to another one here;
 * inside a rank: ``lanes`` device handles (each its own HIP stream and workspace) are fed by one
   thread each.  A pair's kernels form a dependent chain with short single-workgroup links (FIR
-  design, level-correction decisions) and its PCIe copies run in one direction at a time; a second
-  lane fills those holes with another pair's work;
-* around the GPU: decoding and encoding of audio files is host work that takes far longer than
-  mastering, so ``process_batch`` keeps ``io_threads`` loaders ahead of the lanes and writes
-  results behind them.
+  design, level-correction decisions, the limiter's look-back waits) and its PCIe copies run in one
+  direction at a time; the other lanes fill those holes with other pairs' work (three by default: eight
+  resident 4-minute pairs take 2.6 / 2.1 / 1.85 ms with one / two / three; ``MAX_LANES`` says why not many);
+* around the GPU: reading and writing audio files is host work, so ``process_batch`` keeps ``io_threads``
+  loaders ahead of the lanes and writes results behind them.  Integer PCM goes to the GPU as the file
+  holds it and comes back quantised (``stages.main``), which leaves the host little more than file I/O.
 
 ``master_many`` works on arrays in memory, ``process_batch`` on files with the reference's
 ``Result`` objects.  Command line (one rank)::
