@@ -2,9 +2,16 @@
 (matchering/core.py:32-121).  The work is split the way this package needs it: two host-side steps
 around the one call that runs on the GPU.
 
-    files --_read_pair--> float arrays at the internal rate --stages.main (MI355X)--> three renderings
+    files --_read_pair--> frames at the internal rate --stages.main (MI355X)--> three renderings
           --_write_results--> files (+ optional previews)
+
+Integer PCM and float32 WAVE files are mapped, not decoded: their samples go to the GPU as the file holds
+them (``mgx_pcm_decode``), the target's peak statistics are taken there (``mgx_peak_count``), and renderings
+come back quantised for the ``Result`` files' subtype (``mgx_pcm_encode``) -- see ``_read_pair`` and
+``_wanted_encodings``.
 """
+
+import os
 
 import numpy as np
 
@@ -34,8 +41,6 @@ def _wanted_renderings(results):
 def _wanted_encodings(results):
     """Per rendering, the PCM subtype the GPU can quantise to directly: every file made from that rendering
     is a WAVE file of one and the same integer subtype (saver.py:27-33 would quantise on the host)."""
-    import os
-
     from .stages import PCM_BITS
 
     wanted = [set(), set(), set()]
