@@ -28,6 +28,17 @@ CASES = {
                     rms_correction_steps=2, lin_log_oversampling=2,
                     limiter=dict(attack=2.5, hold=3.0, release=1000.0,
                                  hold_filter_coefficient=11.0, release_filter_coefficient=600.0))),
+    # what round 2 added to the supported configurations, through the reference itself: LOWESS with two
+    # robustness passes (statsmodels compiled, defaults.py:76) and second-order hold / release filters
+    # (defaults.py:43-47, hyrax.py:55-72)
+    # (second-order sections 1e-5 from z = 1 amplify the last bits in which two scipy versions' butter()
+    # coefficients differ by ~1e5: the restatement under this numpy / scipy and the reference under the conda
+    # interpreter's agree to 5e-11 instead of 1e-11)
+    "robust_second_order": dict(
+        oracle_tolerance=2e-10,
+        seconds=3.0, reference_seconds=2.6, sample_rate=44100, pair=5, reference_gain=3.0,
+        config=dict(fft_size=2048, max_piece_size=0.7, lowess_it=2,
+                    limiter=dict(hold_filter_order=2, release_filter_order=2))),
     # reference whose peak is one short burst: after peak normalisation its RMS is low, the
     # result never reaches the threshold and the limiter early-outs (hyrax.py:83-85)
     "limiter_bypassed": dict(

@@ -53,8 +53,16 @@ def run_reference_py39(target, reference, cfg_kwargs, extra=None):
 
 
 def main():
+    # python tests/golden/make_golden.py [case ...]: only those cases (the manifest keeps the others' entries)
+    only = sys.argv[1:]
     manifest = {}
+    manifest_path = os.path.join(HERE, "MANIFEST.json")
+    if only and os.path.exists(manifest_path):
+        with open(manifest_path) as f:
+            manifest = json.load(f)
     for name, case in CASES.items():
+        if only and name not in only:
+            continue
         target, reference = build_inputs(case)
         ref = run_reference_py39(target, reference, case["config"])
         cfg = oracle_params(case["config"])
@@ -66,7 +74,7 @@ def main():
         worst = max(worst, float(np.abs(trace["fir_mid"] - ref["fir_mid"]).max()),
                     float(np.abs(trace["fir_side"] - ref["fir_side"]).max()))
         print(f"{name}: n={target.shape[0]} oracle-vs-reference max abs diff {worst:.3e}")
-        assert worst <= 1e-11, "oracle restatement disagrees with the reference"
+        assert worst <= case.get("oracle_tolerance", 1e-11), "oracle restatement disagrees with the reference"
 
         idx = sparse_index(target.shape[0])
         out = {
@@ -102,6 +110,10 @@ def main():
         manifest[name] = {"frames": int(target.shape[0]), "oracle_vs_reference_max_abs": worst,
                           "versions": json.loads(str(ref["versions"]))}
 
+    if only:
+        with open(manifest_path, "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     # LOWESS known-answer vector from the compiled statsmodels
     rng = np.random.RandomState(7)
     n = 8193

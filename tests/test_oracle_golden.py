@@ -15,6 +15,11 @@ from cases import CASES, build_inputs, oracle_params
 TIGHT = 1e-11   # float64 restatement vs float64 reference, absolute (full scale = 1)
 
 
+def tight(name):
+    """The bound of a case: 1e-11 unless the case says why it cannot be (cases.py: oracle_tolerance)."""
+    return CASES[name].get("oracle_tolerance", TIGHT)
+
+
 @pytest.fixture(scope="module")
 def runs():
     cache = {}
@@ -44,7 +49,7 @@ def test_outputs_match_reference(name, golden, runs):
     _, _, outs, _ = runs(name)
     idx = g["sparse_index"]
     for key, mine in zip(("result", "result_no_limiter", "result_no_limiter_normalized"), outs):
-        assert np.abs(mine[idx] - g[key + "_sparse"]).max() <= TIGHT, key
+        assert np.abs(mine[idx] - g[key + "_sparse"]).max() <= tight(name), key
         if key + "_f32" in g:
             assert np.abs(mine - g[key + "_f32"]).max() <= 2e-7 * max(1.0, np.abs(mine).max()), key
 
@@ -79,7 +84,7 @@ def test_limiter_envelopes_match_reference(name, golden, runs):
     idx = g["sparse_index"]
     assert np.abs(env.slided[idx] - g["limiter_slided_sparse"]).max() <= TIGHT
     assert np.abs(env.g_att[idx] - g["limiter_gain_attack_sparse"]).max() <= TIGHT
-    assert np.abs(env.g_rel[idx] - g["limiter_gain_release_sparse"]).max() <= TIGHT
+    assert np.abs(env.g_rel[idx] - g["limiter_gain_release_sparse"]).max() <= tight(name)
 
 
 def test_lowess_known_answer(golden):
