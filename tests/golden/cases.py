@@ -39,6 +39,11 @@ CASES = {
         seconds=3.0, reference_seconds=2.6, sample_rate=44100, pair=5, reference_gain=3.0,
         config=dict(fft_size=2048, max_piece_size=0.7, lowess_it=2,
                     limiter=dict(hold_filter_order=2, release_filter_order=2))),
+    # the largest transform: fft_size 32768 at 192 kHz (analysis segments of two 16384-point transforms, the FIR
+    # designed on the curve, 32 k taps in eight partitions)
+    "fft_32768": dict(
+        seconds=1.6, reference_seconds=1.3, sample_rate=192000, pair=6,
+        config=dict(internal_sample_rate=192000, fft_size=32768, max_piece_size=0.5)),
     # reference whose peak is one short burst: after peak normalisation its RMS is low, the
     # result never reaches the threshold and the limiter early-outs (hyrax.py:83-85)
     "limiter_bypassed": dict(
