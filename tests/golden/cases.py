@@ -39,6 +39,14 @@ CASES = {
         seconds=3.0, reference_seconds=2.6, sample_rate=44100, pair=5, reference_gain=3.0,
         config=dict(fft_size=2048, max_piece_size=0.7, lowess_it=2,
                     limiter=dict(hold_filter_order=2, release_filter_order=2))),
+    # limiter timings at both ends of what the kernels handle: a 4-sample attack and hold (frame-by-frame
+    # windows), and an 8 ms attack whose halos need 1024-block chunks
+    "limiter_four_samples": dict(
+        seconds=2.0, reference_seconds=1.8, sample_rate=44100, pair=7, reference_gain=4.0,
+        config=dict(fft_size=1024, max_piece_size=0.5, limiter=dict(attack=0.1, hold=0.1))),
+    "limiter_long_attack": dict(
+        seconds=2.5, reference_seconds=2.0, sample_rate=44100, pair=8, reference_gain=4.0,
+        config=dict(fft_size=1024, max_piece_size=0.6, limiter=dict(attack=8.0, hold=2.0))),
     # the largest transform: fft_size 32768 at 192 kHz (analysis segments of two 16384-point transforms, the FIR
     # designed on the curve, 32 k taps in eight partitions)
     "fft_32768": dict(
