@@ -236,8 +236,11 @@ def main():
     }
 
     # ---- multi-GPU: all-gather the FIR tables over RCCL (off the timed path) ---------------
-    if ranks.world > 1:
-        # (a failing collective is reported in the line, it does not lose the measurement)
+    # A failing collective is reported in the line, it does not lose the measurement -- and neither does one
+    # that never returns: the exchange runs in a thread the main one waits for two minutes at most.
+    exchange = {}
+
+    def exchange_fir_tables():
         try:
             dev = wl.dev
             id_buf = ctypes.create_string_buffer(128)
@@ -254,10 +257,10 @@ def main():
             firs = dev.download(table, (ranks.world, 2, taps.value))
             own = dev.download(int(taps_dev.value), (2, taps.value))
             ok = bool(np.array_equal(firs[ranks.rank], own)) and bool(np.all(np.isfinite(firs)))
-            line["rccl_fir_allgather"] = {"bytes_per_rank": count * 4, "ok": ok}
+            exchange["result"] = {"bytes_per_rank": count * 4, "ok": ok}
             check(lib.mgx_comm_destroy(dev.handle))
         except Exception as exc:       # noqa: BLE001
-            line["rccl_fir_allgather"] = {"ok": False, "error": str(exc)[:200]}
+            exchange["result"] = {"ok": False, "error": str(exc)[:200]}
 
     if ranks.rank == 0:
         # ---- rooflines of the two streaming kernels, timed where they run: inside the pipeline ----
@@ -311,8 +314,20 @@ def main():
         if not args.no_cpu_baseline and ranks.world == 1:
             line["cpu_baseline"] = cpu_baseline(wl, name)
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+    stuck = False
+    if ranks.world > 1:
+        import threading
+
+        worker = threading.Thread(target=exchange_fir_tables, daemon=True)
+        worker.start()
+        worker.join(120.0)
+        stuck = worker.is_alive()
+        line["rccl_fir_allgather"] = ({"ok": False, "error": "no answer within 120 s"} if stuck
+                                      else exchange.get("result", {"ok": False, "error": "no result"}))
     if ranks.rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    if stuck:                       # (a rank still inside the collective would keep the others' teardown waiting)
+        os._exit(0)
     ranks.finish()
 
 
