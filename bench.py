@@ -56,6 +56,9 @@ def parse():
                     help="auto = 8min_full on one GPU, 4min_x8_full per rank on several")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the side workloads and the PCIe figure")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 counter passes that measure the dominant kernels' HBM traffic")
+    ap.add_argument("--no-gpu-state", action="store_true", help="skip the clock / power / partition probe")
     return ap.parse_args()
 
 
@@ -122,17 +125,22 @@ class Workload:
 
     def __init__(self, name, rank, local, mg, Device, device_count, make_pair):
         self.name = name
+        from matchering_amd.batch import choose_lanes, lane_choice_report, lane_device
+
         index = local % max(1, device_count())          # one rank per GPU; wraps only when ranks outnumber GPUs
-        self.dev = Device(index)
+        self.dev = lane_device(index, 0)                 # (the process-wide handles of matchering_amd.batch)
         self.lanes = [self.dev]
+        self.lane_choice = None
         self.sample_rate, self.fft, self.seconds, self.pairs = 44100, 4096, 480.0, 1
         if name == "4min_x8_full":
             self.seconds, self.pairs = 240.0, 8
-            # three device handles: a pair's latency-bound stretches (FIR design, level decisions, the limiter's
-            # look-back waits) are filled by the other pairs' kernels -- 2.62 / 2.07 / 1.86 ms with 1 / 2 / 3
-            # handles (tools/lanes_sweep.py); more than six could leave the correction tail's resident grids
-            # waiting for each other
-            self.lanes += [Device(index), Device(index)]
+            # two or three device handles, whichever a short measured batch says is faster on THIS GPU
+            # (batch.choose_lanes: a pair's latency-bound stretches -- FIR design, level decisions, the
+            # limiter's look-back waits -- are filled by the other pairs' kernels; boxes of the pool disagree
+            # on whether the third handle still pays).  Outside the timed region.
+            count = choose_lanes(index)
+            self.lane_choice = lane_choice_report(index)
+            self.lanes = [lane_device(index, k) for k in range(count)]
         elif name == "96k_16k_full":
             self.sample_rate, self.fft, self.seconds = 96000, 16384, 240.0
         self.cfg = mg.Config(internal_sample_rate=self.sample_rate, fft_size=self.fft)
@@ -162,7 +170,8 @@ class Workload:
 
     def describe(self):
         if self.name == "4min_x8_full":
-            what = "8 x 240 s stereo 44100 Hz pairs per GPU (config #4's per-GPU share), three device handles"
+            what = (f"8 x 240 s stereo 44100 Hz pairs per GPU (config #4's per-GPU share), {len(self.lanes)} device "
+                    f"handles (measured choice)")
         else:
             what = f"{self.seconds:.0f} s stereo {self.sample_rate} Hz pair per GPU"
         tail = "full pipeline incl. Hyrax limiter" if self.want_limiter else "matching-EQ FIR only (limiter bypassed)"
@@ -186,8 +195,52 @@ class Workload:
         for d, t, n, r, nr, out in self.jobs:
             for b in (t, r, out):
                 b.release()
-        for d in self.lanes[1:]:
-            d.close()
+
+
+def measure_traffic(workload, timeout=240):
+    """HBM bytes per launch of the streaming kernels from the L2's memory-side counters, measured NOW: one
+    rocprofv3 pass per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass) over a short run of this same
+    script (rocprofv3 cannot wrap the process it runs in).  MI355X_MICROARCH.md, HBM: FETCH_SIZE is in KiB and
+    counts 64 B per 128-B request on gfx950 (x2); WRITE_SIZE is in KiB, uncorrected (calibrated in
+    profiles/pmc_traffic.json on kernels of known byte counts).  Returns {stage: bytes} or {} when the
+    profiler is not usable here."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+
+    if not shutil.which("rocprofv3"):
+        return {}
+    kib = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        folder = tempfile.mkdtemp(prefix="mgx_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", folder, "-o", "r",
+                   "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-secondary", "--no-traffic", "--no-gpu-state", "--workload", workload]
+            subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+            acc = defaultdict(list)
+            for root, _, files in os.walk(folder):
+                for name in files:
+                    if name.endswith("counter_collection.csv"):
+                        with open(os.path.join(root, name), newline="") as fh:
+                            for row in csv.DictReader(fh):
+                                if row.get("Counter_Name") == counter:
+                                    acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            kib[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+        except Exception:                                   # noqa: BLE001 -- a measurement aid: never lose the line
+            return {}
+        finally:
+            shutil.rmtree(folder, ignore_errors=True)
+    out = {}
+    for stage, pattern in (("convolve", "k_conv<"), ("limit", "k_limit")):
+        fetch = [v for k, v in kib["FETCH_SIZE"].items() if pattern in k]
+        write = [v for k, v in kib["WRITE_SIZE"].items() if pattern in k]
+        if fetch and write:
+            out[stage] = int(max(fetch) * 1024 * 2 + max(write) * 1024)
+    return out
 
 
 def roofline_of(kernel, ms, frames, traffic):
@@ -229,7 +282,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl.describe(), "frames_per_gpu_per_step": wl.frames,
-                   "pairs_per_gpu_per_step": wl.pairs, "parallelism": f"pairs x{ranks.world * wl.pairs}"},
+                   "pairs_per_gpu_per_step": wl.pairs, "parallelism": f"pairs x{ranks.world * wl.pairs}",
+                   **({"lane_choice": wl.lane_choice} if wl.lane_choice else {})},
         "pipeline_hbm_model": {"bytes_per_frame": model, "achieved_GBs": round(pipeline_gbs, 1),
                                "frac_of_8TBs": round(pipeline_gbs / HBM_PEAK_GBS, 4),
                                "frac_of_6p29TBs": round(pipeline_gbs / HBM_COPY_GBS, 4)},
@@ -266,18 +320,25 @@ def main():
         # ---- rooflines of the two streaming kernels, timed where they run: inside the pipeline ----
         stage_ms, n0 = wl.stage_profile(max(5, min(args.steps, 20)))
         line["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
-        pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path) and name in ("8min_full", "8min_fir_only"):
-            with open(pmc_path) as fh:
-                pmc = json.load(fh).get("stages", {})
+        # HBM traffic by the PMC counters, measured in this run (two rocprofv3 passes over a short child run of
+        # the same workload); null when the profiler cannot be used
+        traffic = {} if (args.no_traffic or ranks.world > 1) else measure_traffic(name)
         kernels = [k for k in ("convolve", "limit") if k in stage_ms]
-        per = {k: roofline_of(k, stage_ms[k], n0, pmc.get(k, {}).get("hbm_bytes_per_launch")) for k in kernels}
-        # (profiles/pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE of the same workload, one rocprofv3 pass per
-        # counter -- tools/gpu_pmc.sh; rocprofv3 cannot wrap the process it runs in)
+        per = {k: roofline_of(k, stage_ms[k], n0, traffic.get(k)) for k in kernels}
+        for k in kernels:
+            per[k]["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE (x2, KiB) + --pmc WRITE_SIZE (KiB), one pass each, "
+                                        "child runs of this script in this call" if k in traffic else None)
         dominant = max(kernels, key=lambda k: stage_ms[k])
         line["roofline"] = per[dominant]
         line["roofline_other"] = [per[k] for k in kernels if k != dominant]
+        if not args.no_gpu_state:
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from gpu_state import compact_state
+
+                line["gpu_state"] = compact_state(wl.dev)
+            except Exception as exc:                        # noqa: BLE001
+                line["gpu_state"] = {"error": repr(exc)[:200]}
 
         if not args.no_secondary and ranks.world == 1:
             side = {}
@@ -290,7 +351,7 @@ def main():
                 side[other] = {"value": round(w2.frames / per_step / 1e6, 2), "unit": "Msamples/s",
                                "ms_per_step": round(per_step * 1e3, 4),
                                "frac_of_8TBs": round(PIPELINE_BYTES[other] * w2.frames / per_step / 1e9 / HBM_PEAK_GBS, 4),
-                               "workload": w2.describe()}
+                               "workload": w2.describe(), **({"lane_choice": w2.lane_choice} if w2.lane_choice else {})}
                 w2.release()
             line["other_workloads"] = side
             # host buffers in, host buffers out (PCIe inclusive) -- never the headline value
@@ -312,8 +373,17 @@ def main():
             except Exception as exc:        # noqa: BLE001 -- an unwritable temp folder must not lose the measurement
                 line["file_to_file"] = {"error": repr(exc)}
         if not args.no_cpu_baseline and ranks.world == 1:
-            line["cpu_baseline"] = cpu_baseline(wl, name)
+            line["cpu_baseline"], oracle_out = cpu_baseline(wl, name)
             line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+            # the timed workload's own output (first pair, as the last timed step left it in HBM) against what
+            # the oracle just computed from the same float32 inputs
+            d, t, n, r, nr, out = wl.jobs[0]
+            got = d.download(out, (n, 2)).astype(np.float64)
+            diff = got - oracle_out
+            line["parity"] = {"rms": float(np.sqrt(np.mean(diff * diff))), "max_abs": float(np.abs(diff).max()),
+                              "tolerance_rms": 1e-5, "ok": bool(np.sqrt(np.mean(diff * diff)) <= 1e-5),
+                              "against": "oracle/mastering_oracle.py (float64) on the workload's first pair; the "
+                                         "GPU result is the one the last timed step left in HBM"}
     stuck = False
     if ranks.world > 1:
         import threading
@@ -416,11 +486,13 @@ def cpu_baseline(wl, name):
     ocfg = mo.params(internal_sample_rate=wl.sample_rate, fft_size=wl.fft)
     need = (True, False, False) if wl.want_limiter else (False, True, False)
     runs = []
+    result = None
     t_all = time.perf_counter()
     while len(runs) < 2 or (time.perf_counter() - t_all < 12.0 and len(runs) < 6):
         t0 = time.perf_counter()
-        mo.master(target, reference, ocfg, *need)
+        result = mo.master(target, reference, ocfg, *need)
         runs.append(time.perf_counter() - t0)
+    result = next(r for r in result if r is not None)
     cpu_s = min(runs)
     n = target.shape[0]
     out = {"value": round(n / cpu_s / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
@@ -448,7 +520,7 @@ def cpu_baseline(wl, name):
                                       f"({slowest:.1f} s; each process times its own call of the oracle)"}
     except Exception as exc:           # noqa: BLE001
         out["all_cores"] = {"error": str(exc)[:200]}
-    return out
+    return out, result
 
 
 if __name__ == "__main__":

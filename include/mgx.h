@@ -185,6 +185,19 @@ int mgx_master_with_fir(mgx_handle* h, const float* target_dev, int64_t n_target
                         float* result_no_limiter_dev, float* result_no_limiter_normalized_dev,
                         mgx_report* report);
 
+/* A/B previews (matchering/preview_creator.py:30-94) on frames that are still in HBM.
+ * mgx_window_energy: dsp.py:128-143 (strided_app_2d + batch_rms_2d): sum of squares over both channels of
+ * every window of `size` frames taken every `step` frames (`size` > n: the whole track is the one window);
+ * energy[w] for w < *count (host array of `capacity` doubles); the loudest window is the argmax (the square
+ * root and the mean of dsp.py:80-86 are monotone).  Waits for the stream.
+ * mgx_preview_cut: frames [begin, begin + size) clipped to +-clip_limit (dsp.py:109-110; <= 0: not clipped)
+ * and faded in and out over `fade` frames (dsp.py:146-152, numpy.linspace(0, 1, fade)), written to
+ * out_dev [size][2]; queued on the handle's stream. */
+int mgx_window_energy(mgx_handle* h, const float* x_dev, int64_t n, int64_t size, int64_t step, double* energy,
+                      int64_t capacity, int64_t* count);
+int mgx_preview_cut(mgx_handle* h, const float* x_dev, int64_t n, int64_t begin, int64_t size, int64_t fade,
+                    double clip_limit, float* out_dev);
+
 /* Measurement aid (bench.py): with timing enabled, mgx_master brackets each of
  * its stages with HIP events recorded on the handle's own stream (no synchronisation is added);
  * mgx_stage_times waits for the stream and returns the device time of every stage of the LAST
@@ -204,6 +217,15 @@ enum mgx_stage {
 };
 int mgx_stage_timing(mgx_handle* h, int32_t enable);
 int mgx_stage_times(mgx_handle* h, float* ms /* [MGX_STAGE_COUNT] */);
+
+/* Measurement aid (bench.py `gpu_state`): the shader clock a kernel actually runs at.  Launches
+ * `workgroups` x 256 threads that each issue `iterations` dependent FMAs; one wave reads the shader
+ * cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) before and after.
+ * out[0] = shader cycles, out[1] = 100 MHz ticks, out[2] = shader MHz = 100 * out[0] / out[1],
+ * out[3] = kernel time in ms by HIP events.  workgroups = 1 probes a nearly idle chip, a few
+ * thousand a chip whose every SIMD issues VALU.  No reference counterpart: the boxes of a pool differ
+ * in the clocks they sustain, and a throughput figure means little without them. */
+int mgx_clock_probe(mgx_handle* h, int32_t workgroups, int32_t iterations, double* out /* [4] */);
 
 /* Device address of the FIR pair ([2][fft_size] float32: mid taps then side taps, level gain
  * not included) designed by the last mgx_master / uploaded by the last mgx_convolve on this

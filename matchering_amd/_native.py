@@ -98,6 +98,7 @@ SYMBOLS = {
     "mgx_memcpy_d2h_async": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_size_t]),
     "mgx_stage_timing": (ctypes.c_int, [_VP, ctypes.c_int32]),
     "mgx_stage_times": (ctypes.c_int, [_VP, c_float_p]),
+    "mgx_clock_probe": (ctypes.c_int, [_VP, ctypes.c_int32, ctypes.c_int32, c_double_p]),
     "mgx_clipped_piece_sumsq": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                                ctypes.c_double, c_double_p]),
     "mgx_limit": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.POINTER(MgxConfig), ctypes.c_double,
@@ -106,6 +107,10 @@ SYMBOLS = {
     "mgx_peak_count": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, c_double_p, ctypes.POINTER(ctypes.c_int64)]),
     "mgx_pcm_decode": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int32, _VP]),
     "mgx_pcm_encode": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int32, _VP]),
+    "mgx_window_energy": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, c_double_p,
+                                         ctypes.c_int64, c_int64_p]),
+    "mgx_preview_cut": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_double, _VP]),
     "mgx_last_fir": (ctypes.c_int, [_VP, ctypes.POINTER(_VP), c_int32_p]),
     "mgx_comm_unique_id": (ctypes.c_int, [_VP]),
     "mgx_comm_init": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),

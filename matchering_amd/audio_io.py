@@ -86,6 +86,8 @@ def _wav_layout(path):
                     code = struct.unpack("<H", fmt[24:26])[0]       # first two bytes of the sub-format GUID
                 if channels < 1 or block < 1:
                     raise RuntimeError("Format not recognised: bad channel count")
+                if code in (_PCM, _FLOAT) and block != channels * ((bits + 7) // 8):
+                    raise RuntimeError(f"Format not recognised: block size {block} for {channels} channel(s) of {bits} bits")
                 return code, channels, int(rate), block, bits, pos + 8, min(size, size_of_file - pos - 8)
             pos += 8 + size + (size & 1)
     raise RuntimeError("Format not recognised: missing fmt or data chunk")
@@ -342,11 +344,27 @@ def write_aiff(path, array, sample_rate, subtype):
         fh.write(b"FORM" + struct.pack(">I", 4 + len(chunks)) + form + chunks)
 
 
+def _native_wave(path):
+    """True for the WAVE layouts ``read_wav`` decodes itself (and can hand on undecoded): integer PCM of 8,
+    16, 24 or 32 bits, FLOAT of 32 or 64.  Everything else libsndfile reads -- A-law, mu-law, ADPCM, GSM,
+    odd containers -- stays with libsndfile when it is installed (loader.py:35)."""
+    try:
+        code, _, _, _, bits, _, _ = _wav_layout(path)
+    except (RuntimeError, OSError, struct.error, ValueError):
+        return False
+    return (code == _PCM and bits in (8, 16, 24, 32)) or (code == _FLOAT and bits in (32, 64))
+
+
 def _read(path, pcm=False):
     with open(path, "rb") as fh:
         magic = fh.read(12)
-    if magic[:4] == b"RIFF" and magic[8:12] == b"WAVE" and (pcm or _sf is None):
-        return read_wav(path, pcm)
+    wave = magic[:4] == b"RIFF" and magic[8:12] == b"WAVE"
+    if wave and (_sf is None or (pcm and _native_wave(path))):
+        try:
+            return read_wav(path, pcm)
+        except (ValueError, struct.error) as exc:          # a header that lies about its sizes
+            if _sf is None:
+                raise RuntimeError(f"Format not recognised: {exc}") from exc
     if _sf is not None:
         return _sf.read(path, always_2d=True)
     if magic[:4] == b"FORM" and magic[8:12] in (b"AIFF", b"AIFC"):

@@ -112,6 +112,79 @@ _lane_devices_lock = threading.Lock()
 MAX_LANES = 6
 
 
+_lane_choice = {}
+
+
+def lanes_allowed(world_size=1):
+    """MAX_LANES is a budget per GPU, not per process: ranks that share one GPU split it."""
+    from .device import device_count
+
+    sharing = max(1, -(-int(world_size) // max(1, device_count())))
+    return max(1, MAX_LANES // sharing)
+
+
+def choose_lanes(device_index=0, candidates=(2, 3), seconds=120.0, pairs=4, master=None):
+    """How many device handles a batch should run on THIS GPU: measured, once per process and GPU.
+
+    Boxes of the pool disagree: on some, three handles beat two by 10 % (1.87 vs 2.11 ms for eight resident
+    4-minute pairs), on others three LOSE to two by 13 % (2.93 vs 2.60 ms; profiles/r02_lanes.txt,
+    profiles/r02_g_bench_slow_box.json, BENCH_r02.json) -- so the number is not a constant of the code.  A
+    short synthetic batch (``pairs`` resident pairs of ``seconds`` each, full pipeline) is timed through
+    each candidate count and the fastest wins; the decision and both timings are kept in
+    ``lane_choice_report(device_index)``.  Costs ~1 s of host time for the synthetic material and a few
+    milliseconds of GPU time."""
+    if master is not None:                       # a stand-in for the GPU (CPU tests): nothing to measure
+        return min(candidates[-1], MAX_LANES)
+    with _lane_devices_lock:
+        if device_index in _lane_choice:
+            return _lane_choice[device_index]["lanes"]
+    import time
+
+    from .synth import make_pair
+
+    native = Config().to_native()
+    host = [make_pair(seconds, 44100, pair=300 + k) for k in range(pairs)]
+    timings = {}
+    for count in candidates:
+        devs = [lane_device(device_index, lane) for lane in range(count)]
+        jobs = []
+        for k, (t, r) in enumerate(host):
+            d = devs[k % count]
+            jobs.append((d, d.upload(t), t.shape[0], d.upload(r), r.shape[0], d.alloc(t.shape[0] * 8)))
+
+        def step():
+            for d, t, n, r, nr, out in jobs:
+                d.master(t, n, r, nr, native, result=out, want_report=False)
+
+        def sync():
+            for d in devs:
+                d.synchronize()
+
+        step()
+        sync()
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            step()
+            step()
+            sync()
+            took = (time.perf_counter() - t0) / 2
+            best = took if best is None else min(best, took)
+        timings[count] = best
+        for d, t, n, r, nr, out in jobs:
+            for b in (t, r, out):
+                b.release()
+    chosen = min(timings, key=timings.get)
+    with _lane_devices_lock:
+        _lane_choice[device_index] = {"lanes": chosen, "ms_per_batch": {str(k): round(v * 1e3, 3) for k, v in timings.items()},
+                                      "batch": f"{pairs} resident pairs of {seconds:.0f} s"}
+    return chosen
+
+
+def lane_choice_report(device_index=0):
+    return dict(_lane_choice.get(device_index, {}))
+
+
 def lane_device(device_index, lane):
     """The device handle of lane ``lane`` on GPU ``device_index``: created once per process and kept --
     with it its FIR plans, workspaces and recycled HBM blocks, which a batch should not pay for twice."""
@@ -138,8 +211,9 @@ def _device_worker(device_index, lane, config, needs, master, encodings=None):
 
 
 def master_many(pairs, config=None, need_default=True, need_no_limiter=False,
-                need_no_limiter_normalized=False, device_index=0, lanes=3, master=None, on_result=None):
-    """``stages.main`` over a list of (target, reference) arrays on ONE GPU, ``lanes`` pairs in flight.
+                need_no_limiter_normalized=False, device_index=0, lanes=None, master=None, on_result=None):
+    """``stages.main`` over a list of (target, reference) arrays on ONE GPU, ``lanes`` pairs in flight
+    (``None``: as many as ``choose_lanes`` measures to be best on this GPU).
 
     Returns the list of result triples in the order of ``pairs``.  Results are bit-identical to
     calling ``stages.main`` pair by pair: lanes only change when work is submitted, never what is
@@ -156,6 +230,8 @@ def master_many(pairs, config=None, need_default=True, need_no_limiter=False,
         else:
             out[index] = value
 
+    if lanes is None:
+        lanes = choose_lanes(device_index, master=master) if len(pairs) > 2 else 2
     pool = _Lanes(lambda lane: _device_worker(device_index, lane, config, needs, master),
                   max(1, min(lanes, MAX_LANES, len(pairs) or 1)))
     for i, pair in enumerate(pairs):
@@ -273,7 +349,7 @@ def _save_job(job, triple, config):
         save(wanted.file, chosen, config.internal_sample_rate, wanted.subtype)
 
 
-def process_batch(jobs, config=None, rank=None, world_size=None, device_index=None, lanes=3, io_threads=4,
+def process_batch(jobs, config=None, rank=None, world_size=None, device_index=None, lanes=None, io_threads=4,
                   master=None):
     """``process`` for a list of jobs, this rank's share only.
 
@@ -304,7 +380,9 @@ def process_batch(jobs, config=None, rank=None, world_size=None, device_index=No
                 return workers[key]((target, reference))
             return run
 
-        lanes = min(max(1, lanes), MAX_LANES)
+        if lanes is None:
+            lanes = choose_lanes(device_index, master=master) if len(mine) > 2 else 2
+        lanes = min(max(1, lanes), MAX_LANES if master is not None else lanes_allowed(w))
         pool = _Lanes(worker_for, lanes)
         # Host memory stays bounded whatever the batch size: at most `io_threads` decoded pairs wait for
         # the lanes (the loaders are started one by one as their predecessors are consumed, and the lane

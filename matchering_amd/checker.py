@@ -103,7 +103,10 @@ def check(array: np.ndarray, sample_rate: int, config: Config, name: str, peaks=
 
     if sample_rate != config.internal_sample_rate:
         debug(f"{name}: converting {sample_rate} Hz -> {config.internal_sample_rate} Hz")
-        array = _resample(pcm_to_float(array, np.float64), sample_rate, config.internal_sample_rate)
+        # float64 like the arrays soundfile hands the reference's resampler (checker.py:42), also for files
+        # that arrive as float32 (FLOAT WAVE, 8-bit PCM)
+        array = _resample(np.asarray(pcm_to_float(array, np.float64), dtype=np.float64), sample_rate,
+                          config.internal_sample_rate)
         if target:
             warning(Code.WARNING_TARGET_IS_RESAMPLED)
         else:

@@ -19,7 +19,7 @@ from .audio_io import load, pcm_channels, pcm_to_float, save
 from .checker import check, check_equality
 from .config import Config
 from .log import Code, ModuleError, debug, debug_line, info
-from .preview import create_preview
+from .preview import PreviewRequest, create_preview, save_previews
 from .results import Result
 from .stages import main
 from .utils import get_temp_folder
@@ -49,6 +49,15 @@ def _wanted_encodings(results):
         wave = os.path.splitext(item.file)[1][1:].upper() in ("WAV", "WAVE")
         wanted[slot].add(item.subtype if wave and item.subtype in PCM_BITS else None)
     return tuple(next(iter(w)) if len(w) == 1 else None for w in wanted)
+
+
+def _file_encoding(item):
+    """The integer subtype of one WAVE file (quantised on the GPU), or None (float frames, host codec)."""
+    from .stages import PCM_BITS
+
+    if item is None or os.path.splitext(item.file)[1][1:].upper() not in ("WAV", "WAVE"):
+        return None
+    return item.subtype if item.subtype in PCM_BITS else None
 
 
 def _gpu():
@@ -108,6 +117,13 @@ def _read_pair(target_path, reference_path, config, temp_folder):
     return target, reference, resident
 
 
+def _same_file(a, b):
+    try:
+        return os.path.exists(a) and os.path.samefile(a, b)
+    except OSError:
+        return False
+
+
 def _write_results(results, renderings, sample_rate):
     """One file per Result, each from the rendering it asked for (core.py:95-108)."""
     limited, plain, normalized = renderings
@@ -128,19 +144,31 @@ def process(target: str, reference: str, results: list, config: Config = None,
 
     target_audio, reference_audio, resident = _read_pair(target, reference, config, temp_folder)
     previews = bool(preview_target or preview_result)
-    # (previews are cut from float frames: with them the renderings stay float and the files are quantised
-    # on the host)
-    encodings = None if previews else _wanted_encodings(results)
+    # With a GPU the previews are cut on it from the frames stages.main leaves in HBM (preview.PreviewRequest):
+    # only the two 30 s pieces cross PCIe, and the renderings keep their integer encodings.  Without one (the
+    # CPU tests put a stand-in behind ``main``) they are cut from float renderings on the host.
+    request = None
+    if previews and _gpu() is not None:
+        request = PreviewRequest(config, preview_target, preview_result,
+                                 (_file_encoding(preview_target), _file_encoding(preview_result)))
+    encodings = None if (previews and request is None) else _wanted_encodings(results)
+    extra = {"preview": request} if request is not None else {}
     renderings = main(resident[0] if resident[0] is not None else target_audio,
                       resident[1] if resident[1] is not None else reference_audio,
-                      config, *_wanted_renderings(results), encodings=encodings)      # (releases the resident frames)
+                      config, *_wanted_renderings(results), encodings=encodings, **extra)   # (releases the resident frames)
     del reference_audio
 
     debug_line()
     info(Code.INFO_EXPORTING)
+    if previews and request is None and any(_same_file(item.file, target) for item in results):
+        # the target may be a read-only mapping of its file (audio_io.read_wav): a result written over that
+        # file would pull the mapping from under the preview cut below
+        target_audio = np.array(target_audio, copy=True)
     _write_results(results, renderings, config.internal_sample_rate)
 
-    if previews:
+    if request is not None:
+        save_previews(request, config, preview_target, preview_result)
+    elif previews:
         mastered = next(audio for audio in renderings if audio is not None)
         create_preview(pcm_to_float(target_audio), mastered, config, preview_target, preview_result)
 

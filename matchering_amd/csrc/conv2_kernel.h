@@ -26,6 +26,10 @@
 
 #include "fft2.h"
 
+#if defined(__clang__) && !defined(MGX_NO_FP_CONTRACT)
+#pragma clang fp contract(fast)        // see fft2.h
+#endif
+
 namespace mgx {
 
 // Cache policy of the streaming accesses (aux bits of the buffer instructions: 2 = nt).  The output is
@@ -336,3 +340,7 @@ struct Conv2Block {
 };
 
 }  // namespace mgx
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif

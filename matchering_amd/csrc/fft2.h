@@ -33,6 +33,15 @@
 
 #include "mgx_hd.h"
 
+// The library is built with -ffp-contract=off (build.py): float64 sums and the host emulation are to
+// round like the plain expressions read.  The float32 butterflies of this file are the exception: a
+// multiply feeding an add may fuse (a sqrt(1/2) rotation into the butterfly that follows it: 4 % fewer
+// VALU instructions in k_conv, 160 -> 154.5 us, profiles/r03_a_fp_contract.txt), results stay within
+// 1e-7 of the unfused ones.  Scoped to this file and conv2_kernel.h.
+#if defined(__clang__) && !defined(MGX_NO_FP_CONTRACT)
+#pragma clang fp contract(fast)
+#endif
+
 namespace mgx {
 
 // (cos, sin)(2 pi k / 32)
@@ -390,3 +399,7 @@ struct Fft2 {
 };
 
 }  // namespace mgx
+
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif

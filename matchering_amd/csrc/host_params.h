@@ -128,6 +128,12 @@ inline std::vector<double> lookback_matrices(int k, const std::vector<Wide>& m, 
     return std::vector<double>();
 }
 
+// What is left of the backward attack smoother's state after the right halo, relative to the state (gains
+// are <= 1, so this bounds the error of gA at the core's last frame; it falls off by rho per frame before it).
+#ifndef MGX_ATTACK_FORGET
+#define MGX_ATTACK_FORGET 1e-8
+#endif
+
 struct LimiterParams {
     int attack, hold, hw, hb, ha;
     // hold / release filters of order > 1 (limiter_general.h): general = max order, 0 when both are first order
@@ -186,8 +192,8 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
     // geometry does not depend on them)
     p.hold_f = butter1(c.hold_filter_coefficient, sr);
     p.rel_f = butter1(c.release_filter_coefficient / c.release_ms, sr);
-    // frames after which the attack smoother has forgotten its state (rho^ha <= 1e-8)
-    p.ha = (int)std::ceil(std::log(1e-8) / std::log(rho));
+    // frames after which the attack smoother has forgotten its state (rho^ha <= MGX_ATTACK_FORGET)
+    p.ha = (int)std::ceil(std::log(MGX_ATTACK_FORGET) / std::log(rho));
     // 256 blocks per chunk while the halos leave at least a quarter of them to the core, else 1024
     p.threads = 256;
     p.geo = LimiterBlock<256>::geometry(p.hw, p.hb, p.ha);

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -67,7 +68,14 @@ struct PlanDev {
     void* blob = nullptr;       // FirPlanHost tables
     double* M = nullptr;        // [bins][bins] raw -> smooth operator
     int2* band = nullptr;       // [bins] columns [x, y) of each row that matter (k_fir_band)
+    std::shared_ptr<FirPlanHost> plan;      // keeps the host tables alive as long as the device copy
 };
+// One copy per (device, Config's design parameters) for the whole process, not per handle: the operator
+// is bins^2 doubles (34 MB at fft_size 4096, 537 MB at 16384), and the three device handles a batch runs
+// on one GPU (batch.py) would otherwise each build and hold their own.  Entries live as long as the
+// process: a handle that is destroyed may leave kernels of its siblings reading them.
+static std::mutex g_plan_mu;
+static std::map<std::pair<int, const FirPlanHost*>, PlanDev> g_plan_dev;
 
 struct mgx_handle {
     int device = 0;
@@ -86,10 +94,13 @@ struct mgx_handle {
     DevBuf lim_tables;                      // general filter orders: matrix powers and look-back matrices
     std::vector<double> lim_tables_host;
     DevBuf fir_scratch;
-    std::map<const FirPlanHost*, PlanDev> plan_dev;               // uploaded plan blobs + dense operators
-    std::vector<std::shared_ptr<FirPlanHost>> plans;              // keeps the host plans alive
     void* pinned = nullptr;
     size_t pinned_bytes = 0;
+    // set by a kernel whose bounded wait expired (limiter look-back, level-correction round): one word of
+    // page-locked host memory the kernels write through its device address, so that every blocking call
+    // can look at it for free once the stream has drained
+    int* error_host = nullptr;
+    int* error_dev = nullptr;
     int last_taps = 0;
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
@@ -414,22 +425,22 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     FirDesignParams p{cfg->fft_size, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac,
                       cfg->lowess_it, cfg->lowess_delta, cfg->min_value};
     std::shared_ptr<FirPlanHost> plan = FirPlanHost::get(p);
-    PlanDev pd;
-    auto it = h->plan_dev.find(plan.get());
-    if (it == h->plan_dev.end()) {
-        HIP_TRY(hipMalloc(&pd.blob, plan->blob_bytes()));
-        HIP_TRY(hipMemcpy(pd.blob, plan->blob(), plan->blob_bytes(), hipMemcpyHostToDevice));
-        h->plan_dev[plan.get()] = pd;
-        h->plans.push_back(plan);
-    } else {
-        pd = it->second;
-    }
     // no operator when LOWESS is not linear (robustness passes), nor when it would not be worth its size:
     // bins^2 doubles are 2.1 GB at fft_size 32768
     const bool robust = cfg->lowess_it > 0, direct = robust || plan->bins() > 8193;
-    if (!direct && !pd.M) {
-        MGX_TRY(build_fir_operator(h, plan->view(pd.blob), &pd.M, &pd.band));
-        h->plan_dev[plan.get()] = pd;
+    PlanDev pd;
+    {
+        // (the first handle to need an operator builds it on its own stream and waits for it; its siblings
+        // wait here and find it complete)
+        std::lock_guard<std::mutex> lock(g_plan_mu);
+        PlanDev& shared = g_plan_dev[std::make_pair(h->device, (const FirPlanHost*)plan.get())];
+        if (!shared.blob) {
+            HIP_TRY(hipMalloc(&shared.blob, plan->blob_bytes()));
+            HIP_TRY(hipMemcpy(shared.blob, plan->blob(), plan->blob_bytes(), hipMemcpyHostToDevice));
+            shared.plan = plan;
+        }
+        if (!direct && !shared.M) MGX_TRY(build_fir_operator(h, plan->view(shared.blob), &shared.M, &shared.band));
+        pd = shared;
     }
     const FirPlanView pl = plan->view(pd.blob);
     const size_t per = (size_t)3 * pl.bins + (size_t)3 * pl.nlog + pl.lw.anchors;
@@ -489,11 +500,11 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
         hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
                            (const int2*)pd.band, (const double*)raw, scratch);
     }
-    const size_t lds_taps = ((size_t)pl.bins + 1024) * sizeof(double);
-    if (pl.fft < TAPS_PER_WG) return fail(MGX_ERR_UNSUPPORTED, "fft_size below 64 is not implemented");
+    const size_t lds_taps = ((size_t)pl.bins + 2048 + 2 * TAP_ROWS) * sizeof(double);
+    if (pl.fft < 64) return fail(MGX_ERR_UNSUPPORTED, "fft_size below 64 is not implemented");
     MGX_TRY(allow_lds(k_fir_taps, lds_taps));
-    hipLaunchKernelGGL(k_fir_taps, dim3(pl.fft / TAPS_PER_WG, 2), dim3(1024), lds_taps, h->stream, pl,
-                       (const double*)scratch, (float*)h->taps.p);
+    hipLaunchKernelGGL(k_fir_taps, dim3((pl.fft / 4 + 1 + TAP_ROWS - 1) / TAP_ROWS, 2), dim3(1024), lds_taps, h->stream,
+                       pl, (const double*)scratch, (float*)h->taps.p);
     HIP_TRY(hipGetLastError());
     h->last_taps = cfg->fft_size;
     return 0;
@@ -533,16 +544,21 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
 }
 
 // taps_dev: [2][F] float (mid then side) already on the device.  F <= 8192: one overlap-save block of
-// N = 2F per filter; longer filters (config #5: 16 k taps at 96 kHz) are cut into K = F/4096
-// partitions on N = 8192 blocks (uniformly partitioned overlap-save), because N = 2F no longer fits
-// a CU's LDS.
+// N = 2F per filter; longer filters (config #5: 16 k taps at 96 kHz) are cut into K = F/8192
+// partitions on N = 16384 blocks (uniformly partitioned overlap-save), because N = 2F no longer fits
+// a CU's LDS.  (Round 2 used K = F/4096 partitions on N = 8192 blocks: K + 1 transforms of 8192 points
+// per channel and 8192 output frames, 325 flop per frame and channel; K/2 + 1 of 16384 points per 16384
+// frames are 210.)
+#ifndef MGX_LONG_FIR_LOG2N
+#define MGX_LONG_FIR_LOG2N 14
+#endif
 static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const float* taps_dev, double gain,
                     float* y, float* ymid, long long* npairs_out, const double* gain_ptr = nullptr) {
     const int l = ilog2_exact(taps);
     if (l < 0) return fail(MGX_ERR_ARGUMENT, "FIR length must be a power of two");
     MGX_TRY(check_length(n));
     int log2b = l + 1;
-    if (log2b > 14) log2b = 13;
+    if (log2b > 14) log2b = MGX_LONG_FIR_LOG2N;
     const size_t nb = (size_t)1 << log2b;
     const int parts = (int)((size_t)2 * taps / nb);
     const long long pair_frames = (long long)nb;
@@ -559,7 +575,7 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     a.pair_peak = nullptr;
     MGX_TRY(get_twiddles(h, log2b, &a.tw));
     if (npairs_out) *npairs_out = a.npairs;
-    if (parts > 1) return launch_conv<13, true>(h, a, taps_dev, gain, gain_ptr);
+    if (parts > 1) return launch_conv<MGX_LONG_FIR_LOG2N, true>(h, a, taps_dev, gain, gain_ptr);
     switch (log2b) {
 #define CASE(L) case L: return launch_conv<L, false>(h, a, taps_dev, gain, gain_ptr);
         CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
@@ -674,10 +690,10 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     MGX_TRY(ensure_ctrl(h));
     a.published = (unsigned long long*)h->lim_published.p;
     a.ticket = (int*)h->lim_ctrl.p;
-    a.error = a.ticket + 1;
+    a.error = h->error_dev;
     if (!preset_done) {
         HIP_TRY(hipMemsetAsync(h->lim_published.p, 0xff, pub_bytes, h->stream));
-        HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 4, h->stream));   // ticket only: a raised error sticks
+        HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 4, h->stream));
     }
     switch (lp.general) {
         case 0: return launch_limiter(h, a, threads);
@@ -685,16 +701,20 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     }
 }
 
-// a look-back wait expired (never seen; the spin is bounded so that a lost chunk cannot hang the GPU)
-static int check_limiter_error(mgx_handle* h) {
-    if (!h->lim_ctrl.p) return 0;
-    int flags[2] = {0, 0};
-    HIP_TRY(hipMemcpy(flags, h->lim_ctrl.p, sizeof(flags), hipMemcpyDeviceToHost));
-    if (flags[1] != 0) {
-        HIP_TRY(hipMemset((int*)h->lim_ctrl.p + 1, 0, 4));
-        return fail(MGX_ERR_HIP, "a bounded device-side wait expired (limiter look-back or level-correction round)");
-    }
-    return 0;
+// A bounded device-side wait expired (never seen in normal operation; the spins are bounded so that a lost
+// word cannot hang the GPU, and the audio behind such a wait is wrong).  Called by every entry point that
+// has just waited for the stream -- with or without a report -- so that the failure cannot pass silently;
+// the flag is host memory, reading it costs nothing.  The counters a timed-out kernel may have left
+// half-counted are put back, so the handle is good for the next call.
+static int check_device_error(mgx_handle* h) {
+    if (!h->error_host || *(volatile int*)h->error_host == 0) return 0;
+    *(volatile int*)h->error_host = 0;
+    if (h->round_ctr.p) HIP_TRY(hipMemsetAsync(h->round_ctr.p, 0, h->round_ctr.bytes, h->stream));
+    if (h->lim_ctrl.p) HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 64, h->stream));
+    if (h->conv_queue.p) HIP_TRY(hipMemsetAsync(h->conv_queue.p, 0, 64, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return fail(MGX_ERR_HIP, "a bounded device-side wait expired (limiter look-back or level-correction round): "
+                             "the results of the calls since the last synchronisation are not valid");
 }
 
 // ---------------------------------------------------------------------------
@@ -753,6 +773,9 @@ int mgx_create(int device, mgx_handle** out) {
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
+    HIP_TRY(hipHostMalloc((void**)&h->error_host, 64, hipHostMallocMapped));
+    std::memset(h->error_host, 0, 64);
+    HIP_TRY(hipHostGetDevicePointer((void**)&h->error_dev, h->error_host, 0));
     *out = h;
     return 0;
 }
@@ -773,12 +796,8 @@ int mgx_destroy(mgx_handle* h) {
             if (b->p) hipFree(b->p);
     }
     for (auto& kv : h->twiddles) hipFree(kv.second);
-    for (auto& kv : h->plan_dev) {
-        if (kv.second.blob) hipFree(kv.second.blob);
-        if (kv.second.M) hipFree(kv.second.M);
-        if (kv.second.band) hipFree(kv.second.band);
-    }
     if (h->pinned) hipHostFree(h->pinned);
+    if (h->error_host) hipHostFree(h->error_host);
     hipEventDestroy(h->ev0);
     hipEventDestroy(h->ev1);
     for (auto& pair : h->stage_ev)
@@ -812,7 +831,7 @@ int mgx_memcpy_d2h(mgx_handle* h, void* host, const void* dev, size_t bytes) {
     if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
     HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return 0;
+    return check_device_error(h);
 }
 // pinned host memory + copies that do not wait: the pieces of an overlapped host <-> HBM pipeline
 int mgx_host_alloc(size_t bytes, void** host) {
@@ -838,7 +857,7 @@ int mgx_memcpy_d2h_async(mgx_handle* h, void* host, const void* dev, size_t byte
 int mgx_synchronize(mgx_handle* h) {
     if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return 0;
+    return check_device_error(h);
 }
 int mgx_timer_start(mgx_handle* h) {
     if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
@@ -850,7 +869,7 @@ int mgx_timer_stop(mgx_handle* h, float* ms) {
     HIP_TRY(hipEventRecord(h->ev1, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev1));
     HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
-    return 0;
+    return check_device_error(h);
 }
 
 // ---- stage level -----------------------------------------------------------
@@ -975,7 +994,7 @@ int mgx_limit(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cf
     CorrectionState host_cs;
     HIP_TRY(hipMemcpyAsync(&host_cs, cs, sizeof(host_cs), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    MGX_TRY(check_limiter_error(h));
+    MGX_TRY(check_device_error(h));
     if (active) *active = host_cs.limiter_active;
     return 0;
 }
@@ -1011,6 +1030,47 @@ int mgx_peak_count(mgx_handle* h, const float* x_dev, int64_t samples, double* p
     std::memcpy(&f, &bits, 4);
     *peak = (double)f;
     *count = (int64_t)host[1];
+    return 0;
+}
+
+int mgx_window_energy(mgx_handle* h, const float* x_dev, int64_t n, int64_t size, int64_t step, double* energy,
+                      int64_t capacity, int64_t* count) {
+    if (!h || !x_dev || !energy || !count || n < 1 || size < 1 || step < 1)
+        return fail(MGX_ERR_ARGUMENT, "bad window energy arguments");
+    HIP_TRY(hipSetDevice(h->device));
+    if (size > n) size = n;                                   // dsp.py:131-132: the whole array is the only window
+    const int64_t windows = (n - size) / step + 1;
+    *count = windows;
+    if (windows > capacity) return fail(MGX_ERR_ARGUMENT, "energy array too small for the number of windows");
+    if (windows > 65535) return fail(MGX_ERR_UNSUPPORTED, "more than 65535 preview windows");
+    const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, size / 16384));
+    const size_t bytes = (size_t)windows * chunks * sizeof(double);
+    MGX_TRY(ensure(h, h->partial, bytes));
+    MGX_TRY(ensure_pinned(h, std::max(bytes, (size_t)1 << 16)));
+    hipLaunchKernelGGL(k_window_energy, dim3(chunks, (unsigned)windows), dim3(256), 0, h->stream, (const float2*)x_dev,
+                       (long long)size, (long long)step, chunks, (double*)h->partial.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->pinned, h->partial.p, bytes, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    MGX_TRY(check_device_error(h));
+    const double* part = (const double*)h->pinned;
+    for (int64_t w = 0; w < windows; ++w) {
+        double s = 0.0;
+        for (int c = 0; c < chunks; ++c) s += part[(size_t)w * chunks + c];
+        energy[w] = s;
+    }
+    return 0;
+}
+
+int mgx_preview_cut(mgx_handle* h, const float* x_dev, int64_t n, int64_t begin, int64_t size, int64_t fade,
+                    double clip_limit, float* out_dev) {
+    if (!h || !x_dev || !out_dev || begin < 0 || size < 1 || begin + size > n || fade < 0 || fade > size)
+        return fail(MGX_ERR_ARGUMENT, "bad preview cut arguments");
+    HIP_TRY(hipSetDevice(h->device));
+    const unsigned grid = (unsigned)std::min<int64_t>((size + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_preview_cut, dim3(grid), dim3(256), 0, h->stream, (const float2*)x_dev, (long long)begin,
+                       (long long)size, (long long)fade, clip_limit, (float2*)out_dev);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -1106,7 +1166,7 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
         ra.cs = cs;
         ra.npeaks = nblocks;
         MGX_TRY(ensure_ctrl(h));
-        ra.error = (int*)h->lim_ctrl.p + 1;
+        ra.error = h->error_dev;
         const size_t lds_step = (size_t)(64 + tw.divisions + (size_t)ra.divisions * ra.chunks) * sizeof(double);
         if (lds_step > (size_t)150 * 1024)
             return fail(MGX_ERR_UNSUPPORTED, "too many analysis pieces for the level-correction kernel's LDS");
@@ -1178,7 +1238,7 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
         HIP_TRY(hipMemcpyAsync(hc, cs, sizeof(CorrectionState), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipMemcpyAsync(c0, h->scalars.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        MGX_TRY(check_limiter_error(h));
+        MGX_TRY(check_device_error(h));
         std::memset(report, 0, sizeof(*report));
         report->final_amplitude_coefficient = st_r->amplitude_c;
         report->target_match_rms = st_t->match_rms;
@@ -1233,6 +1293,52 @@ int mgx_stage_times(mgx_handle* h, float* ms) {
         HIP_TRY(hipEventElapsedTime(&ms[s], h->stage_ev[s][0], h->stage_ev[s][1]));
         h->stage_used[s] = false;
     }
+    return check_device_error(h);
+}
+
+}  // extern "C"
+// shader clock probe (mgx_clock_probe): every thread runs a dependent FMA chain, wave 0 of workgroup 0
+// reads both counters around it
+__global__ void __launch_bounds__(256) k_clock_probe(int iterations, unsigned long long* ticks, float* sink) {
+    const bool reporter = blockIdx.x == 0 && threadIdx.x < 64;
+    unsigned long long c0 = 0, r0 = 0;
+    if (reporter) {
+        c0 = __builtin_readcyclecounter();
+        r0 = wall_clock64();
+    }
+    float a = 1.0f + threadIdx.x * 1e-7f, b = 0.999999f;
+    for (int i = 0; i < iterations; ++i) {
+        a = fmaf(a, b, 1e-9f);
+        a = fmaf(a, b, 1e-9f);
+        a = fmaf(a, b, 1e-9f);
+        a = fmaf(a, b, 1e-9f);
+    }
+    if (reporter && threadIdx.x == 0) {
+        ticks[0] = __builtin_readcyclecounter() - c0;
+        ticks[1] = wall_clock64() - r0;
+    }
+    if (a == 123.456f) sink[0] = a;
+}
+extern "C" {
+int mgx_clock_probe(mgx_handle* h, int32_t workgroups, int32_t iterations, double* out) {
+    if (!h || !out || workgroups < 1 || iterations < 1) return fail(MGX_ERR_ARGUMENT, "bad clock probe arguments");
+    HIP_TRY(hipSetDevice(h->device));
+    MGX_TRY(ensure(h, h->peak_words, 64));
+    unsigned long long* ticks = (unsigned long long*)h->peak_words.p;
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(k_clock_probe, dim3((unsigned)workgroups), dim3(256), 0, h->stream, (int)iterations, ticks,
+                       (float*)(ticks + 4));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    unsigned long long host[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(host, ticks, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    out[0] = (double)host[0];
+    out[1] = (double)host[1];
+    out[2] = host[1] ? 100.0 * (double)host[0] / (double)host[1] : 0.0;
+    out[3] = ms;
     return 0;
 }
 

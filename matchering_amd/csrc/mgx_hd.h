@@ -30,6 +30,11 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 #endif
 #endif
 
+// float32 complex helpers: their adds may fuse with the multiply that feeds them (fft2.h: the one place
+// of a library built with -ffp-contract=off where contraction is let in)
+#if defined(__clang__) && !defined(MGX_NO_FP_CONTRACT)
+#pragma clang fp contract(fast)
+#endif
 namespace mgx {
 
 MGX_HD float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -45,6 +50,12 @@ MGX_HD float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
 // multiply by +i / -i
 MGX_HD float2 cmul_i(float2 a) { return make_float2(-a.y, a.x); }
 MGX_HD float2 cmul_mi(float2 a) { return make_float2(a.y, -a.x); }
+
+}  // namespace mgx
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+namespace mgx {
 
 
 // ---------------------------------------------------------------------------

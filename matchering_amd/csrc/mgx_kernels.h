@@ -140,16 +140,19 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
     typename CB::RowFilter rf;
     typename CB::RowAcc acc;
     CB::clear_acc(acc);
+    // radix-32 middle passes (16384 points) need the registers the early filter fetch would hold
+    constexpr bool LATE_FILTER = F::R(1) >= 32;
     for (int k = 0; k < a.parts; ++k) {
         CB::template phase_load<SIDE>(opaque(tid), pair, edge, a, ps, lds, k);
         __builtin_amdgcn_sched_barrier(0);
-        CB::fetch_filter(tid, h + (size_t)k * F::N, rf);
+        if (!LATE_FILTER) CB::fetch_filter(tid, h + (size_t)k * F::N, rf);
         __syncthreads();
         if (F::P == 3) {
             CB::phase_fwd_mid(opaque(tid), lds, mid_table);
             __syncthreads();
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (LATE_FILTER) CB::fetch_filter(opaque(tid), h + (size_t)k * F::N, rf);
         CB::phase_accumulate(tid, rf, lds, acc);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
@@ -953,45 +956,68 @@ __global__ __launch_bounds__(1024) void k_fir_b(FirPlanView pl, double* scratch)
     __syncthreads();
     FirDesign::phase_pin(tid, s);
 }
-// irfft + ifftshift + Hann (match_frequencies.py:98-99) as a direct cosine sum in float64.  grid =
-// (F / TAPS_PER_WG, 2); a workgroup computes TAPS_PER_WG taps (half the lanes of a wave), its TAP_SLICES
-// waves each summing a slice of the bins.  cos(2 pi k m / F) for the consecutive k of a slice comes from
-// a rotation: start and step are exact table values, the steps in between cost four float64
-// operations each and add ~1e-14 of error over a slice -- no cosine table in LDS (filling 32 KB of
+// irfft + ifftshift + Hann (match_frequencies.py:98-99) as a cosine sum in float64.  The spectrum is real
+// and even, so h0[m] = (H[0] + (-1)^m H[F/2] + 2 S(m)) / F with S(m) = sum_{k=1}^{F/2-1} H[k] cos(2 pi k m / F),
+// and S has two symmetries: S(F - m) = S(m), and with the even-k and odd-k halves E(m), O(m) of the sum,
+// S(m) = E + O while S(F/2 - m) = E - O.  One pair (E, O) for m in [0, F/4] therefore gives four taps:
+// a quarter of the F^2 / 2 terms of the plain sum (at 16 k taps 100 us of this kernel).
+// grid = (ceil((F/4 + 1) / TAP_ROWS), 2); a workgroup takes TAP_ROWS values of m, its TAP_SLICES = 1024 /
+// TAP_ROWS groups of lanes each sum a slice of the bins.  cos(2 pi k m / F) for the consecutive k of a
+// slice comes from a rotation: start and step are exact table values, the steps in between cost four
+// float64 operations each and add ~1e-14 of error over a slice -- no cosine table in LDS (filling 32 KB of
 // it per workgroup was most of this kernel's time) and no gather through the L2.
-constexpr int TAPS_PER_WG = 32, TAP_SLICES = 1024 / TAPS_PER_WG;     // (F / 32 workgroups: every CU gets one at F = 4096 x 2 channels;
-                                                                  // with 64 taps each the kernel ran on half the chip, 16 vs 11 us)
+constexpr int TAP_ROWS = 8, TAP_SLICES = 1024 / TAP_ROWS;
 __global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double* scratch, float* taps /* [2][F] */) {
     MGX_LDS;
     double* sm = reinterpret_cast<double*>(mgx_smem);       // [bins]
-    double* red = sm + pl.bins;                             // [1024]
-    const int plane = blockIdx.y, f = pl.fft, half = f / 2;
+    double* red = sm + pl.bins;                             // [2][1024]: even-k and odd-k partial sums
+    const int plane = blockIdx.y, f = pl.fft, half = f / 2, quarter = f / 4;
     const FirScratch s = fir_scratch(const_cast<double*>(scratch), pl, plane);
-    const int i = blockIdx.x * TAPS_PER_WG + (threadIdx.x % TAPS_PER_WG), slice = threadIdx.x / TAPS_PER_WG;
-    const int mm = (i + half) & (f - 1);
-    const int per = (half - 1 + TAP_SLICES - 1) / TAP_SLICES;   // bins 1 .. half-1 split over the slices
+    const int row = threadIdx.x % TAP_ROWS, slice = threadIdx.x / TAP_ROWS;
+    const int mm = min(blockIdx.x * TAP_ROWS + row, quarter);       // (rows past F/4 repeat it: same stores)
+    // bins 1 .. half-1 in slices of an even number of bins, so that every slice starts on an odd bin
+    int per = (half - 1 + TAP_SLICES - 1) / TAP_SLICES;
+    per += per & 1;
     const int k0 = 1 + slice * per, k1 = min(half, k0 + per);
     // asked for before the barrier: four table look-ups per thread
     const int i0 = (int)(((long long)k0 * mm) & (f - 1));
-    double c = pl.cos_table[i0], sn = pl.cos_table[(i0 - f / 4) & (f - 1)];        // sin x = cos(x - pi/2)
-    const double dc = pl.cos_table[mm], ds = pl.cos_table[(mm - f / 4) & (f - 1)];
-    const double window = pl.hann[i];
+    double c = pl.cos_table[i0], sn = pl.cos_table[(i0 - quarter) & (f - 1)];        // sin x = cos(x - pi/2)
+    const double dc = pl.cos_table[mm], ds = pl.cos_table[(mm - quarter) & (f - 1)];
     for (int k = threadIdx.x; k < pl.bins; k += 1024) sm[k] = s.smooth[k];
     __syncthreads();
-    double acc = 0.0;
-    for (int k = k0; k < k1; ++k) {
-        acc = fma(sm[k], c, acc);
-        const double cn = fma(c, dc, -sn * ds);
+    double odd = 0.0, even = 0.0;
+    for (int k = k0; k < k1; k += 2) {                      // k odd, k + 1 even
+        odd = fma(sm[k], c, odd);
+        double cn = fma(c, dc, -sn * ds);
+        sn = fma(sn, dc, c * ds);
+        c = cn;
+        if (k + 1 < k1) even = fma(sm[k + 1], c, even);
+        cn = fma(c, dc, -sn * ds);
         sn = fma(sn, dc, c * ds);
         c = cn;
     }
-    red[threadIdx.x] = acc;
+    red[threadIdx.x] = even;
+    red[1024 + threadIdx.x] = odd;
     __syncthreads();
-    if (slice == 0) {
+    // TAP_ROWS x 2 sums of TAP_SLICES partials each: one wave per (row, parity)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 2 * TAP_ROWS) {
+        const int r = wave >> 1, parity = wave & 1;
         double t = 0.0;
-#pragma unroll
-        for (int l = 0; l < TAP_SLICES; ++l) t += red[l * TAPS_PER_WG + threadIdx.x];
-        const double v = (sm[0] + ((mm & 1) ? -sm[half] : sm[half]) + 2.0 * t) / f * window;
+        for (int l = lane; l < TAP_SLICES; l += 64) t += red[parity * 1024 + l * TAP_ROWS + r];
+        t = wave_sum(t);
+        if (lane == 0) red[2048 + wave] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * TAP_ROWS) {
+        const int r = threadIdx.x >> 2, which = threadIdx.x & 3;
+        const int m0 = min(blockIdx.x * TAP_ROWS + r, quarter);
+        const double e = red[2048 + 2 * r], o = red[2048 + 2 * r + 1];
+        // which: 0 -> m0, 1 -> F - m0 (E + O);  2 -> F/2 - m0, 3 -> F/2 + m0 (E - O)
+        const int m = (which == 0 ? m0 : which == 1 ? f - m0 : which == 2 ? half - m0 : half + m0) & (f - 1);
+        const double sum = which < 2 ? e + o : e - o;
+        const int i = (m + half) & (f - 1);                 // ifftshift: tap i holds h0[(i + F/2) mod F]
+        const double v = (sm[0] + ((m & 1) ? -sm[half] : sm[half]) + 2.0 * sum) / f * pl.hann[i];
         taps[(size_t)plane * f + i] = (float)v;
     }
 }
@@ -1574,6 +1600,48 @@ __global__ __launch_bounds__(256) void k_scale_outputs(const float2* y, long lon
     }
 }
 
+// ---- A/B previews (preview_creator.py:30-94) --------------------------------------------------------
+// dsp.py:128-143 strided_app_2d + batch_rms_2d: windows of `size` frames every `step` frames; the loudest one
+// is argmax of sqrt(mean(x^2)) over both channels = argmax of the plain sum of squares.  grid = (chunks,
+// windows): workgroup (c, w) sums chunk c of window w in float64 (float32 products are exact in float64);
+// the host adds a window's chunks in order and takes the argmax of a few hundred numbers.
+__global__ __launch_bounds__(256) void k_window_energy(const float2* x, long long size, long long step, int chunks,
+                                                       double* partial /* [windows][chunks] */) {
+    __shared__ double scratch[4];
+    const long long begin = (long long)blockIdx.y * step;
+    const long long len = (size + chunks - 1) / chunks;
+    const long long b = begin + (long long)blockIdx.x * len, e = min(begin + size, b + len);
+    double acc = 0.0;
+    for (long long i = b + threadIdx.x; i < e; i += 256) {
+        const float2 v = x[i];
+        acc = fma((double)v.x, (double)v.x, acc);
+        acc = fma((double)v.y, (double)v.y, acc);
+    }
+    const double s = block_sum<256>(acc, scratch);
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * chunks + blockIdx.x] = s;
+}
+// the cut: out[i] = fade(i) * clip(x[begin + i], -limit, limit) for i < size (dsp.py:109-110 clip -- limit <= 0:
+// none --, dsp.py:146-152 fade: numpy.linspace(0, 1, fade) over the first `fade` frames, its mirror over the
+// last `fade`; both factors where the two ramps overlap, as the reference's two in-place products give)
+__global__ __launch_bounds__(256) void k_preview_cut(const float2* x, long long begin, long long size, long long fade,
+                                                     double limit, float2* out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < size; i += (long long)gridDim.x * 256) {
+        const float2 v = x[begin + i];
+        double l = v.x, r = v.y;
+        if (limit > 0.0) {
+            l = fmin(fmax(l, -limit), limit);
+            r = fmin(fmax(r, -limit), limit);
+        }
+        double g = 1.0;
+        if (fade > 0) {
+            const double denom = fade > 1 ? (double)(fade - 1) : 1.0;         // linspace(0, 1, 1) = [0]
+            if (i < fade) g *= (double)i / denom;
+            if (i >= size - fade) g *= (double)(size - 1 - i) / denom;
+        }
+        out[i] = make_float2((float)(l * g), (float)(r * g));
+    }
+}
+
 // per-block max(|L|,|R|) of interleaved frames (4096 frames per block)
 __global__ __launch_bounds__(256) void k_frame_peaks(const float2* x, long long n, float* block_peak) {
     __shared__ float scratch[4];
@@ -1685,8 +1753,13 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     // hold filter first (scan 1): its aggregate is published as early as possible
     typename LB::Thread th;
     Affine whole;
+#ifdef MGX_LIMITER_NO_QUIET_SKIP
+    const bool busy = true;
+#else
+    const bool busy = __any(LB::neighbourhood_max(opaque(tid), a, lds) > 0.f) != 0;      // wave-uniform
+#endif
     {
-        const Affine m1 = LB::template phase_hold_window<FULL>(opaque(tid), chunk, a, th, lds);
+        const Affine m1 = LB::template phase_hold_window<FULL>(opaque(tid), chunk, a, th, lds, busy);
         const Affine i1 = wave_inclusive<false>(m1);
         if (lane == 63) LB::wave_totals(lds, 1)[wave] = i1;
         const Affine e1 = wave_exclusive<false>(i1);
@@ -1701,7 +1774,7 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     // forward attack smoother (scan 0)
     Affine p0;
     {
-        const Affine m0 = LB::template phase_attack_window<FULL>(opaque(tid), a, th, lds);
+        const Affine m0 = LB::template phase_attack_window<FULL>(opaque(tid), a, th, lds, busy);
         const Affine i0 = wave_inclusive<false>(m0);
         if (lane == 63) LB::wave_totals(lds, 0)[wave] = i0;
         const Affine e0 = wave_exclusive<false>(i0);

@@ -270,6 +270,24 @@ class Device:
             self.synchronize()
         return out
 
+    # ---- previews on frames that are still in HBM (mgx_window_energy / mgx_preview_cut) ----------
+    def window_energy(self, buf, frames, size, step):
+        """dsp.py:128-143: sum of squares (both channels) of every window of ``size`` frames every ``step``."""
+        size = min(int(size), int(frames))
+        count = (int(frames) - size) // int(step) + 1
+        energy = (ctypes.c_double * count)()
+        got = ctypes.c_int64()
+        check(library().mgx_window_energy(self.handle, ctypes.c_void_p(buf.ptr), int(frames), size, int(step), energy,
+                                          count, ctypes.byref(got)))
+        return np.frombuffer(energy, dtype=np.float64, count=got.value).copy()
+
+    def preview_cut(self, buf, frames, begin, size, fade, clip_limit=0.0):
+        """Frames [begin, begin + size) clipped (``clip_limit`` > 0) and faded: a new DeviceBuffer."""
+        out = DeviceBuffer(self, max(int(size) * 8, 1))
+        check(library().mgx_preview_cut(self.handle, ctypes.c_void_p(buf.ptr), int(frames), int(begin), int(size),
+                                        int(fade), float(clip_limit), ctypes.c_void_p(out.ptr)))
+        return out
+
     def synchronize(self):
         check(library().mgx_synchronize(self.handle))
         self._keep_until_sync.clear()

@@ -40,13 +40,15 @@ def _as_frames(array, name):
 
 def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default: bool = True,
          need_no_limiter: bool = False, need_no_limiter_normalized: bool = False, device=None, fir=None,
-         encodings=None):
+         encodings=None, preview=None):
     # (``device``: the handle to run on, default the process-wide one; ``fir``: a DeviceBuffer with a
     # matching FIR to apply instead of designing one -- batch.master_album; ``encodings``: per output,
     # None for float32 frames or "PCM_16" / "PCM_24" / "PCM_32" for the integer samples a file of that
     # subtype holds, quantised on the device (saver.py:27-33 does it on the host) -- int16 / int32 (n, 2),
     # or uint8 (n, 6) for packed 24-bit.  All additions to the reference's signature, keyword-only in
-    # spirit.  ``target`` / ``reference`` may be int16 or int32 PCM as read from a file.)
+    # spirit.  ``target`` / ``reference`` may be int16 or int32 PCM as read from a file.  ``preview``: a
+    # preview.PreviewRequest -- the A/B previews of preview_creator.py:30-94 are cut from the first requested
+    # output and from the target while both are still in HBM, and left in the request.)
     dev = device if device is not None else default_device()
     target = _as_frames(target, "target")
     reference = _as_frames(reference, "reference")
@@ -85,11 +87,28 @@ def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default
                 debug("the result stays under the threshold: the limiter passes it through")
             # queued one behind the other, then ONE wait; the arrays live in pinned host memory
             formats = encodings if encodings is not None else (None, None, None)
+            pieces = []
+            if preview is not None:
+                mastered = next(b for b in outs if b is not None)        # core.py:111: the first rendering there is
+                begin, size, fade = preview.plan(dev.window_energy(mastered, n, preview.size, preview.step), n)
+                for want, src, limit, fmt in ((preview.want_target, t_dev, preview.threshold, preview.encodings[0]),
+                                              (preview.want_result, mastered, 0.0, preview.encodings[1])):
+                    piece = dev.preview_cut(src, n, begin, size, fade, limit) if want else None
+                    pieces.append(piece)
+                    host = (None if piece is None else dev.download(piece, (size, 2), wait=False) if fmt is None
+                            else dev.download_pcm(piece, size, 2, PCM_BITS[fmt], wait=False))
+                    if src is t_dev:
+                        preview.target_piece = host
+                    else:
+                        preview.result_piece = host
             results = tuple(None if b is None
                             else dev.download(b, (n, 2), wait=False) if fmt is None
                             else dev.download_pcm(b, n, 2, PCM_BITS[fmt], wait=False)
                             for b, fmt in zip(outs, formats))
             dev.synchronize()
+            for piece in pieces:
+                if piece is not None:
+                    piece.release()
         finally:
             for b in (t_dev, r_dev, *outs):
                 if b is not None:

@@ -58,11 +58,52 @@ CASES = {
         kind="burst_reference", seconds=2.5, reference_seconds=2.0, sample_rate=16000, pair=4,
         reference_gain=0.5,
         config=dict(internal_sample_rate=16000, fft_size=1024, max_piece_size=0.7)),
+    # NOT from matchering_amd.synth: a mono target (L == R: the side channel is
+    # identically zero, so the side matching curve is A_R / min_value ~ 1e6) made of a 110 Hz square wave with a
+    # DC offset, against a hard-panned reference (R == 0) made of a chirp and an impulse train
+    "square_mono_vs_panned": dict(
+        kind="square_mono_vs_panned", seconds=2.2, reference_seconds=2.0, sample_rate=44100, pair=9,
+        config=dict(fft_size=2048, max_piece_size=0.5)),
 }
+
+
+def hard_material(kind, seconds, sample_rate, seed=0):
+    """Programme material that is nothing like synth(): the shapes the level decisions and the band lists of
+    the level correction have to survive (square waves, impulse trains, DC, one dead channel)."""
+    n = int(seconds * sample_rate)
+    t = np.arange(n) / sample_rate
+    rng = np.random.RandomState(1000 + seed)
+    if kind == "square_mono":                 # L == R exactly
+        x = 0.45 * np.sign(np.sin(2 * np.pi * 110.0 * t)) * (0.6 + 0.4 * np.sin(2 * np.pi * t / 1.3)) + 0.03
+        x = x + 1e-4 * rng.randn(n)
+        return np.stack([x, x], axis=1)
+    if kind == "panned_chirp_impulses":       # R == 0 exactly
+        f0, f1 = 50.0, 8000.0
+        phase = 2 * np.pi * (f0 * t + (f1 - f0) * t * t / (2 * seconds))
+        left = 0.8 * np.sin(phase) * (0.5 + 0.5 * np.sin(2 * np.pi * t / 0.9) ** 2)
+        left[::997] = 0.95
+        return np.stack([left, np.zeros(n)], axis=1)
+    if kind == "square":                      # +-0.9 square, channels in opposite phase half of the time
+        x = 0.9 * np.sign(np.sin(2 * np.pi * 82.0 * t))
+        y = x * np.sign(np.sin(2 * np.pi * 0.7 * t) + 0.3)
+        return np.stack([x, y], axis=1) * (0.7 + 0.3 * np.sin(2 * np.pi * t / 1.7))[:, None]
+    if kind == "impulses":                    # sparse full-scale clicks over a -60 dB floor
+        x = 1e-3 * rng.randn(n, 2)
+        x[::613, 0] += 0.9
+        x[305::613, 1] -= 0.9
+        return x
+    if kind == "dc":                          # music-like noise riding on a large DC offset
+        x = 0.1 * rng.randn(n, 2) * (0.5 + 0.5 * np.sin(2 * np.pi * t / 1.1) ** 2)[:, None]
+        return x + np.array([0.3, -0.2])
+    raise ValueError(kind)
 
 
 def build_inputs(case):
     sr = case["sample_rate"]
+    if case.get("kind") == "square_mono_vs_panned":
+        target = hard_material("square_mono", case["seconds"], sr, case["pair"])
+        reference = hard_material("panned_chirp_impulses", case["reference_seconds"], sr, case["pair"])
+        return target.astype(np.float32), reference.astype(np.float32)
     target, reference = make_pair(
         case["seconds"], sr, case["pair"], reference_seconds=case.get("reference_seconds"),
         reference_gain=case.get("reference_gain", 2.5))

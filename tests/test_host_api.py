@@ -504,3 +504,61 @@ def test_process_keeps_pcm_integer_end_to_end(tmp_path, monkeypatch):
     assert np.abs(got - np.clip(seen["outs"][1], -1, 1)).max() <= 1.6 / (1 << 15)
     got, _ = audio_io.read_wav(str(tmp_path / "e.wav"))
     assert np.array_equal(got, audio_io.pcm_to_float(seen["outs"][2]))
+
+
+def _raw_wave(path, code, channels, bits, block, payload, rate=44100):
+    import struct
+
+    fmt = struct.pack("<HHIIHH", code, channels, rate, rate * block, block, bits)
+    body = b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(payload)) + payload
+    with open(path, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", 4 + len(body)) + b"WAVE" + body)
+
+
+def test_wave_layouts_the_codec_does_not_decode_go_to_libsndfile_or_fail_as_unrecognised(tmp_path, monkeypatch):
+    """loader.py:35: soundfile reads A-law, mu-law, ADPCM ... WAVE files.  With pcm=True (what process passes)
+    they must still reach libsndfile when it is installed, and without it fail as 'Format not recognised'
+    (-> ffmpeg -> ModuleError 4001), never with a stray ValueError."""
+    alaw = str(tmp_path / "alaw.wav")
+    _raw_wave(alaw, 6, 2, 8, 2, bytes(range(200)))                 # WAVE_FORMAT_ALAW
+    lying = str(tmp_path / "lying.wav")
+    _raw_wave(lying, 1, 2, 16, 3, bytes(300))                      # block size 3 for 2 x 16 bits
+    monkeypatch.setattr(audio_io, "_sf", None)
+    for path in (alaw, lying):
+        for pcm in (False, True):
+            with pytest.raises(RuntimeError, match="Format not recognised"):
+                audio_io._read(path, pcm)
+        with pytest.raises(ModuleError) as err:
+            audio_io.load(path, "target", str(tmp_path), pcm=True)
+        assert "4001" in str(err.value)
+
+    class FakeSoundfile:
+        calls = []
+
+        @classmethod
+        def read(cls, path, always_2d=True):
+            cls.calls.append(path)
+            return np.zeros((100, 2)), 44100
+
+    monkeypatch.setattr(audio_io, "_sf", FakeSoundfile)
+    for path in (alaw, lying):
+        sound, rate = audio_io._read(path, pcm=True)
+        assert sound.shape == (100, 2) and rate == 44100
+    assert FakeSoundfile.calls == [alaw, lying]
+    # a plain PCM_16 file still comes back undecoded, without a detour through libsndfile
+    plain = str(tmp_path / "plain.wav")
+    audio_io.write_wav(plain, 0.25 * np.ones((64, 2)), 44100, "PCM_16")
+    sound, _ = audio_io._read(plain, pcm=True)
+    assert sound.dtype == np.int16 and FakeSoundfile.calls == [alaw, lying]
+
+
+def test_resampling_runs_in_float64_also_for_float32_files():
+    """checker.py:42 resamples the float64 arrays soundfile returns; a FLOAT (float32) track must be
+    promoted before the resampler sees it."""
+    rng = np.random.RandomState(3)
+    audio = (0.1 * rng.randn(48000, 2)).astype(np.float32)
+    cfg = mg.Config()
+    out32, rate = checker.check(audio, 48000, cfg, "reference")
+    out64, _ = checker.check(audio.astype(np.float64), 48000, cfg, "reference")
+    assert rate == cfg.internal_sample_rate and out32.dtype == np.float64
+    assert np.array_equal(out32, out64)

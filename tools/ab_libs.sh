@@ -6,6 +6,6 @@ OUT=gpurun_out/${1:-ab}; mkdir -p $OUT; ARGS=$2; shift 2
 for pass in 1 2 3; do
   for lib in "$@"; do
     echo "== pass $pass $lib"
-    MGX_LIB=$PWD/$lib python tools/bench_stages.py $ARGS base 2>&1 | tail -2
+    MGX_LIB=$PWD/$lib timeout 200 python tools/bench_stages.py $ARGS base 2>&1 | tail -2
   done
 done | tee $OUT/ab.txt

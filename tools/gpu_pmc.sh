@@ -5,7 +5,7 @@
 TAG=$1; WL=${2:-8min_full}
 OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --workload $WL > $OUT/pmc_$C.log 2>&1
+  timeout 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_$C -o r -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-traffic --no-gpu-state --workload $WL > $OUT/pmc_$C.log 2>&1
   F=$(find $OUT/pmc_$C -name "*counter_collection.csv" | head -1)
   echo "== $C ($F)"; head -2 $F
   python tools/pmc_summary.py $F $C > $OUT/pmc_$C.txt; cat $OUT/pmc_$C.txt
