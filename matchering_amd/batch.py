@@ -123,13 +123,14 @@ def lanes_allowed(world_size=1):
     return max(1, MAX_LANES // sharing)
 
 
-def choose_lanes(device_index=0, candidates=(2, 3), seconds=120.0, pairs=4, master=None):
+def choose_lanes(device_index=0, candidates=(2, 3), seconds=120.0, pairs=6, master=None):
     """How many device handles a batch should run on THIS GPU: measured, once per process and GPU.
 
     Boxes of the pool disagree: on some, three handles beat two by 10 % (1.87 vs 2.11 ms for eight resident
     4-minute pairs), on others three LOSE to two by 13 % (2.93 vs 2.60 ms; profiles/r02_lanes.txt,
     profiles/r02_g_bench_slow_box.json, BENCH_r02.json) -- so the number is not a constant of the code.  A
-    short synthetic batch (``pairs`` resident pairs of ``seconds`` each, full pipeline) is timed through
+    short synthetic batch (``pairs`` resident pairs of ``seconds`` each -- six: a multiple of both candidate
+    counts, so neither is handed an uneven share --, full pipeline) is timed through
     each candidate count and the fastest wins; the decision and both timings are kept in
     ``lane_choice_report(device_index)``.  Costs ~1 s of host time for the synthetic material and a few
     milliseconds of GPU time."""

@@ -492,6 +492,19 @@ struct LimiterBlock {
         return r;
     }
 
+    // ---- parking: sh is produced in P2 and consumed in P5; in between (the attack path) it waits in the
+    // thread's own row of the plane, which is dead from the barrier after P3 until P6 writes the gains
+    static MGX_HD void park_sh(int tid, const Thread& th, float* lds) {
+        float* row = plane(lds) + tid * STRIDE;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) row[j] = th.sh[j];
+    }
+    static MGX_HD void unpark_sh(int tid, Thread& th, const float* lds) {
+        const float* row = plane(const_cast<float*>(lds)) + tid * STRIDE;
+        MGX_UNROLL
+        for (int j = 0; j < E; ++j) th.sh[j] = row[j];
+    }
+
     // ---- look-back words, split into "ask" and "take" ----------------------------------------------
     struct Polls {
         unsigned long long v[POLL_SLOTS];

@@ -630,6 +630,9 @@ static int launch_limiter_general(mgx_handle* h, const LimiterArgs& a, const Lim
     return 0;
 }
 
+#ifndef MGX_LIMITER_WGS
+#define MGX_LIMITER_WGS 4          // workgroups per CU the 256-block limiter is compiled for (its register budget)
+#endif
 // 256-block chunks (four workgroups per CU) unless the configured attack / hold times need 1024
 static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
     const dim3 grid((unsigned)a.nchunks);
@@ -638,7 +641,7 @@ static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
         MGX_TRY((allow_lds(k_limit<1024, 1>, lds)));
         hipLaunchKernelGGL((k_limit<1024, 1>), grid, dim3(1024), lds, h->stream, a);
     } else {
-        hipLaunchKernelGGL((k_limit<256, 4>), grid, dim3(256), LimiterBlock<256>::LDS_BYTES, h->stream, a);
+        hipLaunchKernelGGL((k_limit<256, MGX_LIMITER_WGS>), grid, dim3(256), LimiterBlock<256>::LDS_BYTES, h->stream, a);
     }
     HIP_TRY(hipGetLastError());
     return 0;

@@ -1781,6 +1781,9 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
         __syncthreads();
         p0 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 0), e0, nullptr);
     }
+#ifdef MGX_LIMITER_PARK
+    LB::park_sh(opaque(tid), th, lds);          // (behind the barrier above: nobody reads g0 from the plane any more)
+#endif
     DEV_MARK(2);      // attack window + scan
     if (tid == LB::T - a.gr) LB::lookback_publish(chunk, 2, a, p0.b);          // attack state at the end of the core
     if (wave == 1) LB::lookback_ask(lane, chunk, 2, a, polls);
@@ -1817,6 +1820,9 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     DEV_MARK(5);      // barrier after the takes (waits for wave 1's attack take)
 
     // hold output, release filter (scan 3)
+#ifdef MGX_LIMITER_PARK
+    LB::unpark_sh(opaque(tid), th, lds);
+#endif
     const Affine mr = LB::template phase_hold<FULL>(opaque(tid), a, th, LB::scalars(lds)[0], tail ? 0.0 : LB::scalars(lds)[2]);
     const Affine ir = wave_inclusive<false>(mr);
     if (lane == 63) LB::wave_totals(lds, 3)[wave] = ir;
