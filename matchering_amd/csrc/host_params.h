@@ -247,6 +247,13 @@ inline void limiter_fill(const LimiterParams& p, float threshold, LimiterArgs& a
     a.n_hold = (int)p.w_hold.size();
     a.n_rel = (int)p.w_rel.size();
     a.n_att = (int)p.w_att.size();
+    // quiet chunks: sum_{k<C} ar^(C-1-k) br ah^k = br (ar^C - ah^C) / (ar - ah), in extended precision
+    const Wide ar = p.rel_f.alpha, ah = p.hold_f.alpha, gap = ar - ah;
+    a.quiet_ok = std::fabs((double)gap) > 1e-9 ? 1 : 0;
+    a.quiet_rel_gain = a.quiet_ok ? (double)((Wide)p.rel_f.beta * (std::pow(ar, (Wide)p.geo.chunk) - std::pow(ah, (Wide)p.geo.chunk)) / gap) : 0.0;
+    a.log2_hold = (float)std::log2(p.hold_f.alpha);
+    a.log2_rel = (float)std::log2(p.rel_f.alpha);
+    a.log2_att = (float)std::log2(p.att.alpha);
 }
 
 // look-back words of a launch: [3][nchunks] of the first-order kernel (the general one uses the attack

@@ -94,6 +94,11 @@ struct LimiterArgs {
     int n_hold, n_rel, n_att;
     int* ticket;                   // chunk dispenser (zeroed before the launch)
     int* error;                    // set to 1 if a bounded wait expired
+    // quiet chunks (limit_chunk_quiet): release state a core of zero input leaves per unit of hold carry,
+    // log2 of the three poles, 0 when the closed forms do not apply (equal hold and release poles)
+    double quiet_rel_gain;
+    float log2_hold, log2_rel, log2_att;
+    int quiet_ok;
 };
 
 constexpr unsigned long long LIMITER_UNPUBLISHED = ~0ull;
@@ -241,6 +246,26 @@ struct LimiterBlock {
         }
     }
     static MGX_HD int block_of(int tid, int j) { return (tid >> 3) + (T / 8) * j; }
+    // the same for a chunk inside the track, keeping the frames: a quiet chunk (below) stores from them
+    struct Reload { float4 q[E / 2]; };
+    static MGX_HD void phase_load_full(int tid, long long chunk, const LimiterArgs& a, float* lds, float (&pm)[E / 2],
+                                       Reload& kept) {
+        const float2* y = a.y + region_start(chunk, a) + 2 * tid;
+        const float g = (float)*a.gain;
+        float* gp = plane(lds);
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) kept.q[j] = *reinterpret_cast<const float4*>(y + 2 * T * j);
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) {
+            const int i = 2 * tid + 2 * T * j;
+            const float4 q = kept.q[j];
+            const float g0 = gain_of(scaled(make_float2(q.x, q.y), g), a.threshold);
+            const float g1 = gain_of(scaled(make_float2(q.z, q.w), g), a.threshold);
+            gp[gidx(i)] = g0;
+            gp[gidx(i + 1)] = g1;
+            pm[j] = fmaxf(g0, g1);
+        }
+    }
 
     // ---- window maxima from the raw plane -----------------------------------------------------------
     // value at frame 16*tid + d of the region, d uniform
@@ -653,6 +678,46 @@ struct LimiterBlock {
         }
     }
 
+    // ---- quiet chunks -------------------------------------------------------------------------------------
+    // A chunk whose whole region (halos included) holds no frame above the threshold has g0 = sl = sh = 0:
+    // its hold and attack aggregates are zero, and with the carries hc (hold), ac (attack), zr (release)
+    // entering its first core frame the envelopes are geometric sequences in the core offset k:
+    //   ho[k] = hc ah^k                      (hyrax.py:66 on zero input: the filter state decays)
+    //   x2[k] = max(0, ho[k]) = ho[k]        (hyrax.py:73; carries are sums of non-negative terms)
+    //   ro[k] = b0r ho[k] + ar^k zr + br hc (ar^k - ah^k) / (ar - ah)
+    //   gA[k] = ac kappa rho^k               (the deferred attack carry term of phase_hold)
+    // and the release state it hands on is hc * quiet_rel_gain (host_params.h).  No windows, no scans, no
+    // reload: the frames wait in registers from the load.  Powers by v_exp_f32 (2e-7 relative).
+    static MGX_HD void phase_quiet_store(int tid, long long chunk, const LimiterArgs& a, const Reload& r, double hold_carry,
+                                         double att_carry, double rel_carry) {
+        const long long r0 = region_start(chunk, a);
+        const int c0 = a.gl * E, c1 = (T - a.gr) * E;
+        const float g = (float)*a.gain, post = (float)*a.post_gain;
+        const float hc = (float)hold_carry, zr0 = (float)rel_carry;
+        const float ak = (float)(att_carry * attack_kappa(a.att));
+        const float d = (float)(a.rel.beta * hold_carry / (a.rel.alpha - a.hold.alpha));
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) {
+            const int i = 2 * tid + 2 * T * j;
+            if (i < c0 || i >= c1) continue;
+            const float k = (float)(i - c0);
+            float eh = exp2f(k * a.log2_hold), er = exp2f(k * a.log2_rel), ea = exp2f(k * a.log2_att);
+            float s[2];
+            MGX_UNROLL
+            for (int u = 0; u < 2; ++u) {
+                const float ho = hc * eh;
+                const float ro = fmaf(a.relf.b0, ho, fmaf(er, zr0, d * (er - eh)));
+                s[u] = (1.0f - fmaxf(fmaxf(ak * ea, ho), ro)) * post;
+                eh *= a.holdf.alpha;
+                er *= a.relf.alpha;
+                ea *= a.attf.alpha;
+            }
+            const float4 q = r.q[j];
+            const float2 v0 = scaled(make_float2(q.x, q.y), g), v1 = scaled(make_float2(q.z, q.w), g);
+            st_stream(reinterpret_cast<float4*>(a.out + (r0 + i)), make_float4(v0.x * s[0], v0.y * s[0], v1.x * s[1], v1.y * s[1]));
+        }
+    }
+
     // ---- P7: coalesced reload, apply gain, store ---------------------------------------------------
     template <bool FULL = false>
     static MGX_HD void phase_store(int tid, long long chunk, const LimiterArgs& a, bool with_gain, const float* lds) {
@@ -690,7 +755,6 @@ struct LimiterBlock {
 
     // The same for a chunk inside the track, in two halves: the reload is issued while the release
     // look-back is in flight (the kernel has nothing else to do there), the rest follows the gains.
-    struct Reload { float4 q[E / 2]; };
     static MGX_HD void phase_reload(int tid, long long chunk, const LimiterArgs& a, Reload& r) {
         // (every frame of the region exists; only the core is stored, so only the core is fetched again:
         // the halos are 13 % of a 256-block region)

@@ -1738,7 +1738,7 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     long long dev_last = wall_clock64();
     if (threadIdx.x == 0 && chunk < DEV_PHASE_CHUNKS) mgx_dev_phase_ticks[chunk][15] = (unsigned)dev_last;
 #endif
-    {
+    if (!FULL) {                                 // (a FULL chunk was loaded by the kernel: limit_chunk_quiet's frames)
         float pm[LB::E / 2];
         LB::template phase_load<FULL>(opaque(tid), chunk, a, lds, pm);
 #pragma unroll
@@ -1746,8 +1746,8 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
             const float m = dpp_max8(pm[j]);
             if ((tid & 7) == 0) LB::block_max(lds)[LB::block_of(tid, j)] = m;
         }
+        __syncthreads();
     }
-    __syncthreads();
     DEV_MARK(0);      // load
 
     // hold filter first (scan 1): its aggregate is published as early as possible
@@ -1847,6 +1847,41 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     if (FULL) LB::phase_store_reloaded(opaque(tid), chunk, a, again, lds);
     else LB::template phase_store<FULL>(opaque(tid), chunk, a, true, lds);
     DEV_MARK(10);     // store
+}
+
+// A chunk without a single frame above the threshold (limiter_kernel.h, "quiet chunks"): two look-backs, no
+// windows, no scans, no reload.  45 % of the chunks of the benchmark's 8-minute pair; none of a track that is
+// limited everywhere.
+template <int T>
+__device__ __forceinline__ void limit_chunk_quiet(const LimiterArgs& a, long long chunk, float* lds,
+                                                  const typename LimiterBlock<T>::Reload& kept) {
+    using LB = LimiterBlock<T>;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) {
+        LB::lookback_publish(chunk, 0, a, 0.0);
+        LB::lookback_publish(chunk, 2, a, 0.0);
+    }
+    typename LB::Polls polls;
+    if (wave == 0) {
+        LB::lookback_ask(lane, chunk, 0, a, polls);
+        const double s = wave_sum(LB::lookback_take(lane, chunk, 0, a, polls));
+        if (lane == 0) LB::scalars(lds)[0] = s;
+    }
+    if (wave == 1) {
+        LB::lookback_ask(lane, chunk, 2, a, polls);
+        const double s = wave_sum(LB::lookback_take(lane, chunk, 2, a, polls));
+        if (lane == 0) LB::scalars(lds)[2] = s;
+    }
+    __syncthreads();
+    const double hc = LB::scalars(lds)[0], ac = LB::scalars(lds)[2];
+    if (tid == 0) LB::lookback_publish(chunk, 1, a, hc * a.quiet_rel_gain);
+    if (wave == 0) {
+        LB::lookback_ask(lane, chunk, 1, a, polls);
+        const double s = wave_sum(LB::lookback_take(lane, chunk, 1, a, polls));
+        if (lane == 0) LB::scalars(lds)[1] = s;
+    }
+    __syncthreads();
+    LB::phase_quiet_store(tid, chunk, a, kept, hc, ac, LB::scalars(lds)[1]);
 }
 
 // ---- PCM at the boundary (loader.py:35 / saver.py:27-33: what soundfile does on the host) ------------
@@ -2111,8 +2146,35 @@ __global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a) {
     if (tid == 0) ticket = atomicAdd(a.ticket, 1);
     __syncthreads();
     const long long chunk = ticket;
-    if (LB::full_chunk(chunk, a)) limit_chunk<T, true>(a, chunk, lds);
-    else limit_chunk<T, false>(a, chunk, lds);
+    if (!LB::full_chunk(chunk, a)) {
+        limit_chunk<T, false>(a, chunk, lds);
+        return;
+    }
+    // a chunk inside the track: load (the frames stay in registers until it is known whether the chunk is
+    // quiet), block maxima, one flag per wave
+    typename LB::Reload kept;
+    {
+        float pm[LB::E / 2];
+        LB::phase_load_full(opaque(tid), chunk, a, lds, pm, kept);
+        float mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < LB::E / 2; ++j) {
+            mine = fmaxf(mine, pm[j]);
+            const float m = dpp_max8(pm[j]);
+            if ((tid & 7) == 0) LB::block_max(lds)[LB::block_of(tid, j)] = m;
+        }
+        const bool wave_busy = __any(mine > 0.f) != 0;
+        if ((tid & 63) == 0) LB::edge_sl(lds)[tid >> 6] = wave_busy ? 1.f : 0.f;   // (16 floats; the track's ends use them, not these chunks)
+    }
+    __syncthreads();
+    bool chunk_busy = false;
+#pragma unroll
+    for (int w = 0; w < LB::WAVES; ++w) chunk_busy = chunk_busy || LB::edge_sl(lds)[w] != 0.f;
+#ifdef MGX_LIMITER_NO_QUIET_CHUNKS
+    chunk_busy = true;
+#endif
+    if (!chunk_busy && a.quiet_ok) limit_chunk_quiet<T>(a, chunk, lds, kept);
+    else limit_chunk<T, true>(a, chunk, lds);
 }
 
 }  // namespace mgx

@@ -251,6 +251,36 @@ def test_limiter_stage(name, oracle_runs):
     assert np.abs(out[:64] - want[:64]).max() <= 1e-6 and np.abs(out[-64:] - want[-64:]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("lim,decay_window", [(dict(), (9.0, 14.0)), (dict(attack=8.0, hold=2.0), (9.0, 14.0)),
+                                              (dict(release=300.0, hold_filter_coefficient=40.0), (7.75, 8.5))])
+def test_limiter_quiet_chunks_between_loud_ones(lim, decay_window):
+    """Chunks without a frame above the threshold take limit_chunk_quiet (closed-form envelopes from the
+    carries, no windows or scans): a track that is quiet for seconds between short bursts, so that the hold,
+    release and attack states decay across many quiet chunks and are picked up again by busy ones -- against
+    hyrax.py:78-99 restated, at the bounds of the other limiter tests.  Second case: 1024-block chunks;
+    third: a fast release and a fast hold filter (large per-chunk decay)."""
+    import matchering_amd as mg
+    from matchering_amd import kernels
+    from matchering_amd.synth import synth
+
+    sr = 44100
+    x = synth(20.0, sr, 31).astype(np.float64)
+    x *= 0.55 / np.abs(x).max()                                   # nowhere near the threshold ...
+    for start, length, level in ((1.0, 0.004, 1.4), (1.03, 0.05, 1.2), (7.5, 0.2, 1.7), (15.0, 0.0005, 1.3), (19.99, 0.005, 1.25)):
+        a, b = int(start * sr), int((start + length) * sr)
+        x[a:b] *= level / np.abs(x[a:b]).max()                     # ... except in five short bursts that peak at `level`
+    y = x.astype(np.float32)
+    assert 1e-4 < np.mean(np.abs(y).max(axis=1) > mg.Config().threshold) < 0.02
+    out, active = kernels.limit(y, mg.Config(limiter=mg.LimiterConfig(**lim)), gain=1.0, post_gain=0.8)
+    want = mo.limit(y.astype(np.float64), mo.params(**lim)) * 0.8
+    assert active
+    assert rms_error(out, want) <= 1e-6
+    assert np.abs(out - want).max() <= 5e-6
+    quiet = slice(int(decay_window[0] * sr), int(decay_window[1] * sr))   # after a burst: pure carry decay
+    assert np.abs(out[quiet] - want[quiet]).max() <= 2e-6
+    assert np.abs(want[quiet] - 0.8 * y[quiet]).max() > 1e-4        # (and the carries do matter there)
+
+
 @pytest.mark.parametrize("lim", [
     dict(sr=44100, attack=0.1, hold=0.1),          # windows of a few samples, read out frame by frame
     dict(sr=8000, attack=1.0, hold=1.0),           # half window 8: the split form at its shortest
