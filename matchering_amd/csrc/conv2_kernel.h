@@ -26,7 +26,7 @@
 
 #include "fft2.h"
 
-#if defined(__clang__) && !defined(MGX_NO_FP_CONTRACT)
+#if defined(__clang__)
 #pragma clang fp contract(fast)        // see fft2.h
 #endif
 

@@ -38,7 +38,7 @@
 // multiply feeding an add may fuse (a sqrt(1/2) rotation into the butterfly that follows it: 4 % fewer
 // VALU instructions in k_conv, 160 -> 154.5 us, profiles/r03_a_fp_contract.txt), results stay within
 // 1e-7 of the unfused ones.  Scoped to this file and conv2_kernel.h.
-#if defined(__clang__) && !defined(MGX_NO_FP_CONTRACT)
+#if defined(__clang__)
 #pragma clang fp contract(fast)
 #endif
 

@@ -517,19 +517,6 @@ struct LimiterBlock {
         return r;
     }
 
-    // ---- parking: sh is produced in P2 and consumed in P5; in between (the attack path) it waits in the
-    // thread's own row of the plane, which is dead from the barrier after P3 until P6 writes the gains
-    static MGX_HD void park_sh(int tid, const Thread& th, float* lds) {
-        float* row = plane(lds) + tid * STRIDE;
-        MGX_UNROLL
-        for (int j = 0; j < E; ++j) row[j] = th.sh[j];
-    }
-    static MGX_HD void unpark_sh(int tid, Thread& th, const float* lds) {
-        const float* row = plane(const_cast<float*>(lds)) + tid * STRIDE;
-        MGX_UNROLL
-        for (int j = 0; j < E; ++j) th.sh[j] = row[j];
-    }
-
     // ---- look-back words, split into "ask" and "take" ----------------------------------------------
     struct Polls {
         unsigned long long v[POLL_SLOTS];
@@ -764,11 +751,7 @@ struct LimiterBlock {
         for (int j = 0; j < E / 2; ++j) {
             const int i = 2 * tid + 2 * T * j;
             r.q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifdef MGX_RELOAD_ALL
-            r.q[j] = *reinterpret_cast<const float4*>(y + 2 * T * j);
-#else
             if (i >= c0 && i < c1) r.q[j] = *reinterpret_cast<const float4*>(y + 2 * T * j);
-#endif
         }
     }
     static MGX_HD void phase_store_reloaded(int tid, long long chunk, const LimiterArgs& a, const Reload& r, const float* lds) {

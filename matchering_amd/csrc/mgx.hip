@@ -549,16 +549,14 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
 // a CU's LDS.  (Round 2 used K = F/4096 partitions on N = 8192 blocks: K + 1 transforms of 8192 points
 // per channel and 8192 output frames, 325 flop per frame and channel; K/2 + 1 of 16384 points per 16384
 // frames are 210.)
-#ifndef MGX_LONG_FIR_LOG2N
-#define MGX_LONG_FIR_LOG2N 14
-#endif
+constexpr int LONG_FIR_LOG2N = 14;
 static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const float* taps_dev, double gain,
                     float* y, float* ymid, long long* npairs_out, const double* gain_ptr = nullptr) {
     const int l = ilog2_exact(taps);
     if (l < 0) return fail(MGX_ERR_ARGUMENT, "FIR length must be a power of two");
     MGX_TRY(check_length(n));
     int log2b = l + 1;
-    if (log2b > 14) log2b = MGX_LONG_FIR_LOG2N;
+    if (log2b > 14) log2b = LONG_FIR_LOG2N;
     const size_t nb = (size_t)1 << log2b;
     const int parts = (int)((size_t)2 * taps / nb);
     const long long pair_frames = (long long)nb;
@@ -575,7 +573,7 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     a.pair_peak = nullptr;
     MGX_TRY(get_twiddles(h, log2b, &a.tw));
     if (npairs_out) *npairs_out = a.npairs;
-    if (parts > 1) return launch_conv<MGX_LONG_FIR_LOG2N, true>(h, a, taps_dev, gain, gain_ptr);
+    if (parts > 1) return launch_conv<LONG_FIR_LOG2N, true>(h, a, taps_dev, gain, gain_ptr);
     switch (log2b) {
 #define CASE(L) case L: return launch_conv<L, false>(h, a, taps_dev, gain, gain_ptr);
         CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
@@ -630,9 +628,6 @@ static int launch_limiter_general(mgx_handle* h, const LimiterArgs& a, const Lim
     return 0;
 }
 
-#ifndef MGX_LIMITER_WGS
-#define MGX_LIMITER_WGS 4          // workgroups per CU the 256-block limiter is compiled for (its register budget)
-#endif
 // 256-block chunks (four workgroups per CU) unless the configured attack / hold times need 1024
 static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
     const dim3 grid((unsigned)a.nchunks);
@@ -641,7 +636,7 @@ static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
         MGX_TRY((allow_lds(k_limit<1024, 1>, lds)));
         hipLaunchKernelGGL((k_limit<1024, 1>), grid, dim3(1024), lds, h->stream, a);
     } else {
-        hipLaunchKernelGGL((k_limit<256, MGX_LIMITER_WGS>), grid, dim3(256), LimiterBlock<256>::LDS_BYTES, h->stream, a);
+        hipLaunchKernelGGL((k_limit<256, 4>), grid, dim3(256), LimiterBlock<256>::LDS_BYTES, h->stream, a);
     }
     HIP_TRY(hipGetLastError());
     return 0;

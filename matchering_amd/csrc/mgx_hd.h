@@ -32,7 +32,7 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 
 // float32 complex helpers: their adds may fuse with the multiply that feeds them (fft2.h: the one place
 // of a library built with -ffp-contract=off where contraction is let in)
-#if defined(__clang__) && !defined(MGX_NO_FP_CONTRACT)
+#if defined(__clang__)
 #pragma clang fp contract(fast)
 #endif
 namespace mgx {

@@ -1753,11 +1753,7 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     // hold filter first (scan 1): its aggregate is published as early as possible
     typename LB::Thread th;
     Affine whole;
-#ifdef MGX_LIMITER_NO_QUIET_SKIP
-    const bool busy = true;
-#else
     const bool busy = __any(LB::neighbourhood_max(opaque(tid), a, lds) > 0.f) != 0;      // wave-uniform
-#endif
     {
         const Affine m1 = LB::template phase_hold_window<FULL>(opaque(tid), chunk, a, th, lds, busy);
         const Affine i1 = wave_inclusive<false>(m1);
@@ -1781,9 +1777,6 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
         __syncthreads();
         p0 = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 0), e0, nullptr);
     }
-#ifdef MGX_LIMITER_PARK
-    LB::park_sh(opaque(tid), th, lds);          // (behind the barrier above: nobody reads g0 from the plane any more)
-#endif
     DEV_MARK(2);      // attack window + scan
     if (tid == LB::T - a.gr) LB::lookback_publish(chunk, 2, a, p0.b);          // attack state at the end of the core
     if (wave == 1) LB::lookback_ask(lane, chunk, 2, a, polls);
@@ -1820,9 +1813,6 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     DEV_MARK(5);      // barrier after the takes (waits for wave 1's attack take)
 
     // hold output, release filter (scan 3)
-#ifdef MGX_LIMITER_PARK
-    LB::unpark_sh(opaque(tid), th, lds);
-#endif
     const Affine mr = LB::template phase_hold<FULL>(opaque(tid), a, th, LB::scalars(lds)[0], tail ? 0.0 : LB::scalars(lds)[2]);
     const Affine ir = wave_inclusive<false>(mr);
     if (lane == 63) LB::wave_totals(lds, 3)[wave] = ir;
@@ -2170,9 +2160,6 @@ __global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a) {
     bool chunk_busy = false;
 #pragma unroll
     for (int w = 0; w < LB::WAVES; ++w) chunk_busy = chunk_busy || LB::edge_sl(lds)[w] != 0.f;
-#ifdef MGX_LIMITER_NO_QUIET_CHUNKS
-    chunk_busy = true;
-#endif
     if (!chunk_busy && a.quiet_ok) limit_chunk_quiet<T>(a, chunk, lds, kept);
     else limit_chunk<T, true>(a, chunk, lds);
 }

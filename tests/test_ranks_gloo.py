@@ -61,3 +61,73 @@ def test_two_ranks_over_gloo():
     assert max0 == max1 == 11.0                # max over ranks, identical everywhere
     assert ok0 and ok1                          # rank 0's 128-byte id reached rank 1
     assert sum0 != sum1                         # every rank masters its own pair
+
+
+# ---- the batch front end itself under a real two-process world ---------------
+def _batch_worker(rank, world, port, folder, queue):
+    """What ``python -m torch.distributed.run ... -m matchering_amd.batch jobs.json`` does on each rank, with
+    the CPU oracle behind the ``master`` hook: ranks come from the launcher's environment, every rank masters
+    its own share of the jobs and writes its own files; gloo is used for the rendezvous and two barriers only
+    (the batch path has no data-path collective)."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+
+    import matchering_amd as mg
+    from matchering_amd import batch
+    from test_batch import _oracle_master
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        jobs = batch.jobs_from_json(os.path.join(folder, "jobs.json"))
+        cfg = mg.Config(internal_sample_rate=8000, fft_size=256, max_piece_size=2)
+        dist.barrier()
+        mine = batch.process_batch(jobs, cfg, lanes=2, io_threads=2, master=_oracle_master)      # rank, world: from the environment
+        dist.barrier()
+        many = batch.master_many([(np.zeros((4, 2), np.float32),) * 2] * 3, cfg, lanes=None,
+                                 master=lambda t, r, c, *needs: (rank, None, None))             # lanes=None without a GPU
+        queue.put((rank, mine, [m[0] for m in many]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_process_batch_in_two_rank_processes(tmp_path):
+    import json
+
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mastering_oracle as mo
+    from matchering_amd import audio_io
+    from matchering_amd.synth import synth
+
+    rate, jobs = 8000, []
+    for b in range(5):
+        t = (0.5 * synth(1.5, rate, 1 + 2 * b)).astype(np.float32)
+        r = np.clip(2.5 * synth(1.5, rate, 2 + 2 * b), -1, 1).astype(np.float32)
+        tp, rp = str(tmp_path / f"t{b}.wav"), str(tmp_path / f"r{b}.wav")
+        audio_io.write_wav(tp, t, rate, "FLOAT")
+        audio_io.write_wav(rp, r, rate, "FLOAT")
+        jobs.append({"target": tp, "reference": rp, "results": [{"file": str(tmp_path / f"out{b}.wav"), "subtype": "FLOAT"}]})
+    (tmp_path / "jobs.json").write_text(json.dumps(jobs))
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, str(tmp_path), queue)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(queue.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, mine0, tags0), (r1, mine1, tags1) = results
+    assert (r0, mine0, r1, mine1) == (0, [0, 2, 4], 1, [1, 3])          # pair i -> rank i mod world, nothing twice
+    assert tags0 == [0, 0, 0] and tags1 == [1, 1, 1]
+    ocfg = mo.params(internal_sample_rate=rate, fft_size=256, max_piece_size=2)
+    for b, job in enumerate(jobs):
+        t, _ = audio_io.read_wav(job["target"])
+        r, _ = audio_io.read_wav(job["reference"])
+        want = mo.master(t.astype(np.float64), r.astype(np.float64), ocfg, True, False, False)[0]
+        got, _ = audio_io.read_wav(job["results"][0]["file"])
+        assert np.abs(got - want).max() <= 1e-6
