@@ -226,6 +226,21 @@ int mgx_stage_times(mgx_handle* h, float* ms /* [MGX_STAGE_COUNT] */);
  * thousand a chip whose every SIMD issues VALU.  No reference counterpart: the boxes of a pool differ
  * in the clocks they sustain, and a throughput figure means little without them. */
 int mgx_clock_probe(mgx_handle* h, int32_t workgroups, int32_t iterations, double* out /* [4] */);
+/* The same for the memory system: out[0..2] = nanoseconds per dependent load in working sets of 1 GiB (HBM),
+ * 2 MiB (L2) and 8 KiB (first level); out[3] = GB/s of a streaming read of 1 GiB; out[4] = microseconds per
+ * launch of 200 empty kernels queued back to back; out[5], out[6] = nanoseconds per instruction of one wave
+ * walking 112 KiB of straight-line code, cold and again; out[7] = ns per dependent LDS read; out[8] = ns per
+ * workgroup barrier (256 threads); out[9] = ns per returning atomic on one word; out[10..13] = ns per instruction
+ * of a wave looping over 16 / 32 / 48 / 64 KiB of code (which footprints the instruction cache holds).
+ * Allocates and frees 1 GiB. */
+int mgx_memory_probe(mgx_handle* h, double* out /* [14] */);
+/* Code bytes of the seven big kernel families (analyze, match_curve, conv_prep, conv, correction_round,
+ * correction_tail, limit), bytes[family * 16 + variant] with variant = log2 of the transform size (0 / 1 for the
+ * 256 / 1024-block limiter, 0 for the untemplated kernels), as read from this library's own device code
+ * object -- what the kernels' first workgroups read as data to put their code into the L2 ahead of the
+ * instruction cache ("fast and slow boxes").  Returns the number of families; needs no
+ * GPU.  Zeros mean the code object could not be read and the kernels do not warm. */
+int mgx_code_bytes(int32_t* bytes, int32_t capacity);
 
 /* Device address of the FIR pair ([2][fft_size] float32: mid taps then side taps, level gain
  * not included) designed by the last mgx_master / uploaded by the last mgx_convolve on this

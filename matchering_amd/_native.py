@@ -99,6 +99,8 @@ SYMBOLS = {
     "mgx_stage_timing": (ctypes.c_int, [_VP, ctypes.c_int32]),
     "mgx_stage_times": (ctypes.c_int, [_VP, c_float_p]),
     "mgx_clock_probe": (ctypes.c_int, [_VP, ctypes.c_int32, ctypes.c_int32, c_double_p]),
+    "mgx_memory_probe": (ctypes.c_int, [_VP, c_double_p]),
+    "mgx_code_bytes": (ctypes.c_int, [c_int32_p, ctypes.c_int32]),
     "mgx_clipped_piece_sumsq": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                                ctypes.c_double, c_double_p]),
     "mgx_limit": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.POINTER(MgxConfig), ctypes.c_double,

@@ -50,6 +50,85 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 // ---------------------------------------------------------------------------
+// code sizes of the big kernels, from this library's own device code object (mgx_kernels.h, "code warming")
+// ---------------------------------------------------------------------------
+// libmgx.so -> section .hip_fatbin -> clang offload bundle -> the gfx950 ELF -> .symtab.  Anything unexpected
+// (a compressed bundle, a stripped table) leaves the sizes at zero and the kernels do not warm.
+#include <dlfcn.h>
+#include <elf.h>
+
+#include <fstream>
+#include <iterator>
+
+static const char* const CODE_NAMES[CODE_KERNELS] = {"k_analyzeILi", "k_match_curve", "k_conv_prepILi", "k_convILi",
+                                                     "k_correction_round", "k_correction_tail", "k_limitILi"};
+static bool elf_ok(const std::vector<char>& f, size_t at) {
+    return at + sizeof(Elf64_Ehdr) <= f.size() && std::memcmp(f.data() + at, ELFMAG, SELFMAG) == 0 &&
+           f[at + EI_CLASS] == ELFCLASS64;
+}
+// bytes[family][variant]: variant = the first template argument (log2 of the transform; 256 / 1024 blocks of the
+// limiter -> 0 / 1), 0 for plain kernels; the smaller size where two instantiations share a variant
+static void code_sizes_from_library(int (&bytes)[CODE_KERNELS][CODE_VARIANTS]) {
+    for (auto& row : bytes)
+        for (int& b : row) b = 0;
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<const void*>(&code_sizes_from_library), &info) || !info.dli_fname) return;
+    std::ifstream in(info.dli_fname, std::ios::binary);
+    if (!in) return;
+    const std::vector<char> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    if (!elf_ok(f, 0)) return;
+    const Elf64_Ehdr* eh = reinterpret_cast<const Elf64_Ehdr*>(f.data());
+    if (eh->e_shoff + (size_t)eh->e_shnum * sizeof(Elf64_Shdr) > f.size() || eh->e_shstrndx >= eh->e_shnum) return;
+    const Elf64_Shdr* sh = reinterpret_cast<const Elf64_Shdr*>(f.data() + eh->e_shoff);
+    const char* names = f.data() + sh[eh->e_shstrndx].sh_offset;
+    size_t fat = 0, fat_size = 0;
+    for (int i = 0; i < eh->e_shnum; ++i)
+        if (std::strcmp(names + sh[i].sh_name, ".hip_fatbin") == 0) { fat = sh[i].sh_offset; fat_size = sh[i].sh_size; }
+    static const char MAGIC[] = "__CLANG_OFFLOAD_BUNDLE__";
+    if (!fat || fat + fat_size > f.size() || fat_size < 32 || std::memcmp(f.data() + fat, MAGIC, 24) != 0) return;
+    uint64_t entries = 0;
+    std::memcpy(&entries, f.data() + fat + 24, 8);
+    size_t pos = fat + 32, dev = 0;
+    for (uint64_t e = 0; e < entries && pos + 24 <= fat + fat_size; ++e) {
+        uint64_t off = 0, size = 0, tsize = 0;
+        std::memcpy(&off, f.data() + pos, 8);
+        std::memcpy(&size, f.data() + pos + 8, 8);
+        std::memcpy(&tsize, f.data() + pos + 16, 8);
+        if (pos + 24 + tsize > fat + fat_size) return;
+        const std::string triple(f.data() + pos + 24, f.data() + pos + 24 + tsize);
+        if (triple.find("gfx950") != std::string::npos && fat + off + size <= f.size()) dev = fat + off;
+        pos += 24 + tsize;
+    }
+    if (!dev || !elf_ok(f, dev)) return;
+    const Elf64_Ehdr* de = reinterpret_cast<const Elf64_Ehdr*>(f.data() + dev);
+    if (dev + de->e_shoff + (size_t)de->e_shnum * sizeof(Elf64_Shdr) > f.size()) return;
+    const Elf64_Shdr* ds = reinterpret_cast<const Elf64_Shdr*>(f.data() + dev + de->e_shoff);
+    for (int i = 0; i < de->e_shnum; ++i) {
+        if (ds[i].sh_type != SHT_SYMTAB || ds[i].sh_link >= de->e_shnum) continue;
+        const char* str = f.data() + dev + ds[ds[i].sh_link].sh_offset;
+        const size_t count = ds[i].sh_size / sizeof(Elf64_Sym);
+        const Elf64_Sym* sym = reinterpret_cast<const Elf64_Sym*>(f.data() + dev + ds[i].sh_offset);
+        for (size_t k = 0; k < count; ++k) {
+            if (ELF64_ST_TYPE(sym[k].st_info) != STT_FUNC || sym[k].st_size == 0) continue;
+            const char* name = str + sym[k].st_name;
+            for (int c = 0; c < CODE_KERNELS; ++c) {
+                const char* hit = std::strstr(name, CODE_NAMES[c]);
+                if (!hit) continue;
+                int variant = 0;
+                const size_t len = std::strlen(CODE_NAMES[c]);
+                if (len >= 3 && std::strcmp(CODE_NAMES[c] + len - 3, "ILi") == 0) {      // templated: ...ILi<number>E
+                    const int number = std::atoi(hit + len);
+                    variant = number == 256 ? 0 : number == 1024 ? 1 : number;
+                }
+                if (variant < 0 || variant >= CODE_VARIANTS) continue;
+                int& slot = bytes[c][variant];
+                if (slot == 0 || (int)sym[k].st_size < slot) slot = (int)sym[k].st_size;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------
 struct DevBuf {
@@ -774,6 +853,21 @@ int mgx_create(int device, mgx_handle** out) {
     HIP_TRY(hipHostMalloc((void**)&h->error_host, 64, hipHostMallocMapped));
     std::memset(h->error_host, 0, 64);
     HIP_TRY(hipHostGetDevicePointer((void**)&h->error_dev, h->error_host, 0));
+    {   // code sizes for warm_code, once per device
+        static std::mutex mu;
+        static std::map<int, bool> done;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!done[device]) {
+            int bytes[CODE_KERNELS][CODE_VARIANTS];
+            code_sizes_from_library(bytes);
+            if (const char* off = std::getenv("MGX_NO_CODE_WARM"))          // measurement aid (tools/bench_stages.py variants)
+                if (off[0] == '1')
+                    for (auto& row : bytes)
+                        for (int& b : row) b = 0;
+            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(mgx::g_code_bytes), bytes, sizeof(bytes)));
+            done[device] = true;
+        }
+    }
     *out = h;
     return 0;
 }
@@ -1338,6 +1432,164 @@ int mgx_clock_probe(mgx_handle* h, int32_t workgroups, int32_t iterations, doubl
     out[2] = host[1] ? 100.0 * (double)host[0] / (double)host[1] : 0.0;
     out[3] = ms;
     return 0;
+}
+
+}  // extern "C"
+// memory probe (mgx_memory_probe): one lane chases a chain of dependent loads through a table
+template <bool BYPASS_L1>
+__global__ void k_chase(const unsigned* table, unsigned start, int hops, unsigned long long* ticks, unsigned* sink) {
+    unsigned i = start;
+    const unsigned long long t0 = wall_clock64();
+    for (int k = 0; k < hops; ++k) i = BYPASS_L1 ? __builtin_nontemporal_load(table + i) : table[i];
+    ticks[0] = wall_clock64() - t0;
+    sink[0] = i;
+}
+__global__ void k_chase_fill(unsigned* table, unsigned entries, unsigned stride) {
+    // entry j of the cycle: j -> (j + stride) mod entries, with entries and stride coprime (one cycle through all)
+    for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < entries; j += gridDim.x * 256) table[j] = (j + stride) % entries;
+}
+__global__ __launch_bounds__(256) void k_stream_read(const float4* x, long long n, float* sink) {
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float4 v = x[i];
+        acc += v.x + v.y + v.z + v.w;
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+// latency probes for what the kernels of this library lean on besides HBM: instruction fetch (a wave walks
+// 112 KiB of straight-line code, more than the instruction cache holds, cold and again), LDS (a chain of dependent
+// ds_read_b32), the workgroup barrier (256 threads), and a returning atomic on one L2 word
+// (.rept inside ONE asm statement: the assembler unrolls, the compiler sees a single instruction)
+#define MGX_CODE_16K(lit) asm volatile(".rept 2048\n v_add_f32 %0, " lit ", %0\n .endr" : "+v"(v))
+__global__ void k_ifetch(unsigned long long* ticks, float* sink, float seed) {
+    float v = seed;
+    const unsigned long long t0 = wall_clock64();
+    // 7 x 2048 VOP2 instructions with a 32-bit literal: 8 bytes each = 112 KiB of straight-line code
+    MGX_CODE_16K("0x3f800001"); MGX_CODE_16K("0x3f800002"); MGX_CODE_16K("0x3f800003"); MGX_CODE_16K("0x3f800004");
+    MGX_CODE_16K("0x3f800005"); MGX_CODE_16K("0x3f800006"); MGX_CODE_16K("0x3f800007");
+    ticks[0] = wall_clock64() - t0;
+    sink[0] = v;
+}
+// the same walk over a footprint of `blocks` x 16 KiB, sixteen times: nanoseconds per instruction of the last
+// eight rounds tell which footprints stay in the instruction cache
+__global__ void k_iloop(int blocks, unsigned long long* ticks, float* sink, float seed) {
+    float v = seed;
+    unsigned long long t0 = 0;
+#pragma unroll 1                        // (the compiler takes the .rept blocks for three lines each)
+    for (int rep = 0; rep < 16; ++rep) {
+        if (rep == 8) t0 = wall_clock64();
+        MGX_CODE_16K("0x3f800001");
+        if (blocks > 1) MGX_CODE_16K("0x3f800002");
+        if (blocks > 2) MGX_CODE_16K("0x3f800003");
+        if (blocks > 3) MGX_CODE_16K("0x3f800004");
+    }
+    ticks[0] = wall_clock64() - t0;
+    sink[0] = v;
+}
+__global__ __launch_bounds__(256) void k_onchip(unsigned long long* ticks, unsigned* word, unsigned* sink) {
+    __shared__ unsigned chain[1024];
+    for (int i = threadIdx.x; i < 1024; i += 256) chain[i] = (i + 331) & 1023;
+    __syncthreads();
+    unsigned i = 0;
+    unsigned long long t0 = wall_clock64();
+    for (int k = 0; k < 4096; ++k) i = chain[i];
+    if (threadIdx.x == 0) ticks[2] = wall_clock64() - t0;
+    __syncthreads();
+    t0 = wall_clock64();
+    for (int k = 0; k < 2048; ++k) __syncthreads();
+    if (threadIdx.x == 0) ticks[3] = wall_clock64() - t0;
+    unsigned a = i;
+    if (threadIdx.x == 0) {
+        t0 = wall_clock64();
+        for (int k = 0; k < 2048; ++k) a = atomicAdd(word, a & 1u) + 1u;
+        ticks[4] = wall_clock64() - t0;
+    }
+    sink[0] = i + a;
+}
+__global__ void k_empty() {}
+extern "C" {
+int mgx_memory_probe(mgx_handle* h, double* out) {
+    if (!h || !out) return fail(MGX_ERR_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(h->device));
+    const size_t big = (size_t)1 << 30;                         // 1 GiB: four times the Infinity Cache
+    unsigned* table = nullptr;
+    HIP_TRY(hipMalloc((void**)&table, big));
+    MGX_TRY(ensure(h, h->peak_words, 64));
+    unsigned long long* ticks = (unsigned long long*)h->peak_words.p;
+    // dependent-load latency in three working sets: HBM (1 GiB, 4 MiB + 64 B steps), L2 (2 MiB), first level (8 KiB)
+    const struct { size_t bytes; unsigned stride; int hops; } sets[3] = {
+        {big, (4u << 20) / 4 + 16, 4096}, {(size_t)2 << 20, 4099, 8192}, {(size_t)8 << 10, 67, 8192}};
+    for (int s = 0; s < 3; ++s) {
+        const unsigned entries = (unsigned)(sets[s].bytes / 4);
+        hipLaunchKernelGGL(k_chase_fill, dim3(2048), dim3(256), 0, h->stream, table, entries, sets[s].stride);
+        // a first walk warms the TLB (and, for the two small sets, the cache under test); the HBM walk is then
+        // repeated from an entry 256 bytes further on: the same pages, lines nobody has touched
+        if (s == 2) {
+            hipLaunchKernelGGL(k_chase<false>, dim3(1), dim3(1), 0, h->stream, table, 0u, sets[s].hops, ticks, (unsigned*)(ticks + 4));
+            hipLaunchKernelGGL(k_chase<false>, dim3(1), dim3(1), 0, h->stream, table, 0u, sets[s].hops, ticks, (unsigned*)(ticks + 4));
+        } else {
+            hipLaunchKernelGGL(k_chase<true>, dim3(1), dim3(1), 0, h->stream, table, 0u, sets[s].hops, ticks, (unsigned*)(ticks + 4));
+            hipLaunchKernelGGL(k_chase<true>, dim3(1), dim3(1), 0, h->stream, table, s == 0 ? 64u : 0u, sets[s].hops, ticks,
+                               (unsigned*)(ticks + 4));
+        }
+        unsigned long long t = 0;
+        HIP_TRY(hipMemcpyAsync(&t, ticks, 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        out[s] = (double)t * 10.0 / sets[s].hops;               // ns per hop (100 MHz ticks)
+    }
+    // streaming read of the 1 GiB, GB/s (best of three)
+    double best = 0.0;
+    for (int rep = 0; rep < 4; ++rep) {
+        HIP_TRY(hipEventRecord(h->ev0, h->stream));
+        hipLaunchKernelGGL(k_stream_read, dim3(4096), dim3(256), 0, h->stream, (const float4*)table, (long long)(big / 16),
+                           (float*)(ticks + 4));
+        HIP_TRY(hipEventRecord(h->ev1, h->stream));
+        HIP_TRY(hipEventSynchronize(h->ev1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        if (rep > 0) best = std::max(best, (double)big / (ms * 1e-3) / 1e9);
+    }
+    out[3] = best;
+    // 200 empty kernels back to back: microseconds per launch as the device sees them (events on the stream)
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    for (int k = 0; k < 200; ++k) hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, h->stream);
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    out[4] = ms * 1e3 / 200.0;
+    // instruction fetch, LDS, barrier, atomic (nanoseconds per instruction / hop / barrier / atomic)
+    HIP_TRY(hipMemsetAsync(ticks, 0, 64, h->stream));
+    hipLaunchKernelGGL(k_ifetch, dim3(1), dim3(64), 0, h->stream, ticks, (float*)(ticks + 6), 1.0f);        // cold
+    hipLaunchKernelGGL(k_ifetch, dim3(1), dim3(64), 0, h->stream, ticks + 1, (float*)(ticks + 6), 1.0f);    // again: from the L2
+    hipLaunchKernelGGL(k_onchip, dim3(1), dim3(256), 0, h->stream, ticks, (unsigned*)(ticks + 7), (unsigned*)(ticks + 6));
+    unsigned long long t5[5] = {0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(t5, ticks, sizeof(t5), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    out[5] = (double)t5[0] * 10.0 / 14336.0;                    // cold walk of 112 KiB of code
+    out[6] = (double)t5[1] * 10.0 / 14336.0;                    // second walk
+    out[7] = (double)t5[2] * 10.0 / 4096.0;                     // dependent LDS read
+    out[8] = (double)t5[3] * 10.0 / 2048.0;                     // workgroup barrier, 256 threads
+    out[9] = (double)t5[4] * 10.0 / 2048.0;                     // returning atomic on one word
+    // footprints of 16, 32, 48 and 64 KiB of code walked over and over
+    for (int b = 1; b <= 4; ++b) {
+        hipLaunchKernelGGL(k_iloop, dim3(1), dim3(64), 0, h->stream, b, ticks, (float*)(ticks + 6), 1.0f);
+        unsigned long long t = 0;
+        HIP_TRY(hipMemcpyAsync(&t, ticks, 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        out[9 + b] = (double)t * 10.0 / (8.0 * 2048.0 * b);
+    }
+    HIP_TRY(hipFree(table));
+    return 0;
+}
+
+int mgx_code_bytes(int32_t* bytes, int32_t capacity) {
+    if (!bytes || capacity < CODE_KERNELS * CODE_VARIANTS) return fail(MGX_ERR_ARGUMENT, "need room for 7 x 16 sizes");
+    int found[CODE_KERNELS][CODE_VARIANTS];
+    code_sizes_from_library(found);
+    for (int c = 0; c < CODE_KERNELS; ++c)
+        for (int v = 0; v < CODE_VARIANTS; ++v) bytes[c * CODE_VARIANTS + v] = found[c][v];
+    return CODE_KERNELS;
 }
 
 int mgx_last_fir(mgx_handle* h, void** taps_dev, int32_t* taps) {

@@ -72,6 +72,32 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 }
 
 // ---------------------------------------------------------------------------
+// code warming
+// ---------------------------------------------------------------------------
+// The kernels of this library are long stretches of straight-line code (a fully unrolled 8192-point
+// transform is 38 KB, the limiter 105 KB), and every launch finds them evicted from the L2s by the hundreds of
+// megabytes the previous kernel streamed.  The instruction cache then pulls them in line by line behind the
+// first wave: ~32 ns per 64-byte line on some boxes of the pool and ~170 ns on others (same clocks, same
+// memory latencies; `mgx_memory_probe`, profiles/r03_*_box_class.json) -- the whole difference between a
+// "fast" and a "slow" box.  So the first eight workgroups of a launch -- one per XCD: the L2s are per XCD --
+// read their own kernel's code AS DATA, 4 KB per load instruction and all of it in flight at once, which puts it
+// into the XCD's L2; instruction fetch then finds it there.  (Every workgroup of the first generation doing so was
+// measured: the limiter lost 14 us to the wait; so was warming again every 16th or 64th workgroup of an XCD, in
+// case the streamed audio pushes the code out of the L2 again: +6 / +13 us.)  Sizes come from the code object's
+// symbol table (mgx.hip, code_sizes_from_library); zero = no warming.
+enum { CODE_ANALYZE = 0, CODE_MATCH_CURVE, CODE_CONV_PREP, CODE_CONV, CODE_ROUND, CODE_TAIL, CODE_LIMIT, CODE_KERNELS };
+constexpr int CODE_VARIANTS = 16;                                  // second index: log2 of the transform; 0 / 1 = 256 / 1024-block limiter
+__device__ int g_code_bytes[CODE_KERNELS][CODE_VARIANTS];
+__device__ __forceinline__ void warm_code(int which, int variant = 0) {
+    if (blockIdx.x >= 8 || threadIdx.x >= 64) return;             // workgroup b runs on XCD b % 8: one wave per L2
+    const int bytes = g_code_bytes[which][variant] - 1024;         // (s_getpc sits a little behind the entry point)
+    const char* pc = reinterpret_cast<const char*>(__builtin_amdgcn_s_getpc());
+    int acc = 0;
+    for (int off = (int)threadIdx.x * 64; off < bytes; off += 4096) acc += *reinterpret_cast<const volatile int*>(pc + off);
+    if (acc == 0x7ffffff1) asm volatile("s_nop 0");                // (the sum is needed: the loads are waited for here)
+}
+
+// ---------------------------------------------------------------------------
 // convolution
 // ---------------------------------------------------------------------------
 template <int LOG2N>
@@ -209,6 +235,7 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2A
 // the plain kernel should not pay for)
 template <int LOG2N, bool MULTI>
 __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) void k_conv(Conv2Args a) {
+    warm_code(CODE_CONV, LOG2N);
     using CB = Conv2Block<LOG2N>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
@@ -253,6 +280,7 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
 template <int LOG2N>
 __global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_prep(const float* taps, const float2* tw, float2* tables,
                                                               int parts, const double* gain_ptr, double gain) {
+    warm_code(CODE_CONV_PREP, LOG2N);
     using CB = Conv2Block<LOG2N>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
@@ -296,6 +324,7 @@ constexpr int analysis_waves_per_simd() {
 template <int LOG2N>
 __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) void k_analyze(AnalysisArgs a0, AnalysisArgs a1,
                                                                                              int nwg0) {
+    warm_code(CODE_ANALYZE, LOG2N);
     using AB = Analysis2Block<LOG2N>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
@@ -747,6 +776,7 @@ __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack 
                                                       double threshold, double eps, double curve_floor,
                                                       double* raw /* [2][bins] */, double* c0_out,
                                                       CorrectionState* cs_init) {
+    warm_code(CODE_MATCH_CURVE);
     MGX_LDS;
     const int rows = tt.nwg + tr.nwg;
     double* acc = reinterpret_cast<double*>(mgx_smem);
@@ -1215,6 +1245,7 @@ __device__ __forceinline__ double correction_decide(const RoundArgs& a, int tota
 }
 
 __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
+    warm_code(CODE_ROUND);
     MGX_LDS;
     double* red = reinterpret_cast<double*>(mgx_smem);          // 64 doubles of scratch
     double* sums = red + 64;                                     // [divisions]
@@ -1392,6 +1423,7 @@ __host__ __device__ inline size_t correction_tail_lds_bytes(int divisions, int g
     return ((size_t)64 + divisions + (size_t)divisions * groups) * 8 + (size_t)4 * TAIL_CACHE_PER_WAVE * 4 + 16;
 }
 __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups, int rounds) {
+    warm_code(CODE_TAIL);
     MGX_LDS;
     double* red = reinterpret_cast<double*>(mgx_smem);          // 64 doubles of scratch
     double* sums = red + 64;                                     // [divisions]
@@ -2123,6 +2155,7 @@ __global__ __launch_bounds__(256, 2) void k_limit_general(LimiterArgs a, General
 // per CU the kernel is compiled for (register budget 512 / (WGS * T / 256) per lane)
 template <int T, int WGS>
 __global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a) {
+    warm_code(CODE_LIMIT, T == 256 ? 0 : 1);
     using LB = LimiterBlock<T>;
     MGX_LDS;
     float* lds = reinterpret_cast<float*>(mgx_smem);

@@ -66,3 +66,47 @@ def test_entry_points_that_need_no_device():
     rc = lib.mgx_create(0, ctypes.byref(h))
     assert rc < 0 and not h.value                      # no CPU path: creation fails, loudly
     assert lib.mgx_last_error()                        # ... with a message
+
+
+def test_code_sizes_are_read_from_the_librarys_own_code_object():
+    """mgx_code_bytes (no GPU needed): the windows the kernels' first workgroups read as data to put their own code
+    into the L2 (mgx_kernels.h, warm_code) come from the device ELF inside libmgx.so.  They must be there for the
+    instantiations the benchmarks run, and no larger than the symbols llvm-readelf reports: a window that
+    reaches past its kernel could reach past the end of the code object."""
+    import ctypes
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    from matchering_amd import _native
+
+    lib = _native.library()
+    sizes = (ctypes.c_int32 * 112)()
+    assert lib.mgx_code_bytes(sizes, 112) == 7
+    table = [[sizes[c * 16 + v] for v in range(16)] for c in range(7)]
+    analyze, match_curve, conv_prep, conv, rnd, tail, limit = table
+    assert analyze[12] > 4000 and conv[13] > 20000 and conv[14] > 20000 and conv_prep[13] > 2000
+    assert match_curve[0] > 4000 and rnd[0] > 4000 and tail[0] > 4000 and limit[0] > 40000 and limit[1] > 40000
+    assert lib.mgx_code_bytes(sizes, 8) < 0                                   # too little room: refused
+    objcopy, bundler, readelf = ("/opt/rocm/lib/llvm/bin/" + t for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf"))
+    if not all(os.path.exists(t) for t in (objcopy, bundler, readelf)):
+        pytest.skip("LLVM binary tools not installed")
+    folder = tempfile.mkdtemp()
+    try:
+        fat, dev = os.path.join(folder, "fat.bin"), os.path.join(folder, "dev.co")
+        subprocess.check_call([objcopy, "--dump-section", f".hip_fatbin={fat}", _native.LIB_PATH, os.path.join(folder, "x.so")])
+        subprocess.check_call([bundler, "--unbundle", "--type=o", f"--input={fat}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={dev}"])
+        listing = subprocess.run([readelf, "-s", "--wide", dev], capture_output=True, text=True, check=True).stdout
+    finally:
+        shutil.rmtree(folder, ignore_errors=True)
+    seen = {}
+    for line in listing.splitlines():
+        m = re.match(r"\s*\d+:\s+[0-9a-f]+\s+(\d+)\s+FUNC\s+\S+\s+\S+\s+\S+\s+(\S+)", line)
+        if m:
+            seen[m.group(2)] = int(m.group(1))
+    assert seen["_ZN3mgx6k_convILi13ELb0EEEvNS_9Conv2ArgsE"] == conv[13]
+    assert seen["_ZN3mgx7k_limitILi256ELi4EEEvNS_11LimiterArgsE"] == limit[0]
+    assert seen["_ZN3mgx9k_analyzeILi12EEEvNS_12AnalysisArgsES1_i"] == analyze[12]
+    assert min(seen["_ZN3mgx6k_convILi14ELb0EEEvNS_9Conv2ArgsE"], seen["_ZN3mgx6k_convILi14ELb1EEEvNS_9Conv2ArgsE"]) == conv[14]

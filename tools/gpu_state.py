@@ -199,6 +199,16 @@ def compact_state(dev=None):
         out["under_probe"] = seen
         out["shader_mhz_one_workgroup"], _ = probe(1, 200000)
         out["shader_mhz_short_kernel"], out["short_kernel_ms"] = probe(2048, 2000)
+        mem = (ctypes.c_double * 14)()
+        _native.check(lib.mgx_memory_probe(dev.handle, mem))
+        out["memory_probe"] = {"ns_per_dependent_load": {"1GiB_hbm": round(mem[0], 1), "2MiB_l2": round(mem[1], 1),
+                                                         "8KiB_first_level": round(mem[2], 1)},
+                               "stream_read_GBs": round(mem[3], 1), "us_per_empty_launch": round(mem[4], 2),
+                               "ns_per_instruction_112KiB_code": {"cold": round(mem[5], 2), "again": round(mem[6], 2)},
+                               "ns_per_dependent_lds_read": round(mem[7], 1), "ns_per_barrier_256": round(mem[8], 1),
+                               "ns_per_returning_atomic": round(mem[9], 1),
+                               "ns_per_instruction_looping_over_code_of": {"16KiB": round(mem[10], 2), "32KiB": round(mem[11], 2),
+                                                                            "48KiB": round(mem[12], 2), "64KiB": round(mem[13], 2)}}
         if own:
             dev.close()
     except Exception as exc:                                     # noqa: BLE001
