@@ -111,10 +111,10 @@ class Ranks:
 
 def spin_up(sync, step, seconds):
     """Untimed steps for ``seconds`` before the warm-up.  The device sleeps while the host builds the synthetic
-    pairs (sclk ~100 MHz, deep sleep enabled) and takes tens of milliseconds of work to climb back to the
-    clocks it sustains; W = 3-5 warm-up steps are 2 ms.  Measured on one box: 0.504 ms per step in a cold
-    10-step run, 0.482 ms sustained over 3000 steps (profiles/r03_h_box_class_fast_box.json).  A mastering
-    service is a busy device, so that is the state the K timed steps should see.  Returns the steps run."""
+    pairs (sclk ~100 MHz, deep sleep enabled) and W = 3-5 warm-up steps are only 2 ms; a mastering service is a
+    busy device, so that is the state the K timed steps should see.  On the boxes measured it makes no
+    difference (0.504 ms per step with and without; profiles/r03_e_*, r03_i_*): it is insurance against a box
+    that climbs out of idle slowly, not a speed-up.  Returns the steps run."""
     done, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(8):
@@ -300,8 +300,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "spinup": {"seconds": args.spinup, "steps": spun,
-                   "note": "untimed steps before the W warm-up steps, so that the K timed steps run at the clocks a busy "
-                           "device sustains rather than on the climb out of idle (0.504 vs 0.482 ms per step measured)"},
+                   "note": "untimed steps before the W warm-up steps, so that the K timed steps see a busy device rather "
+                           "than the climb out of idle; no measurable effect on the boxes seen so far"},
         "config": {"workload": wl.describe(), "frames_per_gpu_per_step": wl.frames,
                    "pairs_per_gpu_per_step": wl.pairs, "parallelism": f"pairs x{ranks.world * wl.pairs}",
                    **({"lane_choice": wl.lane_choice} if wl.lane_choice else {})},
