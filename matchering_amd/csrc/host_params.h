@@ -130,9 +130,9 @@ inline std::vector<double> lookback_matrices(int k, const std::vector<Wide>& m, 
 
 // What is left of the backward attack smoother's state after the right halo, relative to the state (gains
 // are <= 1, so this bounds the error of gA at the core's last frame; it falls off by rho per frame before it).
-#ifndef MGX_ATTACK_FORGET
-#define MGX_ATTACK_FORGET 1e-8
-#endif
+// 1e-7 is a tenth of the RMS bound the limiter tests hold (1e-6) and leaves 224 of a chunk's 256 blocks to the
+// core at the default timings (1e-8: 221; 1e-6: 228, measured 1 % faster: profiles/r03_f_ab_limiter_quiet_chunks.txt).
+constexpr double MGX_ATTACK_FORGET = 1e-7;
 
 struct LimiterParams {
     int attack, hold, hw, hb, ha;
