@@ -214,7 +214,7 @@ class Workload:
                 b.release()
 
 
-def measure_traffic(workload, timeout=240):
+def measure_traffic(workload, timeout=150):
     """HBM bytes per launch of the streaming kernels from the L2's memory-side counters, measured NOW: one
     rocprofv3 pass per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass) over a short run of this same
     script (rocprofv3 cannot wrap the process it runs in).  MI355X_MICROARCH.md, HBM: FETCH_SIZE is in KiB and
@@ -229,6 +229,8 @@ def measure_traffic(workload, timeout=240):
 
     if not shutil.which("rocprofv3"):
         return {}
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER_")) for k in os.environ):
+        return {}                                          # already running under a profiler: no nesting
     kib = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         folder = tempfile.mkdtemp(prefix="mgx_pmc_", dir="/tmp")
