@@ -147,7 +147,15 @@ def library():
         # and returns at once when they agree: an edited kernel or struct never meets a stale binary
         from . import build as _build
 
-        _build.build()
+        try:
+            _build.build()
+        except Exception as exc:               # noqa: BLE001 -- no hipcc on this host, a read-only tree ...
+            if not os.path.exists(LIB_PATH):
+                raise
+            import warnings
+
+            warnings.warn(f"libmgx.so could not be rebuilt from the sources beside it ({exc!r}); loading the "
+                          f"existing binary, which may be older than they are", RuntimeWarning)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError here = header and library disagree

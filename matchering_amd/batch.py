@@ -411,6 +411,12 @@ def process_batch(jobs, config=None, rank=None, world_size=None, device_index=No
             pool.close()
         for s in savers:
             s.result()
+    if master is None:                       # a batch of varied track lengths leaves many size classes behind
+        from .device import pinned
+
+        for lane in range(lanes):
+            lane_device(device_index, lane).trim()
+        pinned.trim()
     return mine
 
 

@@ -53,6 +53,30 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     out = out or OUT
     if not force and up_to_date(out, extra_flags):
         return out
+    import fcntl
+    import tempfile
+
+    # two ranks starting together must not compile onto the same path: one lock per output, the binary is
+    # written beside it and moved into place when it is whole
+    with open(out + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and up_to_date(out, extra_flags):          # somebody else built it while this process waited
+            return out
+        fd, partial = tempfile.mkstemp(prefix=os.path.basename(out) + ".", suffix=".part", dir=os.path.dirname(out))
+        os.close(fd)
+        try:
+            _compile(partial, extra_flags, verbose)
+            os.chmod(partial, 0o755)
+            os.replace(partial, out)
+        finally:
+            if os.path.exists(partial):
+                os.remove(partial)
+        with open(_stamp(out), "w") as fh:
+            fh.write(source_hash(extra_flags))
+    return out
+
+
+def _compile(out, extra_flags, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fno-slp-vectorize: packing the butterflies' float pairs into v_pk_* costs more v_mov shuffles
     # than it saves on gfx950 (k_conv 233 -> 196 us, k_analyze 108 -> 65 us, profiles/r01_d_*)
@@ -60,9 +84,6 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
-    with open(_stamp(out), "w") as fh:
-        fh.write(source_hash(extra_flags))
-    return out
 
 
 if __name__ == "__main__":

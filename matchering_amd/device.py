@@ -26,10 +26,15 @@ class _PinnedPool:
     with asynchronous DMA instead of a staged copy."""
 
     KEEP = 8                                   # free blocks kept per size class
+    MAX_FREE_BYTES = 4 << 30                   # ... and in total: above 16 MiB every track length is its own size
+                                               # class, so a long batch of varied tracks would otherwise pile up
+                                               # page-locked memory without bound (ADVICE round 2)
 
     def __init__(self):
         self.lock = threading.Lock()
         self.free = {}                         # size class -> [address, ...]
+        self.free_bytes = 0
+        self.order = []                        # (size, address) of the free blocks, oldest first
         self.starts, self.ends = [], []        # live blocks, sorted by address
 
     def empty(self, shape, dtype=np.float32):
@@ -39,6 +44,9 @@ class _PinnedPool:
         with self.lock:
             stack = self.free.get(size)
             address = stack.pop() if stack else None
+            if address is not None:
+                self.free_bytes -= size
+                self.order.remove((size, address))
         if address is None:
             ptr = ctypes.c_void_p()
             check(library().mgx_host_alloc(size, ctypes.byref(ptr)))
@@ -53,17 +61,42 @@ class _PinnedPool:
         return array
 
     def _give_back(self, address, size):
+        doomed = []
         with self.lock:
             stack = self.free.setdefault(size, [])
-            if len(stack) < self.KEEP:
+            if len(stack) < self.KEEP and size <= self.MAX_FREE_BYTES:
                 stack.append(address)
-                return
-            i = bisect.bisect_left(self.starts, address)
-            del self.starts[i], self.ends[i]
-        try:
-            library().mgx_host_free(ctypes.c_void_p(address))
-        except Exception:
-            pass
+                self.order.append((size, address))
+                self.free_bytes += size
+                while self.free_bytes > self.MAX_FREE_BYTES:          # trim the blocks that have waited longest
+                    old_size, old_address = self.order.pop(0)
+                    self.free[old_size].remove(old_address)
+                    self.free_bytes -= old_size
+                    doomed.append(old_address)
+            else:
+                doomed.append(address)
+            for a in doomed:
+                i = bisect.bisect_left(self.starts, a)
+                del self.starts[i], self.ends[i]
+        for a in doomed:
+            try:
+                library().mgx_host_free(ctypes.c_void_p(a))
+            except Exception:
+                pass
+
+    def trim(self):
+        """Give every free block back to the OS (``process_batch`` calls this when it is done)."""
+        with self.lock:
+            doomed = [a for _, a in self.order]
+            self.order, self.free, self.free_bytes = [], {}, 0
+            for a in doomed:
+                i = bisect.bisect_left(self.starts, a)
+                del self.starts[i], self.ends[i]
+        for a in doomed:
+            try:
+                library().mgx_host_free(ctypes.c_void_p(a))
+            except Exception:
+                pass
 
     def holds(self, array):
         """True when ``array``'s bytes lie inside one of this pool's blocks."""
@@ -148,6 +181,7 @@ class Device:
         self.lock = threading.RLock()
         self._keep_until_sync = []            # host arrays with a queued DMA still reading them
         self._blocks = {}                     # free HBM blocks by size class
+        self._free_hbm = 0                    # ... and their total size
         h = ctypes.c_void_p()
         check(library().mgx_create(index, ctypes.byref(h)))
         self.handle = h
@@ -164,11 +198,13 @@ class Device:
     # HBM blocks are recycled: a block released while kernels of THIS handle may still read it is only
     # reused by later work on the same stream, which is ordered behind them
     KEEP_BLOCKS = 6
+    MAX_FREE_HBM = 24 << 30                  # free HBM blocks kept per handle, in total (a lane's share of 288 GB)
 
     def _take_block(self, capacity):
         with self.lock:
             stack = self._blocks.get(capacity)
             if stack:
+                self._free_hbm -= capacity
                 return stack.pop()
         ptr = ctypes.c_void_p()
         check(library().mgx_malloc(self.handle, capacity, ctypes.byref(ptr)))
@@ -177,10 +213,19 @@ class Device:
     def _give_block(self, capacity, ptr):
         with self.lock:
             stack = self._blocks.setdefault(capacity, [])
-            if len(stack) < self.KEEP_BLOCKS:
+            if len(stack) < self.KEEP_BLOCKS and self._free_hbm + capacity <= self.MAX_FREE_HBM:
                 stack.append(ptr)
+                self._free_hbm += capacity
                 return
         library().mgx_free(self.handle, ctypes.c_void_p(ptr))
+
+    def trim(self):
+        """Free every recycled HBM block of this handle."""
+        with self.lock:
+            stacks, self._blocks, self._free_hbm = self._blocks, {}, 0
+        for stack in stacks.values():
+            for ptr in stack:
+                library().mgx_free(self.handle, ctypes.c_void_p(ptr))
 
     def __del__(self):
         try:

@@ -562,3 +562,46 @@ def test_resampling_runs_in_float64_also_for_float32_files():
     out64, _ = checker.check(audio.astype(np.float64), 48000, cfg, "reference")
     assert rate == cfg.internal_sample_rate and out32.dtype == np.float64
     assert np.array_equal(out32, out64)
+
+
+def test_pinned_pool_is_capped_by_total_bytes(monkeypatch):
+    """ADVICE round 2: free page-locked blocks are kept per size class AND under a total, the oldest go first;
+    ``trim`` gives everything back.  (A stand-in allocator behind ``library()``: no GPU needed.)"""
+    import ctypes
+    import gc
+
+    from matchering_amd import device
+
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype = ctypes.c_void_p
+    libc.free.argtypes = [ctypes.c_void_p]
+    live = set()
+
+    class FakeLibrary:
+        @staticmethod
+        def mgx_host_alloc(size, out):
+            address = libc.malloc(ctypes.c_size_t(int(size)))
+            live.add(address)
+            ctypes.cast(out, ctypes.POINTER(ctypes.c_void_p))[0] = address
+            return 0
+
+        @staticmethod
+        def mgx_host_free(ptr):
+            live.discard(ptr.value)
+            libc.free(ptr)
+            return 0
+
+    monkeypatch.setattr(device, "library", lambda: FakeLibrary)
+    pool = device._PinnedPool()
+    pool.MAX_FREE_BYTES = 3 << 20
+    arrays = [pool.empty((1 << 18,), np.float32) for _ in range(6)]          # six 1 MiB blocks in use
+    assert len(live) == 6 and all(pool.holds(a) for a in arrays)
+    del arrays
+    gc.collect()
+    assert pool.free_bytes == 3 << 20 and len(live) == 3                      # three kept, the three oldest returns freed
+    again = pool.empty((1 << 18,), np.float32)                                # recycled, not allocated
+    assert len(live) == 3 and pool.free_bytes == 2 << 20
+    del again
+    gc.collect()
+    pool.trim()
+    assert pool.free_bytes == 0 and not live and not pool.starts
