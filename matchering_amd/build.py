@@ -80,7 +80,10 @@ def _compile(out, extra_flags, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fno-slp-vectorize: packing the butterflies' float pairs into v_pk_* costs more v_mov shuffles
     # than it saves on gfx950 (k_conv 233 -> 196 us, k_analyze 108 -> 65 us, profiles/r01_d_*)
-    cmd = [hipcc, *FLAGS, *extra_flags, "-o", out] + SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-lrocprofiler-sdk-roctx", "-Wl,-rpath,/opt/rocm/lib"]
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(hipcc)), "lib")
+    roctx = (["-lrocprofiler-sdk-roctx"] if os.path.exists(os.path.join(rocm_lib, "librocprofiler-sdk-roctx.so"))
+             else ["-DMGX_NO_ROCTX"])             # (ROCm installs without the profiler SDK: the stage markers go)
+    cmd = [hipcc, *FLAGS, *extra_flags, *roctx, "-o", out] + SOURCES + [f"-L{rocm_lib}", "-lrccl", f"-Wl,-rpath,{rocm_lib}"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
