@@ -29,9 +29,9 @@
 //    across the workgroup by an ordered float64 scan (wave shuffles + one LDS hop), and the exact
 //    outputs are the local run plus alpha^j times the carry.  Rounding never accumulates beyond
 //    16 frames.
-//  * The attack smoother's pole rho = exp(coef/attack) forgets quickly: rho^HA <= 1e-8 after
-//    HA ~ 9*attack frames.  The right halo is HA (+ window) frames long, so the backward run of
-//    scipy.signal.filtfilt started from zero at the end of the halo is exact (to 1e-8) inside the
+//  * The attack smoother's pole rho = exp(coef/attack) forgets quickly: rho^HA <= 1e-7 after
+//    HA ~ 8*attack frames.  The right halo is HA (+ window) frames long, so the backward run of
+//    scipy.signal.filtfilt started from zero at the end of the halo is exact (to 1e-7) inside the
 //    core and never needs a later chunk.  filtfilt's edge handling (odd extension by 6,
 //    steady-state initial conditions) is applied by the chunks that contain frame 0 / frame n-1.
 //  * The forward attack smoother, the hold and the release low-passes carry state from chunk to
