@@ -528,7 +528,8 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     }
     const FirPlanView pl = plan->view(pd.blob);
     const size_t per = (size_t)3 * pl.bins + (size_t)3 * pl.nlog + pl.lw.anchors;
-    MGX_TRY(ensure(h, h->fir_scratch, (2 * per + 2 * (size_t)pl.bins) * sizeof(double)));
+    // (two scratch planes, the raw curves, and the partial transforms of the tap synthesis: [2][fft/2] double2)
+    MGX_TRY(ensure(h, h->fir_scratch, (2 * per + 2 * (size_t)pl.bins + 2 * (size_t)pl.fft + 2) * sizeof(double)));
     MGX_TRY(ensure(h, h->scalars, 64));
     MGX_TRY(ensure(h, h->taps, (size_t)2 * cfg->fft_size * sizeof(float)));
     FirInputs in;
@@ -584,11 +585,33 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
         hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
                            (const int2*)pd.band, (const double*)raw, scratch);
     }
-    const size_t lds_taps = ((size_t)pl.bins + 2048 + 2 * TAP_ROWS) * sizeof(double);
     if (pl.fft < 64) return fail(MGX_ERR_UNSUPPORTED, "fft_size below 64 is not implemented");
-    MGX_TRY(allow_lds(k_fir_taps, lds_taps));
-    hipLaunchKernelGGL(k_fir_taps, dim3((pl.fft / 4 + 1 + TAP_ROWS - 1) / TAP_ROWS, 2), dim3(1024), lds_taps, h->stream,
-                       pl, (const double*)scratch, (float*)h->taps.p);
+    // tap synthesis: the symmetric cosine sum up to 4096 taps (8 us in one launch -- two launches of the split
+    // transform cost 10), the split transform from 8192 taps on (13 us against 47 at 16384;
+    // profiles/r03_x_tap_synthesis.txt).  MGX_TAPS_BY_COSINE_SUM=1 forces the sum: the A/B switch of that profile.
+    if (pl.fft >= TAP_TRANSFORM_FROM && !std::getenv("MGX_TAPS_BY_COSINE_SUM")) {
+        const int m = pl.fft / 2 / TAP_SPLIT;
+        const size_t sub_at = (2 * per + 2 * (size_t)pl.bins + 1) & ~(size_t)1;      // 16-byte aligned
+        double2* sub = reinterpret_cast<double2*>(scratch + sub_at);
+        const size_t lds_sub = fir_taps_sub_lds_bytes(m);
+        switch (m) {
+#define MGX_TAPS_SUB(L)                                                                                                \
+    case 1 << L:                                                                                                       \
+        hipLaunchKernelGGL(k_fir_taps_sub<L>, dim3(TAP_SPLIT, 2), dim3(TapFft<L>::T), lds_sub, h->stream, pl,          \
+                           (const double*)scratch, sub);                                                               \
+        break;
+            MGX_TAPS_SUB(9) MGX_TAPS_SUB(10) MGX_TAPS_SUB(11)
+#undef MGX_TAPS_SUB
+            default: return fail(MGX_ERR_UNSUPPORTED, "tap synthesis: transform length not instantiated");
+        }
+        hipLaunchKernelGGL(k_fir_taps_combine, dim3((pl.fft / 2 + 255) / 256, 2), dim3(256), 0, h->stream, pl,
+                           (const double2*)sub, TAP_SPLIT, (float*)h->taps.p);
+    } else {
+        const size_t lds_taps = ((size_t)pl.bins + 2048 + 2 * TAP_ROWS) * sizeof(double);
+        MGX_TRY(allow_lds(k_fir_taps, lds_taps));
+        hipLaunchKernelGGL(k_fir_taps, dim3((pl.fft / 4 + 1 + TAP_ROWS - 1) / TAP_ROWS, 2), dim3(1024), lds_taps, h->stream,
+                           pl, (const double*)scratch, (float*)h->taps.p);
+    }
     HIP_TRY(hipGetLastError());
     h->last_taps = cfg->fft_size;
     return 0;

@@ -1052,6 +1052,129 @@ __global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double*
     }
 }
 
+// The same taps by a transform, for fft_size >= 8192 (below that the sum above is one 8 us launch and wins).
+// numpy.fft.irfft of the real, even spectrum H[0..F/2] as ONE complex inverse DFT of N = F/2 points:
+//     Z[k] = (H[k] + H[N-k]) + i w^k (H[k] - H[N-k]),  w = exp(2 pi i / F);   z = IDFT_N(Z) / F;
+//     h0[2n] = Re z[n],  h0[2n+1] = Im z[n]
+// (the even and odd output samples are the real and imaginary parts of one half-length transform), then
+// ifftshift and the Hann window as above.  A workgroup is one CU, and one CU needs 32 us for 8192 points in
+// float64 however the passes are arranged (measured: instruction issue, not LDS or its banks), so the transform
+// is split by decimation in time over R = 8 workgroups per channel:
+//   k_fir_taps_sub<LOG2M>   grid (R, 2): workgroup rho transforms Z[R m + rho], m < M = N/R, in LDS -- Z goes in
+//       bit-reversed, then passes that do TWO radix-2 stages in registers (four points per group, a barrier per
+//       pass; one plain radix-2 stage first when log2 M is odd); twiddles from a quarter-wave table in LDS
+//       (M/4 + 1 exact values of cos_table, the rest by symmetry), so no pass waits on global memory;
+//   k_fir_taps_combine      grid (N/256, 2): z[n] = sum_rho w_N^(rho n) A_rho[n mod M] in a fixed order, scale,
+//       window, store the two taps of z[n].
+// O(F log F) instead of the cosine sum's O(F^2 / 8): 13 us against 47 at 16384 taps; float64 throughout,
+// twiddles are table values (cos_table holds cos(2 pi j / F)).  M <= 2048 (32768 taps) is 38 KB of LDS.
+// (The bit-reversed store puts a wavefront's 64 consecutive m at a stride of M/64 points: one LDS bank.  A spare
+// point after every M/64 turns that stride odd -- TapFft::at -- and costs the later passes nothing.)
+constexpr int TAP_SPLIT = 8, TAP_TRANSFORM_FROM = 8192;
+__host__ __device__ inline size_t fir_taps_sub_lds_bytes(int m) { return ((size_t)m + 64) * 16 + ((size_t)m / 4 + 1) * 8; }
+template <int LOG2M>
+struct TapFft {
+    static constexpr int M = 1 << LOG2M, PAD_SHIFT = LOG2M >= 8 ? LOG2M - 6 : 30;
+    static constexpr int T = M / 4 < 64 ? 64 : (M / 4 > 1024 ? 1024 : M / 4);         // threads: a group of four points each
+    static __device__ __forceinline__ int at(int i) { return i + (i >> PAD_SHIFT); }
+};
+template <int M>
+__device__ __forceinline__ double2 quarter_wave_twiddle(const double* q, int t) {      // exp(+2 pi i t / M), 0 <= t < M/2
+    const int d = t - M / 4;
+    return make_double2(d <= 0 ? q[t] : -q[M / 2 - t], q[d < 0 ? -d : d]);
+}
+__device__ __forceinline__ void dit_butterfly(double2& x, double2& y, double2 w) {
+    const double yr = fma(y.x, w.x, -y.y * w.y), yi = fma(y.x, w.y, y.y * w.x);
+    y = make_double2(x.x - yr, x.y - yi);
+    x = make_double2(x.x + yr, x.y + yi);
+}
+template <int LOG2M>
+__global__ __launch_bounds__(TapFft<LOG2M>::T) void k_fir_taps_sub(FirPlanView pl, const double* scratch,
+                                                                   double2* sub /* [2][R][M] */) {
+    MGX_LDS;
+    using P = TapFft<LOG2M>;
+    constexpr int M = P::M, T = P::T;
+    double2* z = reinterpret_cast<double2*>(mgx_smem);       // [M + 64], indexed through P::at
+    double* q = reinterpret_cast<double*>(z + M + 64);       // [M/4 + 1]: cos(2 pi j / M)
+    const int plane = blockIdx.y, rho = blockIdx.x, r = gridDim.x, n = M * r, f = 2 * n;
+    const FirScratch s = fir_scratch(const_cast<double*>(scratch), pl, plane);
+    for (int j = threadIdx.x; j <= M / 4; j += T) q[j] = pl.cos_table[2 * r * j];
+#pragma unroll
+    for (int m0 = 0; m0 < M; m0 += T) {
+        const int m = m0 + threadIdx.x;
+        if (M >= T || m < M) {
+            const int k = r * m + rho;
+            const double a = s.smooth[k], b = s.smooth[n - k];
+            const double c = pl.cos_table[k], sn = pl.cos_table[(k - f / 4) & (f - 1)];     // w^k = c + i sn
+            const double sum = a + b, d = a - b;
+            z[P::at((int)(__brev((unsigned)m) >> (32 - LOG2M)))] = make_double2(sum - sn * d, c * d);
+        }
+    }
+    __syncthreads();
+    int h = 1;
+    if (LOG2M & 1) {
+#pragma unroll
+        for (int b0 = 0; b0 < M / 2; b0 += T) {
+            const int b = b0 + threadIdx.x;
+            if (M / 2 >= T || b < M / 2) {
+                const int i0 = P::at(2 * b), i1 = P::at(2 * b + 1);
+                double2 x = z[i0], y = z[i1];
+                dit_butterfly(x, y, make_double2(1.0, 0.0));
+                z[i0] = x, z[i1] = y;
+            }
+        }
+        __syncthreads();
+        h = 2;
+    }
+#pragma unroll 1
+    for (; h < M; h <<= 2) {
+#pragma unroll
+        for (int b0 = 0; b0 < M / 4; b0 += T) {
+            const int b = b0 + threadIdx.x;
+            if (M / 4 >= T || b < M / 4) {
+                const int rr = b & (h - 1), j = ((b - rr) << 2) + rr;
+                const int ta = rr * (M / 2 / h), tb = ta >> 1;
+                const int i0 = P::at(j), i1 = P::at(j + h), i2 = P::at(j + 2 * h), i3 = P::at(j + 3 * h);
+                double2 a0 = z[i0], a1 = z[i1], a2 = z[i2], a3 = z[i3];
+                const double2 wa = quarter_wave_twiddle<M>(q, ta);
+                dit_butterfly(a0, a1, wa);
+                dit_butterfly(a2, a3, wa);
+                dit_butterfly(a0, a2, quarter_wave_twiddle<M>(q, tb));
+                dit_butterfly(a1, a3, quarter_wave_twiddle<M>(q, tb + M / 4));
+                z[i0] = a0, z[i1] = a1, z[i2] = a2, z[i3] = a3;
+            }
+        }
+        __syncthreads();
+    }
+    double2* out = sub + ((size_t)plane * r + rho) * M;
+#pragma unroll
+    for (int i0 = 0; i0 < M; i0 += T) {
+        const int i = i0 + threadIdx.x;
+        if (M >= T || i < M) out[i] = z[P::at(i)];
+    }
+}
+__global__ __launch_bounds__(256) void k_fir_taps_combine(FirPlanView pl, const double2* sub /* [2][R][M] */, int r,
+                                                          float* taps /* [2][F] */) {
+    const int plane = blockIdx.y, f = pl.fft, n_all = f / 2, m_len = n_all / r;
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= n_all) return;
+    const double2* a = sub + (size_t)plane * n_all + (n & (m_len - 1));
+    double zr = 0.0, zi = 0.0;
+    for (int rho = 0; rho < r; ++rho) {
+        const int e = (2 * rho * n) & (f - 1);                // w_N^(rho n) = exp(2 pi i (2 rho n) / F)
+        const double c = pl.cos_table[e], sn = pl.cos_table[(e - f / 4) & (f - 1)];
+        const double2 v = a[(size_t)rho * m_len];
+        zr += fma(v.x, c, -v.y * sn);
+        zi += fma(v.x, sn, v.y * c);
+    }
+    const double inv = 1.0 / (double)f;
+    const int i = (2 * n + n_all) & (f - 1);                  // ifftshift: tap i holds h0[(i + F/2) mod F]; i is even
+    float2 t;
+    t.x = (float)(zr * inv * pl.hann[i]);
+    t.y = (float)(zi * inv * pl.hann[i + 1]);
+    *reinterpret_cast<float2*>(taps + (size_t)plane * f + i) = t;
+}
+
 // ---------------------------------------------------------------------------
 // level correction (stages.py:138-170)
 // ---------------------------------------------------------------------------

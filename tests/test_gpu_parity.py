@@ -580,7 +580,7 @@ def test_other_sample_rates(rate):
         assert rms_error(mine, ref) <= RMS_TOL
 
 
-@pytest.mark.parametrize("fft_size", [64, 256, 1024, 2048, 8192])
+@pytest.mark.parametrize("fft_size", [64, 128, 256, 512, 1024, 2048, 8192])
 def test_other_fft_sizes(fft_size):
     """Every transform plan end to end: analysis segments of fft_size frames and convolution blocks of
     twice that (fft2.h plans 6..14)."""
