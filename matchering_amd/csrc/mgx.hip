@@ -1263,7 +1263,8 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
         ra.piece = tw.piece;
         ra.divisions = tw.divisions;
         ra.chunks = std::max(1, 1024 / tw.divisions);        // ~1000 workgroups: each pays one publish + ticket
-        MGX_TRY(ensure(h, h->partial, (size_t)ra.divisions * ra.chunks * sizeof(double)));
+        // (round 0's partial sums, and behind them the peak words of k_correction_tail's workgroups)
+        MGX_TRY(ensure(h, h->partial, (size_t)2 * ra.divisions * ra.chunks * sizeof(double)));
         ra.partial = (double*)h->partial.p;
         // arrival counters [1 + divisions], zero between launches; the 16 gain words of k_correction_tail
         // live in their own buffer (a layout that moved with `divisions` would leave one call's preset
@@ -1298,10 +1299,6 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
         ra.tail_gains = rounds > 1 ? (unsigned long long*)h->tail_gains.p : nullptr;
         auto with_final = [&](RoundArgs& r) -> int {          // the launch that runs the last round
             r.final_peaks = (const float*)h->block_peak.p;
-            if (result_dev) {
-                MGX_TRY(limiter_state(h, n_target, cfg, &r.lim_published, &r.lim_words, &r.lim_ticket));
-                limiter_preset = true;
-            }
             return 0;
         };
         if (rounds >= 1) {                                    // round 0 streams the mid plane and builds the band lists
@@ -1309,6 +1306,10 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
             r0.final_peaks = nullptr;
             r0.build_band = 1;
             r0.step = 0;
+            if (result_dev) {     // the limiter's look-back words are preset by this grid: a thousand workgroups, two words a thread
+                MGX_TRY(limiter_state(h, n_target, cfg, &r0.lim_published, &r0.lim_words, &r0.lim_ticket));
+                limiter_preset = true;
+            }
             if (rounds == 1) MGX_TRY(with_final(r0));
             hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, r0);
         }
@@ -1666,3 +1667,13 @@ int mgx_comm_destroy(mgx_handle* h) {
 
 }  // extern "C"
 
+
+#ifdef MGX_TAIL_TRACE
+// experiments only (tools/tail_trace.py): the 100 MHz phase stamps of the last k_correction_round / k_correction_tail
+extern "C" int mgx_debug_tail_trace(unsigned long long* tail /* [160*32] */, unsigned long long* round /* [8] */) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(tail, HIP_SYMBOL(mgx::g_tail_trace), sizeof(unsigned long long) * 160 * 32));
+    HIP_TRY(hipMemcpyFromSymbol(round, HIP_SYMBOL(mgx::g_round_trace), sizeof(unsigned long long) * 8));
+    return 0;
+}
+#endif

@@ -450,6 +450,23 @@ __device__ __forceinline__ void piece_sums_to_lds(const double* partial, int chu
     }
     __syncthreads();
 }
+// The same sums with L lanes side by side on a piece (L a power of two, as many as the workgroup has for
+// `divisions` pieces, at most 64) and a butterfly over them: a fixed order too, and no wave walks alone
+// through its pieces.
+__device__ __forceinline__ void piece_sums_by_groups(const double* partial, int chunks, int divisions, double* sums) {
+    int l = 64;
+    while (l > 1 && l * divisions > (int)blockDim.x) l >>= 1;
+    const int part = threadIdx.x & (l - 1), per_pass = blockDim.x / l;
+    for (int d0 = 0; d0 < divisions; d0 += per_pass) {
+        const int d = d0 + threadIdx.x / l;
+        double s = 0.0;
+        if (d < divisions)
+            for (int ch = part; ch < chunks; ch += l) s += partial[(size_t)d * chunks + ch];
+        for (int o = l >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (d < divisions && part == 0) sums[d] = s;
+    }
+    __syncthreads();
+}
 // returns (on every thread) average rms, match rms and the loud count; optionally stores rms/loud
 template <int THREADS>
 __device__ __forceinline__ void decide_loud(const double* sums, int divisions, long long piece, double inv_c,
@@ -1175,6 +1192,15 @@ __global__ __launch_bounds__(256) void k_fir_taps_combine(FirPlanView pl, const 
     *reinterpret_cast<float2*>(taps + (size_t)plane * f + i) = t;
 }
 
+#ifdef MGX_TAIL_TRACE      // experiments: 100 MHz timestamps of the phases (tools/tail_trace.py)
+__device__ unsigned long long g_tail_trace[160 * 32];
+__device__ unsigned long long g_round_trace[8];
+#define TAIL_STAMP(slot) do { if (threadIdx.x == 0 && blockIdx.x < 160) g_tail_trace[blockIdx.x * 32 + (slot)] = wall_clock64(); } while (0)
+#define ROUND_STAMP(slot) do { if (threadIdx.x == 0) g_round_trace[slot] = wall_clock64(); } while (0)
+#else
+#define TAIL_STAMP(slot) do {} while (0)
+#define ROUND_STAMP(slot) do {} while (0)
+#endif
 // ---------------------------------------------------------------------------
 // level correction (stages.py:138-170)
 // ---------------------------------------------------------------------------
@@ -1341,11 +1367,14 @@ __device__ __forceinline__ double correction_decide(const RoundArgs& a, int tota
         }
     }
     __syncthreads();
-    piece_sums_to_lds(stage, per, a.divisions, sums);
-    double avg, match;
-    int count;
-    decide_loud<256>(sums, a.divisions, a.piece, 1.0, red, nullptr, nullptr, avg, match, count);
-    const float pk = block_max<256>(m, fscratch);
+    // (the last arriver works alone while the chip waits: lanes side by side on a piece and ONE wave's decision,
+    // 2.5 us where wave-per-piece sums and three block-wide reductions took 5.3 -- profiles/r03_z_correction_phases.txt)
+    piece_sums_by_groups(stage, per, a.divisions, sums);
+    float pk = 0.f;
+    if (a.final_peaks) pk = block_max<256>(m, fscratch);                   // (uniform)
+    double avg = 0.0, match = 1.0;
+    int count = 0;
+    if (threadIdx.x < 64) wave_decide(sums, a.divisions, a.piece, 1.0, nullptr, nullptr, avg, match, count);
     if (threadIdx.x == 0) {
         const double c = *a.reference_match_rms / fmax(a.eps, match);      // match_levels.py:106-111
         CorrectionState* cs = a.cs;
@@ -1368,6 +1397,7 @@ __device__ __forceinline__ double correction_decide(const RoundArgs& a, int tota
 }
 
 __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
+    if (blockIdx.x == 0) ROUND_STAMP(0);
     warm_code(CODE_ROUND);
     MGX_LDS;
     double* red = reinterpret_cast<double*>(mgx_smem);          // 64 doubles of scratch
@@ -1526,7 +1556,9 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
     }
     __syncthreads();
     if (!is_last) return;
+    ROUND_STAMP(1);
     correction_decide(a, a.divisions * a.chunks, a.chunks, red, sums, true, a.step, g);
+    ROUND_STAMP(2);
 }
 
 // Rounds 1 .. K-1 of stages.py:149-168 in ONE launch.  After round 0 a round only touches the band
@@ -1547,6 +1579,7 @@ __host__ __device__ inline size_t correction_tail_lds_bytes(int divisions, int g
 }
 __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups, int rounds) {
     warm_code(CODE_TAIL);
+    TAIL_STAMP(0);
     MGX_LDS;
     double* red = reinterpret_cast<double*>(mgx_smem);          // 64 doubles of scratch
     double* sums = red + 64;                                     // [divisions]
@@ -1563,6 +1596,7 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
             a.lim_published[i] = ~0ull;
         if (blockIdx.x == 0 && threadIdx.x == 0) *a.lim_ticket = 0;      // ticket only: a raised error sticks
     }
+    TAIL_STAMP(1);
     double g = a.cs->gain;
     // ---- once: closed-form parts and band lists of this workgroup's chunks (lane c <-> chunk ch0 + c) ----
     const int nch = ch1 - ch0;                                           // <= 64 (host)
@@ -1585,14 +1619,45 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
     const bool cached = wave_total <= TAIL_CACHE_PER_WAVE;               // uniform per wave
     float* mine = cache + wave * TAIL_CACHE_PER_WAVE;
     if (cached) {
-        for (int c = 0; c < nch; ++c) {
-            const BandChunk bc = band_chunk(a.band, a.piece, a.chunks, d, ch0 + c);
-            const float* list = bc.lists + wave * bc.wave_cap;
-            const int n = __shfl(my_count, c, 64), off = __shfl(before, c, 64);
-            for (int k = lane; k < n; k += 64) mine[off + k] = list[k];
+        // two chunks' lists at a time, six loads per lane and list in flight before the first is stored: a loop
+        // of load -> wait -> store per 64 samples was 48 round trips in a row (profiles/r03_z_correction_phases.txt).
+        // (Four chunks at a time, the first four asked for before the counts are known, and round 0's loads
+        // software-pipelined were all measured slower.)
+        constexpr int PER = 6;
+        for (int c0 = 0; c0 < nch; c0 += 2) {
+            const float* list[2];
+            int n[2], off[2];
+            float v[2][PER];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = c0 + u < nch ? c0 + u : c0;
+                const BandChunk bc = band_chunk(a.band, a.piece, a.chunks, d, ch0 + c);
+                list[u] = bc.lists + wave * bc.wave_cap;
+                n[u] = c0 + u < nch ? __shfl(my_count, c, 64) : 0;
+                off[u] = __shfl(before, c, 64);
+#pragma unroll
+                for (int j = 0; j < PER; ++j) v[u][j] = lane + 64 * j < n[u] ? list[u][lane + 64 * j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int j = 0; j < PER; ++j)
+                    if (lane + 64 * j < n[u]) mine[off[u] + lane + 64 * j] = v[u][j];
+                for (int k = lane + 64 * PER; k < n[u]; k += 64) mine[off[u] + k] = list[u][k];
+            }
         }
     }
+    // this workgroup's share of the convolution's pair peaks, for the decider of the last round
+    float my_peak = 0.f;
+    if (a.final_peaks) {
+        float m = 0.f;
+        for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < a.npeaks; k += (long long)total * 256)
+            m = fmaxf(m, a.final_peaks[k]);
+        my_peak = block_max<256>(m, fscratch);
+    }
+    double* peak_words = a.partial + (size_t)a.divisions * a.chunks;     // [total], behind round 0's partials
     const float* final_peaks = a.final_peaks;
+    TAIL_STAMP(2);
     for (int r = 0; r < rounds; ++r) {
         double acc = 0.0;
         auto add = [&](float v) {
@@ -1601,7 +1666,12 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
         };
         if (g >= BAND_G_LO && g <= BAND_G_HI) {                          // uniform over the grid
             if (cached) {
-                for (int k = lane; k < wave_total; k += 64) add(mine[k]);
+                int k = lane;
+                for (; k + 192 < wave_total; k += 256) {                 // four LDS loads in flight, summed in order
+                    const float v0 = mine[k], v1 = mine[k + 64], v2 = mine[k + 128], v3 = mine[k + 192];
+                    add(v0), add(v1), add(v2), add(v3);
+                }
+                for (; k < wave_total; k += 64) add(mine[k]);
             } else {
                 for (int c = 0; c < nch; ++c) {
                     const BandChunk bc = band_chunk(a.band, a.piece, a.chunks, d, ch0 + c);
@@ -1618,19 +1688,29 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
             }
         }
         const double s = block_sum<256>(acc, red);
+        TAIL_STAMP(3 + 6 * r);
         if (threadIdx.x == 0) {
             __hip_atomic_store(a.partial + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (r == rounds - 1 && final_peaks)
+                __hip_atomic_store(peak_words + blockIdx.x, (double)my_peak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            is_last = atomicAdd(a.arrivals, 1u) == (unsigned)total - 1;
+#ifdef MGX_TAIL_TRACE
+            if (blockIdx.x < 160) g_tail_trace[blockIdx.x * 32 + 4 + 6 * r] = wall_clock64();
+#endif
+            // the counter runs on through the rounds (nobody has to zero it, and wait for that, between them):
+            // the last arriver of round r is the one who finds total * (r + 1) - 1
+            is_last = atomicAdd(a.arrivals, 1u) == (unsigned)(total * (r + 1) - 1);
         }
         __syncthreads();
+        TAIL_STAMP(5 + 6 * r);
         const bool last_round = r == rounds - 1;
         if (is_last) {                                                   // uniform: one workgroup per round
             for (int k = threadIdx.x; k < total; k += 256)
                 stage[k] = __hip_atomic_load(a.partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             float m = 0.f;
             if (last_round && final_peaks)
-                for (long long k = threadIdx.x; k < a.npeaks; k += 256) m = fmaxf(m, final_peaks[k]);
+                for (int k = threadIdx.x; k < total; k += 256)
+                    m = fmaxf(m, (float)__hip_atomic_load(peak_words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
             __syncthreads();
             for (int p = threadIdx.x; p < a.divisions; p += 256) {
                 double t = 0.0;
@@ -1638,6 +1718,7 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
                 sums[p] = t;
             }
             const float pk = block_max<256>(m, fscratch);                 // (barrier inside: sums[] is complete after it)
+            TAIL_STAMP(6 + 6 * r);
             if (wave == 0) {
                 double avg, match;
                 int count;
@@ -1645,15 +1726,23 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
                 if (lane == 0) {
                     const double c = *a.reference_match_rms / fmax(a.eps, match);      // match_levels.py:106-111
                     const double next = g * c;
+                    // the gain word first: a hundred workgroups are polling it
+                    if (!last_round)
+                        __hip_atomic_store(a.tail_gains + r, double_bits(next), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     // Write-through stores, field by field: the rounds of one launch are decided by
                     // workgroups on different XCDs, and two L2s each holding a dirty copy of this line
-                    // would overwrite each other's fields when they write it back.
+                    // would overwrite each other's fields when they write it back.  A round writes its own
+                    // coefficient; the fields every round would write are left to the last one.
                     CorrectionState* cs = a.cs;
                     auto put = [](double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
                     auto puti = [](int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
                     put(&cs->coeffs[a.step + r], c);
-                    puti(&cs->steps_done, a.step + r + 1);
-                    put(&cs->gain, next);
+                    if (last_round) {
+                        puti(&cs->steps_done, a.step + r + 1);
+                        put(&cs->gain, next);
+                        // zero again for the next launch (which the stream orders behind this kernel)
+                        __hip_atomic_store(a.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     if (last_round && final_peaks) {
                         const double peak = (double)(float)((double)pk * next);      // max |float32(y*gain)|
                         const double rect = fmax(peak, a.threshold) / a.threshold;
@@ -1661,13 +1750,9 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
                         puti(&cs->limiter_active, fabs(rect - 1.0) > (1e-8 + 1e-5) ? 1 : 0);   // numpy.isclose defaults, hyrax.py:83
                         put(&cs->normalize_c, fmax(a.eps, peak / a.threshold));               // dsp.py:93-100
                     }
-                    // the counter is back at zero before anybody can arrive again
-                    __hip_atomic_store(a.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (!last_round)
-                        __hip_atomic_store(a.tail_gains + r, double_bits(next), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
+            TAIL_STAMP(7 + 6 * r);
         }
         if (last_round) break;
         if (threadIdx.x == 0) {
@@ -1688,6 +1773,7 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
         __syncthreads();
         g = gain_now;
         __syncthreads();
+        TAIL_STAMP(8 + 6 * r);
     }
 }
 
