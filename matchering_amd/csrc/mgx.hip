@@ -1270,7 +1270,11 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
         // live in their own buffer (a layout that moved with `divisions` would leave one call's preset
         // gain words where the next call counts arrivals)
         const size_t ctr_bytes = (size_t)(1 + ra.divisions) * sizeof(unsigned);
-        MGX_TRY(ensure(h, h->tail_gains, 16 * sizeof(unsigned long long)));
+        // at most ~128 workgroups in k_correction_tail, at most 64 chunks (the lanes of a wave) per workgroup
+        const int tail_groups = std::max((ra.chunks + 63) / 64, std::max(1, std::min(ra.chunks, 128 / ra.divisions)));
+        const int tail_total = cfg->rms_correction_steps > 1 ? ra.divisions * tail_groups : 0;
+        MGX_TRY(ensure(h, h->tail_gains, (16 + (size_t)15 * tail_total) * sizeof(unsigned long long)));
+        ra.tail_total = tail_total;
         if (h->round_ctr.bytes < ctr_bytes) {                 // zeroed when (re)allocated, reset by each launch
             MGX_TRY(ensure(h, h->round_ctr, std::max(ctr_bytes, (size_t)4096)));
             HIP_TRY(hipMemsetAsync(h->round_ctr.p, 0, h->round_ctr.bytes, h->stream));
@@ -1318,8 +1322,7 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
             rt.build_band = 0;
             rt.step = 1;
             MGX_TRY(with_final(rt));
-            // at most ~128 workgroups, at most 64 chunks (the lanes of a wave) per workgroup
-            const int groups = std::max((ra.chunks + 63) / 64, std::max(1, std::min(ra.chunks, 128 / ra.divisions)));
+            const int groups = tail_groups;
             const size_t lds_tail = correction_tail_lds_bytes(ra.divisions, groups);
             if (lds_tail > (size_t)150 * 1024)
                 return fail(MGX_ERR_UNSUPPORTED, "too many analysis pieces for the level-correction kernel's LDS");

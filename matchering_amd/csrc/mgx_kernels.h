@@ -1333,7 +1333,9 @@ struct RoundArgs {
     unsigned long long* lim_published;
     long long lim_words;
     int* lim_ticket;
-    unsigned long long* tail_gains;   // [16] gains published between the rounds of k_correction_tail, or null
+    unsigned long long* tail_gains;   // [16] gains published between the rounds of k_correction_tail, or null; behind
+                                      // them [15][tail_total] words for its workgroups' partial sums (the value is the flag)
+    int tail_total;                   // workgroups of the k_correction_tail launch that follows (0: none)
     int* error;                       // set when a bounded wait expired
 };
 // The decision of one round (stages.py:149-168), taken by ONE 256-thread workgroup after every partial
@@ -1408,7 +1410,8 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
     const long long b = bc.b, e = bc.e;
     const double g = a.cs->gain;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (a.tail_gains && blockIdx.x == 0 && threadIdx.x < 16) a.tail_gains[threadIdx.x] = ~0ull;   // "not yet": k_correction_tail
+    if (a.tail_gains && blockIdx.x == 0)                                                         // "not yet": k_correction_tail
+        for (int i = threadIdx.x; i < 16 + 15 * a.tail_total; i += 256) a.tail_gains[i] = ~0ull;
     if (a.lim_published) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.lim_words; i += (long long)gridDim.x * 256)
             a.lim_published[i] = ~0ull;
@@ -1585,7 +1588,6 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
     double* sums = red + 64;                                     // [divisions]
     double* stage = sums + a.divisions;                          // [divisions * groups]
     float* cache = reinterpret_cast<float*>(stage + a.divisions * groups);
-    __shared__ int is_last;
     __shared__ double gain_now;
     __shared__ float fscratch[4];
     const int d = blockIdx.x / groups, grp = blockIdx.x % groups;
@@ -1689,24 +1691,36 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
         }
         const double s = block_sum<256>(acc, red);
         TAIL_STAMP(3 + 6 * r);
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(a.partial + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (r == rounds - 1 && final_peaks)
-                __hip_atomic_store(peak_words + blockIdx.x, (double)my_peak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef MGX_TAIL_TRACE
-            if (blockIdx.x < 160) g_tail_trace[blockIdx.x * 32 + 4 + 6 * r] = wall_clock64();
-#endif
-            // the counter runs on through the rounds (nobody has to zero it, and wait for that, between them):
-            // the last arriver of round r is the one who finds total * (r + 1) - 1
-            is_last = atomicAdd(a.arrivals, 1u) == (unsigned)(total * (r + 1) - 1);
-        }
-        __syncthreads();
-        TAIL_STAMP(5 + 6 * r);
+        // The partial sum is published as an 8-byte word whose value is the flag (a sum of squares is never the
+        // all-ones pattern round 0 left there); workgroup 0 decides every round and polls the words, one lane
+        // per word.  An arrival counter cost each round the publisher's wait for its store, the atomic's round
+        // trip (a hundred of them on one word take a microsecond) and the last arriver's read of the partials.
+        unsigned long long* words = a.tail_gains + 16 + (size_t)r * total;
         const bool last_round = r == rounds - 1;
-        if (is_last) {                                                   // uniform: one workgroup per round
-            for (int k = threadIdx.x; k < total; k += 256)
-                stage[k] = __hip_atomic_load(a.partial + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            if (last_round && final_peaks) {                             // the peak word first, and landed
+                __hip_atomic_store(peak_words + blockIdx.x, (double)my_peak, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __hip_atomic_store(words + blockIdx.x, double_bits(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        TAIL_STAMP(5 + 6 * r);
+        if (blockIdx.x == 0) {                                           // uniform: the deciding workgroup
+            for (int k = threadIdx.x; k < total; k += 256) {
+                unsigned long long v = __hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                while (v == ~0ull && spins < (1 << 20)) {
+                    if (spins < 64) __builtin_amdgcn_s_sleep(1);
+                    else __builtin_amdgcn_s_sleep(16);
+                    v = __hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ++spins;
+                }
+                if (v == ~0ull) {
+                    *a.error = 1;
+                    v = 0ull;
+                }
+                stage[k] = bits_double(v);
+            }
             float m = 0.f;
             if (last_round && final_peaks)
                 for (int k = threadIdx.x; k < total; k += 256)
@@ -1740,8 +1754,6 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
                     if (last_round) {
                         puti(&cs->steps_done, a.step + r + 1);
                         put(&cs->gain, next);
-                        // zero again for the next launch (which the stream orders behind this kernel)
-                        __hip_atomic_store(a.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     if (last_round && final_peaks) {
                         const double peak = (double)(float)((double)pk * next);      // max |float32(y*gain)|
