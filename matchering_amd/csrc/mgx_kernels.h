@@ -1568,14 +1568,16 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
 // lists (a few MB) and a handful of scalars, so a launch per round was mostly launch, ramp and a chain
 // of cold round trips: 16 us each for ~1 us of work.  Here a small grid (divisions x groups workgroups,
 // at most ~128: every one of them must be resident at once, also next to other handles' kernels) keeps
-// running.  Before the first round a workgroup adds up the closed-form parts of its chunks and copies
-// their band lists into LDS (when they fit); a round is then: sum from LDS -> publish the partial ->
-// one arrival counter -> the last arriver reads the partials (L2-bypassing loads, no fence), decides
-// with one wave and publishes the new gain as an 8-byte word whose value is the flag (preset to
-// all-ones by round 0) -> everybody polls it (one lane, bounded) and goes on.  A gain outside
-// [BAND_G_LO, BAND_G_HI] makes a workgroup stream its part of the mid plane instead (slow with so few
-// workgroups, and never seen: coefficients are ratios of two loudness estimates of nearly the same
-// signal).
+// running.  Before the first round a workgroup adds up the closed-form parts of its chunks, copies
+// their band lists into LDS (when they fit) and reduces its share of the convolution's pair peaks; a
+// round is then: sum from LDS -> publish the partial as an 8-byte word whose value is the flag (preset
+// to all-ones by round 0) -> workgroup 0 polls the words, one lane per word, decides with one wave and
+// publishes the new gain the same way -> everybody polls it (one lane, bounded) and goes on.  Every wait
+// is bounded and raises the handle's error word.  A gain outside [BAND_G_LO, BAND_G_HI] makes a
+// workgroup stream its part of the mid plane instead (slow with so few workgroups, and never seen:
+// coefficients are ratios of two loudness estimates of nearly the same signal).
+// Phase stamps of this kernel and of round 0's last workgroup: profiles/r03_z_correction_phases.txt
+// (-DMGX_TAIL_TRACE, tools/tail_trace.py).
 constexpr int TAIL_CACHE_PER_WAVE = 3072;        // floats of band list a wave keeps in LDS
 __host__ __device__ inline size_t correction_tail_lds_bytes(int divisions, int groups) {
     return ((size_t)64 + divisions + (size_t)divisions * groups) * 8 + (size_t)4 * TAIL_CACHE_PER_WAVE * 4 + 16;
