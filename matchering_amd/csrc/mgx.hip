@@ -1323,11 +1323,12 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
             rt.step = 1;
             MGX_TRY(with_final(rt));
             const int groups = tail_groups;
-            const size_t lds_tail = correction_tail_lds_bytes(ra.divisions, groups);
+            const size_t lds_tail = correction_tail_lds_bytes(ra.divisions, groups, ra.chunks);
             if (lds_tail > (size_t)150 * 1024)
                 return fail(MGX_ERR_UNSUPPORTED, "too many analysis pieces for the level-correction kernel's LDS");
             MGX_TRY(allow_lds(k_correction_tail, lds_tail));
-            hipLaunchKernelGGL(k_correction_tail, dim3(ra.divisions * groups), dim3(256), lds_tail, h->stream, rt, groups,
+            // (+ 1: the deciding workgroup)
+            hipLaunchKernelGGL(k_correction_tail, dim3(ra.divisions * groups + 1), dim3(256), lds_tail, h->stream, rt, groups,
                                rounds - 1);
         }
         if (rounds == 0)

@@ -1335,7 +1335,8 @@ struct RoundArgs {
     int* lim_ticket;
     unsigned long long* tail_gains;   // [16] gains published between the rounds of k_correction_tail, or null; behind
                                       // them [15][tail_total] words for its workgroups' partial sums (the value is the flag)
-    int tail_total;                   // workgroups of the k_correction_tail launch that follows (0: none)
+    int tail_total;                   // summing workgroups of the k_correction_tail launch that follows (0: none);
+                                      // with one, this launch leaves its partials and the decision to that kernel
     int* error;                       // set when a bounded wait expired
 };
 // The decision of one round (stages.py:149-168), taken by ONE 256-thread workgroup after every partial
@@ -1543,6 +1544,10 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
         }
     }
     const double s = block_sum<256>(acc, red);
+    if (a.build_band && a.tail_total > 0) {                              // uniform: k_correction_tail decides round 0
+        if (threadIdx.x == 0) a.partial[blockIdx.x] = s;
+        return;
+    }
     if (threadIdx.x == 0) {
         // write-through 8-byte store + drained vmcnt instead of a release fence (a fence per workgroup
         // would write back the XCD's whole L2 two thousand times)
@@ -1578,9 +1583,112 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
 // coefficients are ratios of two loudness estimates of nearly the same signal).
 // Phase stamps of this kernel and of round 0's last workgroup: profiles/r03_z_correction_phases.txt
 // (-DMGX_TAIL_TRACE, tools/tail_trace.py).
+// one lane's bounded wait for an 8-byte flag word to leave the all-ones pattern (0 and the error word on expiry)
+__device__ __forceinline__ unsigned long long poll_word(const unsigned long long* w, int* error, unsigned long long on_expiry) {
+    unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spins = 0;
+    while (v == ~0ull && spins < (1 << 20)) {
+        if (spins < 64) __builtin_amdgcn_s_sleep(1);
+        else __builtin_amdgcn_s_sleep(16);
+        v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ++spins;
+    }
+    if (v == ~0ull) {
+        *error = 1;
+        v = on_expiry;
+    }
+    return v;
+}
+constexpr int TAIL_GAIN0 = 15;                   // tail_gains slot of the gain after round 0
+// The deciding workgroup of k_correction_tail (the one past the summing ones).  First round 0's decision from the
+// partials k_correction_round left (the launch boundary made them visible; that kernel skips its own arrival
+// count and decision when a tail follows -- they were 4 us with the whole chip waiting, here they run beside the
+// other workgroups' list copies), then every round: poll the summing workgroups' words, decide, publish.
+__device__ __forceinline__ void tail_decider(const RoundArgs& a, int groups, int rounds, int total, double* red, double* sums,
+                                             double* stage, double* stage0, float* fscratch) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double decided;
+    double* peak_words = a.partial + (size_t)a.divisions * a.chunks;
+    const float* final_peaks = a.final_peaks;
+    auto put = [](double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto puti = [](int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    {
+        const int n0 = a.divisions * a.chunks;
+        for (int k0 = threadIdx.x; k0 < n0; k0 += 8 * 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = k0 + 256 * u < n0 ? a.partial[k0 + 256 * u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (k0 + 256 * u < n0) stage0[k0 + 256 * u] = v[u];
+        }
+        const double gain_in = a.cs->gain;
+        __syncthreads();
+        piece_sums_by_groups(stage0, a.chunks, a.divisions, sums);
+        if (wave == 0) {
+            double avg, match;
+            int count;
+            wave_decide(sums, a.divisions, a.piece, 1.0, nullptr, nullptr, avg, match, count);
+            if (lane == 0) {
+                const double c = *a.reference_match_rms / fmax(a.eps, match);          // match_levels.py:106-111
+                const double next = gain_in * c;
+                __hip_atomic_store(a.tail_gains + TAIL_GAIN0, double_bits(next), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                put(&a.cs->coeffs[a.step - 1], c);
+                decided = next;
+            }
+        }
+        __syncthreads();
+    }
+    double g = decided;
+    for (int r = 0; r < rounds; ++r) {
+        const unsigned long long* words = a.tail_gains + 16 + (size_t)r * total;
+        const bool last_round = r == rounds - 1;
+        for (int k = threadIdx.x; k < total; k += 256) stage[k] = bits_double(poll_word(words + k, a.error, 0ull));
+        float m = 0.f;
+        if (last_round && final_peaks)
+            for (int k = threadIdx.x; k < total; k += 256)
+                m = fmaxf(m, (float)__hip_atomic_load(peak_words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        for (int p = threadIdx.x; p < a.divisions; p += 256) {
+            double t = 0.0;
+            for (int q = 0; q < groups; ++q) t += stage[p * groups + q];
+            sums[p] = t;
+        }
+        const float pk = block_max<256>(m, fscratch);                     // (barrier inside: sums[] is complete after it)
+        if (wave == 0) {
+            double avg, match;
+            int count;
+            wave_decide(sums, a.divisions, a.piece, 1.0, nullptr, nullptr, avg, match, count);
+            if (lane == 0) {
+                const double c = *a.reference_match_rms / fmax(a.eps, match);          // match_levels.py:106-111
+                const double next = g * c;
+                // the gain word first: a hundred workgroups are polling it
+                if (!last_round)
+                    __hip_atomic_store(a.tail_gains + r, double_bits(next), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                CorrectionState* cs = a.cs;
+                put(&cs->coeffs[a.step + r], c);
+                if (last_round) {
+                    puti(&cs->steps_done, a.step + r + 1);
+                    put(&cs->gain, next);
+                    if (final_peaks) {
+                        const double peak = (double)(float)((double)pk * next);      // max |float32(y*gain)|
+                        const double rect = fmax(peak, a.threshold) / a.threshold;
+                        put(&cs->result_peak, peak);
+                        puti(&cs->limiter_active, fabs(rect - 1.0) > (1e-8 + 1e-5) ? 1 : 0);   // numpy.isclose defaults, hyrax.py:83
+                        put(&cs->normalize_c, fmax(a.eps, peak / a.threshold));               // dsp.py:93-100
+                    }
+                }
+                decided = next;
+            }
+        }
+        __syncthreads();
+        g = decided;
+    }
+}
 constexpr int TAIL_CACHE_PER_WAVE = 3072;        // floats of band list a wave keeps in LDS
-__host__ __device__ inline size_t correction_tail_lds_bytes(int divisions, int groups) {
-    return ((size_t)64 + divisions + (size_t)divisions * groups) * 8 + (size_t)4 * TAIL_CACHE_PER_WAVE * 4 + 16;
+__host__ __device__ inline size_t correction_tail_lds_bytes(int divisions, int groups, int chunks) {
+    const size_t cache = (size_t)4 * TAIL_CACHE_PER_WAVE * 4, stage0 = (size_t)divisions * chunks * 8;   // (the decider's)
+    return ((size_t)64 + divisions + (size_t)divisions * groups) * 8 + (cache > stage0 ? cache : stage0) + 16;
 }
 __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups, int rounds) {
     warm_code(CODE_TAIL);
@@ -1601,7 +1709,10 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
         if (blockIdx.x == 0 && threadIdx.x == 0) *a.lim_ticket = 0;      // ticket only: a raised error sticks
     }
     TAIL_STAMP(1);
-    double g = a.cs->gain;
+    if ((int)blockIdx.x == total) {                                      // uniform: the extra workgroup decides
+        tail_decider(a, groups, rounds, total, red, sums, stage, reinterpret_cast<double*>(cache), fscratch);
+        return;
+    }
     // ---- once: closed-form parts and band lists of this workgroup's chunks (lane c <-> chunk ch0 + c) ----
     const int nch = ch1 - ch0;                                           // <= 64 (host)
     int my_count = 0;
@@ -1662,6 +1773,9 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
     double* peak_words = a.partial + (size_t)a.divisions * a.chunks;     // [total], behind round 0's partials
     const float* final_peaks = a.final_peaks;
     TAIL_STAMP(2);
+    if (threadIdx.x == 0) gain_now = bits_double(poll_word(a.tail_gains + TAIL_GAIN0, a.error, double_bits(1.0)));
+    __syncthreads();
+    double g = gain_now;                                                 // round 0's, from the deciding workgroup
     for (int r = 0; r < rounds; ++r) {
         double acc = 0.0;
         auto add = [&](float v) {
@@ -1694,9 +1808,9 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
         const double s = block_sum<256>(acc, red);
         TAIL_STAMP(3 + 6 * r);
         // The partial sum is published as an 8-byte word whose value is the flag (a sum of squares is never the
-        // all-ones pattern round 0 left there); workgroup 0 decides every round and polls the words, one lane
-        // per word.  An arrival counter cost each round the publisher's wait for its store, the atomic's round
-        // trip (a hundred of them on one word take a microsecond) and the last arriver's read of the partials.
+        // all-ones pattern round 0 left there); the deciding workgroup polls the words, one lane per word.  An
+        // arrival counter cost each round the publisher's wait for its store, the atomic's round trip (a hundred
+        // of them on one word take a microsecond) and the last arriver's read of the partials.
         unsigned long long* words = a.tail_gains + 16 + (size_t)r * total;
         const bool last_round = r == rounds - 1;
         if (threadIdx.x == 0) {
@@ -1707,83 +1821,8 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
             __hip_atomic_store(words + blockIdx.x, double_bits(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         TAIL_STAMP(5 + 6 * r);
-        if (blockIdx.x == 0) {                                           // uniform: the deciding workgroup
-            for (int k = threadIdx.x; k < total; k += 256) {
-                unsigned long long v = __hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                int spins = 0;
-                while (v == ~0ull && spins < (1 << 20)) {
-                    if (spins < 64) __builtin_amdgcn_s_sleep(1);
-                    else __builtin_amdgcn_s_sleep(16);
-                    v = __hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ++spins;
-                }
-                if (v == ~0ull) {
-                    *a.error = 1;
-                    v = 0ull;
-                }
-                stage[k] = bits_double(v);
-            }
-            float m = 0.f;
-            if (last_round && final_peaks)
-                for (int k = threadIdx.x; k < total; k += 256)
-                    m = fmaxf(m, (float)__hip_atomic_load(peak_words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            __syncthreads();
-            for (int p = threadIdx.x; p < a.divisions; p += 256) {
-                double t = 0.0;
-                for (int q = 0; q < groups; ++q) t += stage[p * groups + q];
-                sums[p] = t;
-            }
-            const float pk = block_max<256>(m, fscratch);                 // (barrier inside: sums[] is complete after it)
-            TAIL_STAMP(6 + 6 * r);
-            if (wave == 0) {
-                double avg, match;
-                int count;
-                wave_decide(sums, a.divisions, a.piece, 1.0, nullptr, nullptr, avg, match, count);
-                if (lane == 0) {
-                    const double c = *a.reference_match_rms / fmax(a.eps, match);      // match_levels.py:106-111
-                    const double next = g * c;
-                    // the gain word first: a hundred workgroups are polling it
-                    if (!last_round)
-                        __hip_atomic_store(a.tail_gains + r, double_bits(next), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // Write-through stores, field by field: the rounds of one launch are decided by
-                    // workgroups on different XCDs, and two L2s each holding a dirty copy of this line
-                    // would overwrite each other's fields when they write it back.  A round writes its own
-                    // coefficient; the fields every round would write are left to the last one.
-                    CorrectionState* cs = a.cs;
-                    auto put = [](double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-                    auto puti = [](int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-                    put(&cs->coeffs[a.step + r], c);
-                    if (last_round) {
-                        puti(&cs->steps_done, a.step + r + 1);
-                        put(&cs->gain, next);
-                    }
-                    if (last_round && final_peaks) {
-                        const double peak = (double)(float)((double)pk * next);      // max |float32(y*gain)|
-                        const double rect = fmax(peak, a.threshold) / a.threshold;
-                        put(&cs->result_peak, peak);
-                        puti(&cs->limiter_active, fabs(rect - 1.0) > (1e-8 + 1e-5) ? 1 : 0);   // numpy.isclose defaults, hyrax.py:83
-                        put(&cs->normalize_c, fmax(a.eps, peak / a.threshold));               // dsp.py:93-100
-                    }
-                }
-            }
-            TAIL_STAMP(7 + 6 * r);
-        }
         if (last_round) break;
-        if (threadIdx.x == 0) {
-            unsigned long long v = __hip_atomic_load(a.tail_gains + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int spins = 0;
-            while (v == ~0ull && spins < (1 << 20)) {
-                if (spins < 64) __builtin_amdgcn_s_sleep(2);
-                else __builtin_amdgcn_s_sleep(16);
-                v = __hip_atomic_load(a.tail_gains + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ++spins;
-            }
-            if (v == ~0ull) {
-                *a.error = 1;
-                v = double_bits(1.0);
-            }
-            gain_now = bits_double(v);
-        }
+        if (threadIdx.x == 0) gain_now = bits_double(poll_word(a.tail_gains + r, a.error, double_bits(1.0)));
         __syncthreads();
         g = gain_now;
         __syncthreads();
