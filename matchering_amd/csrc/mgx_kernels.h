@@ -1576,8 +1576,9 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
 // running.  Before the first round a workgroup adds up the closed-form parts of its chunks, copies
 // their band lists into LDS (when they fit) and reduces its share of the convolution's pair peaks; a
 // round is then: sum from LDS -> publish the partial as an 8-byte word whose value is the flag (preset
-// to all-ones by round 0) -> workgroup 0 polls the words, one lane per word, decides with one wave and
-// publishes the new gain the same way -> everybody polls it (one lane, bounded) and goes on.  Every wait
+// to all-ones by round 0) -> the deciding workgroup (one past the summing ones: tail_decider, which also
+// takes round 0's decision while the others copy their lists) polls the words, one lane per word, decides
+// with one wave and publishes the new gain the same way -> everybody polls it (one lane, bounded) and goes on.  Every wait
 // is bounded and raises the handle's error word.  A gain outside [BAND_G_LO, BAND_G_HI] makes a
 // workgroup stream its part of the mid plane instead (slow with so few workgroups, and never seen:
 // coefficients are ratios of two loudness estimates of nearly the same signal).
