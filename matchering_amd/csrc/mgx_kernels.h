@@ -1737,8 +1737,9 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
     if (cached) {
         // two chunks' lists at a time, six loads per lane and list in flight before the first is stored: a loop
         // of load -> wait -> store per 64 samples was 48 round trips in a row (profiles/r03_z_correction_phases.txt).
-        // (Four chunks at a time, the first four asked for before the counts are known, and round 0's loads
-        // software-pipelined were all measured slower.)
+        // (Four chunks at a time, the first four asked for before the counts are known, eight chunks at a time
+        // with 16-byte loads, and round 0's loads software-pipelined were all measured slower: more loads in
+        // flight on these cold, scattered lists cost more than they hide.)
         constexpr int PER = 6;
         for (int c0 = 0; c0 < nch; c0 += 2) {
             const float* list[2];
