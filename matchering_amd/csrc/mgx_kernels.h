@@ -1645,6 +1645,8 @@ __device__ __forceinline__ void tail_decider(const RoundArgs& a, int groups, int
         const unsigned long long* words = a.tail_gains + 16 + (size_t)r * total;
         const bool last_round = r == rounds - 1;
         for (int k = threadIdx.x; k < total; k += 256) stage[k] = bits_double(poll_word(words + k, a.error, 0ull));
+        asm volatile("" ::: "memory");        // the peak words are read AFTER their flag words were seen (compiler order;
+                                              // the publisher waited for its peak store before it stored the flag)
         float m = 0.f;
         if (last_round && final_peaks)
             for (int k = threadIdx.x; k < total; k += 256)
