@@ -4,6 +4,10 @@
     python bench.py --gpus N --steps K --warmup W [--workload NAME]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: started by a launcher (RANK / WORLD_SIZE / LOCAL_RANK in the environment) every
+process is one rank; started plainly with ``--gpus N`` the script starts its N rank processes itself (ranks
+wrap onto the visible GPUs when there are fewer than N) and rank 0 prints the line.
+
 One "step" = one pass of the whole hot path (``mgx_master`` = matchering ``stages.main``: level
 analysis of target and reference, FIR design, overlap-save convolution, 4-round level correction,
 Hyrax limiter) over synthetic stereo pairs that are already resident in HBM.
@@ -19,8 +23,8 @@ With N ranks every rank masters its own pairs (pairs are independent: no data-pa
 scaling); the FIR tables are all-gathered over RCCL after the timed region, the only traffic that
 crosses xGMI.
 
-torch is used for rendezvous/barrier/max-reduce only (gloo, CPU tensors); device memory, streams and
-timing go through libmgx.  Prints ONE JSON line on rank 0.
+Rendezvous, barrier and max-reduce go through matchering_amd.ranks (a local socket: no torch anywhere in this
+file); device memory, streams and timing go through libmgx.  Prints ONE JSON line on rank 0.
 """
 
 import argparse
@@ -28,6 +32,7 @@ import ctypes
 import json
 import os
 import statistics
+import subprocess
 import sys
 import time
 
@@ -59,54 +64,56 @@ def parse():
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 counter passes that measure the dominant kernels' HBM traffic")
     ap.add_argument("--no-gpu-state", action="store_true", help="skip the clock / power / partition probe")
+    ap.add_argument("--stand-in", action="store_true",
+                    help="no GPU: a step is 1 ms of sleep (the multi-rank plumbing of this script, for the CPU tests)")
     ap.add_argument("--spinup", type=float, default=0.5,
                     help="seconds of untimed steps before the warm-up (the device climbs out of its idle clocks)")
     return ap.parse_args()
 
 
-class Ranks:
-    """Rendezvous + barrier + max-reduce over the ranks torch.distributed.run started."""
+from matchering_amd.ranks import Ranks  # noqa: E402  (rendezvous + barrier + max + broadcast over a local socket)
 
-    def __init__(self):
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.local = int(os.environ.get("LOCAL_RANK", "0"))
-        self.dist = None
-        if self.world > 1:
-            import torch.distributed as dist
 
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
-            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            self.dist = dist
+def _free_port():
+    import socket
 
-    def barrier(self):
-        if self.dist:
-            self.dist.barrier()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    def max(self, value):
-        if not self.dist:
-            return value
-        import torch
 
-        t = torch.tensor([value], dtype=torch.float64)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def broadcast_bytes(self, payload, size):
-        if not self.dist:
-            return payload
-        import torch
-
-        t = torch.zeros(size, dtype=torch.uint8)
-        if self.rank == 0:
-            t[:] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
-        self.dist.broadcast(t, src=0)
-        return bytes(t.numpy().tobytes())
-
-    def finish(self):
-        if self.dist:
-            self.dist.destroy_process_group()
+def launch_ranks(world, argv=None):
+    """``python bench.py --gpus N`` without a launcher: start the N rank processes (this same script with RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT set, as ``torch.distributed.run`` would), let rank 0's
+    standard output through -- it prints the line -- and return the first non-zero exit code, 0 if none.  Rank r
+    uses GPU r modulo the number of visible GPUs (no HIP_VISIBLE_DEVICES games: RCCL wants to see the peers)."""
+    argv = list(sys.argv[1:] if argv is None else argv)
+    port = _free_port()                       # only a name for the rendezvous socket (matchering_amd.ranks)
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MGX_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    code = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0 and code == 0:
+                    code = rc
+                    for q in pending:           # a rank that died takes the job with it: the others would wait for it
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return code
 
 
 def spin_up(sync, step, seconds):
@@ -124,7 +131,10 @@ def spin_up(sync, step, seconds):
     return done
 
 
-def timed_steps(ranks, sync, step, steps, warmup):
+def timed_steps(ranks, sync, step, steps, warmup, own=None):
+    """W untimed steps, then K steps between two barriers (each behind a stream synchronisation); returns the
+    maximum over ranks.  ``own`` (a list) receives this rank's time up to its own synchronisation, before the
+    closing barrier: the spread over ranks tells a straggler from a uniformly slow job."""
     for _ in range(warmup):
         step()
     sync()
@@ -133,7 +143,10 @@ def timed_steps(ranks, sync, step, steps, warmup):
     for _ in range(steps):
         step()
     sync()
+    mine = time.perf_counter() - t0
     ranks.barrier()
+    if own is not None:
+        own.append(mine)
     return ranks.max(time.perf_counter() - t0)
 
 
@@ -273,34 +286,81 @@ def roofline_of(kernel, ms, frames, traffic):
                       "profiled steps (cold inputs: the whole pipeline runs between two launches)"}
 
 
+class StandIn:
+    """A workload without a GPU: ``--stand-in`` (tests/test_bench_launch.py drives the N > 1 path of this script --
+    self-launch, rendezvous, barriers, max over ranks, the line -- on a machine that has none).  A step sleeps."""
+
+    name, frames, pairs, lane_choice = "stand_in", 44100, 1, None
+
+    def step(self):
+        time.sleep(0.001)
+
+    def sync(self):
+        pass
+
+    def describe(self):
+        return "stand-in: no GPU, one step = 1 ms of sleep (plumbing test of the multi-rank path)"
+
+
+def share_one_gpu_over_rccl(rank):
+    """More ranks than GPUs (a 1-GPU box running ``--gpus 2``): RCCL refuses two ranks of one host on one device
+    ("Duplicate GPU detected").  Giving every rank its own NCCL_HOSTID makes them look like one-GPU hosts that
+    talk over the loop-back socket transport -- enough to prove the exchange end to end where no second GPU
+    exists; never set when every rank has its own GPU."""
+    os.environ["NCCL_HOSTID"] = f"mgx-bench-rank-{rank}"
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    os.environ.setdefault("NCCL_SHM_DISABLE", "1")
+    os.environ.setdefault("NCCL_P2P_DISABLE", "1")
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))                  # this process only starts the ranks and waits
     ranks = Ranks()
-    if args.gpus != ranks.world and ranks.world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    import matchering_amd as mg
-    from matchering_amd._native import check, library
-    from matchering_amd.device import Device, device_count
-    from matchering_amd.synth import make_pair
+    if args.gpus != ranks.world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {ranks.world} ranks")
+    try:
+        run(args, ranks)
+    finally:
+        ranks.finish()
 
-    lib = library()
-    name = args.workload
-    if name == "auto":
-        name = "8min_full" if ranks.world == 1 else "4min_x8_full"
-    wl = Workload(name, ranks.rank, ranks.local, mg, Device, device_count, make_pair)
+
+def run(args, ranks):
+    line = {
+        "metric": "stereo Msamples/s mastered (44.1 kHz pairs); % HBM roofline @1/2/4/8 GPU",
+        "unit": "Msamples/s", "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "launch": "self" if os.environ.get("MGX_BENCH_SELF_LAUNCHED") else ("launcher" if ranks.world > 1 else "single"),
+    }
+    if args.stand_in:
+        wl, lib, name, sharing = StandIn(), None, "stand_in", False
+    else:
+        import matchering_amd as mg
+        from matchering_amd._native import check, library
+        from matchering_amd.device import Device, device_count
+        from matchering_amd.synth import make_pair
+
+        sharing = ranks.world > max(1, device_count())
+        if sharing:
+            share_one_gpu_over_rccl(ranks.rank)
+        lib = library()
+        name = args.workload
+        if name == "auto":
+            name = "8min_full" if ranks.world == 1 else "4min_x8_full"
+        wl = Workload(name, ranks.rank, ranks.local, mg, Device, device_count, make_pair)
     spun = spin_up(wl.sync, wl.step, args.spinup)
-    elapsed = timed_steps(ranks, wl.sync, wl.step, args.steps, args.warmup)
+    own_seconds = []
+    elapsed = timed_steps(ranks, wl.sync, wl.step, args.steps, args.warmup, own_seconds)
     frames_total = wl.frames * args.steps * ranks.world
     value = frames_total / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
-    model = PIPELINE_BYTES[name]
-    pipeline_gbs = model * wl.frames / (elapsed / args.steps) / 1e9
+    model = PIPELINE_BYTES.get(name, 0)
+    pipeline_gbs = model * wl.frames * ranks.world / (elapsed / args.steps) / 1e9
 
-    line = {
-        "metric": "stereo Msamples/s mastered (44.1 kHz pairs); % HBM roofline @1/2/4/8 GPU",
-        "value": round(value, 2), "unit": "Msamples/s", "n_gpus": ranks.world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+    line.update({
+        "value": round(value, 2), "ms_per_step": round(ms_per_step, 4),
         "spinup": {"seconds": args.spinup, "steps": spun,
                    "note": "untimed steps before the W warm-up steps, so that the K timed steps see a busy device rather "
                            "than the climb out of idle; no measurable effect on the boxes seen so far"},
@@ -308,9 +368,13 @@ def main():
                    "pairs_per_gpu_per_step": wl.pairs, "parallelism": f"pairs x{ranks.world * wl.pairs}",
                    **({"lane_choice": wl.lane_choice} if wl.lane_choice else {})},
         "pipeline_hbm_model": {"bytes_per_frame": model, "achieved_GBs": round(pipeline_gbs, 1),
-                               "frac_of_8TBs": round(pipeline_gbs / HBM_PEAK_GBS, 4),
-                               "frac_of_6p29TBs": round(pipeline_gbs / HBM_COPY_GBS, 4)},
-    }
+                               "peak_GBs": HBM_PEAK_GBS * ranks.world,
+                               "frac_of_8TBs": round(pipeline_gbs / (HBM_PEAK_GBS * ranks.world), 4),
+                               "frac_of_6p29TBs": round(pipeline_gbs / (HBM_COPY_GBS * ranks.world), 4),
+                               "note": "whole job: bytes of all ranks against N x the one-GPU figures"},
+    })
+    # every rank's own time for the K steps (up to its own stream synchronisation, before the closing barrier)
+    line["rank_seconds"] = [round(v, 6) for v in ranks.gather(own_seconds[0])]
 
     # ---- multi-GPU: all-gather the FIR tables over RCCL (off the timed path) ---------------
     # A failing collective is reported in the line, it does not lose the measurement -- and neither does one
@@ -325,6 +389,8 @@ def main():
                 check(lib.mgx_comm_unique_id(id_buf))
             uid = ranks.broadcast_bytes(id_buf.raw, 128)
             check(lib.mgx_comm_init(dev.handle, ctypes.c_char_p(uid), ranks.rank, ranks.world))
+            seen = ctypes.c_int32()
+            check(lib.mgx_comm_count(dev.handle, ctypes.byref(seen)))
             taps_dev, taps = ctypes.c_void_p(), ctypes.c_int32()
             check(lib.mgx_last_fir(dev.handle, ctypes.byref(taps_dev), ctypes.byref(taps)))
             count = 2 * taps.value
@@ -334,18 +400,41 @@ def main():
             firs = dev.download(table, (ranks.world, 2, taps.value))
             own = dev.download(int(taps_dev.value), (2, taps.value))
             ok = bool(np.array_equal(firs[ranks.rank], own)) and bool(np.all(np.isfinite(firs)))
-            exchange["result"] = {"bytes_per_rank": count * 4, "ok": ok}
+            # every rank mastered its own pairs, so the gathered tables must differ from rank to rank
+            distinct = len({firs[r].tobytes() for r in range(ranks.world)})
+            exchange["result"] = {"bytes_per_rank": count * 4, "ok": ok, "ranks_seen": int(seen.value),
+                                  "distinct_tables": distinct,
+                                  "transport": ("loop-back sockets (ranks share a GPU: NCCL_HOSTID made distinct per rank)"
+                                                if sharing else "RCCL default (xGMI peer-to-peer between the node's GPUs)")}
             check(lib.mgx_comm_destroy(dev.handle))
         except Exception as exc:       # noqa: BLE001
             exchange["result"] = {"ok": False, "error": str(exc)[:200]}
 
-    if ranks.rank == 0:
+    stuck = False
+    if ranks.world > 1 and not args.stand_in:
+        import threading
+
+        worker = threading.Thread(target=exchange_fir_tables, daemon=True)
+        worker.start()
+        worker.join(120.0)
+        stuck = worker.is_alive()
+        mine = ({"ok": False, "error": "no answer within 120 s"} if stuck
+                else exchange.get("result", {"ok": False, "error": "no result"}))
+        if not stuck:
+            everyone = ranks.gather(mine)                      # the line carries rank 0's view and how many ranks agree
+            mine = dict(everyone[0], ranks_ok=sum(1 for e in everyone if e.get("ok")))
+        line["rccl_fir_allgather"] = mine
+    elif ranks.world > 1:
+        line["rendezvous"] = {"ranks_seen": len(ranks.gather(ranks.rank)), "transport": "matchering_amd.ranks"}
+
+    if ranks.rank == 0 and not args.stand_in:
         # ---- rooflines of the two streaming kernels, timed where they run: inside the pipeline ----
+        # (at N > 1 the other ranks are idle by now: these legs describe one GPU, as at N = 1)
         stage_ms, n0 = wl.stage_profile(max(5, min(args.steps, 20)))
         line["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
         # HBM traffic by the PMC counters, measured in this run (two rocprofv3 passes over a short child run of
         # the same workload); null when the profiler cannot be used
-        traffic = {} if (args.no_traffic or ranks.world > 1) else measure_traffic(name)
+        traffic = {} if args.no_traffic else measure_traffic(name)
         kernels = [k for k in ("convolve", "limit") if k in stage_ms]
         per = {k: roofline_of(k, stage_ms[k], n0, traffic.get(k)) for k in kernels}
         for k in kernels:
@@ -364,13 +453,14 @@ def main():
                 line["gpu_state"] = {"error": repr(exc)[:200]}
 
         if not args.no_secondary and ranks.world == 1:
+            alone = Ranks(rank=0, world=1, local=ranks.local)
             side = {}
             for other in WORKLOADS:
                 if other == name:
                     continue
                 w2 = Workload(other, 0, ranks.local, mg, Device, device_count, make_pair)
                 spin_up(w2.sync, w2.step, min(args.spinup, 0.2))
-                e2 = timed_steps(ranks, w2.sync, w2.step, max(3, args.steps // 2), 1)
+                e2 = timed_steps(alone, w2.sync, w2.step, max(3, args.steps // 2), 1)
                 per_step = e2 / max(3, args.steps // 2)
                 side[other] = {"value": round(w2.frames / per_step / 1e6, 2), "unit": "Msamples/s",
                                "ms_per_step": round(per_step * 1e3, 4),
@@ -396,33 +486,23 @@ def main():
                 line["file_to_file"] = file_to_file(mg, wl.host_pair)
             except Exception as exc:        # noqa: BLE001 -- an unwritable temp folder must not lose the measurement
                 line["file_to_file"] = {"error": repr(exc)}
-        if not args.no_cpu_baseline and ranks.world == 1:
-            line["cpu_baseline"], oracle_out = cpu_baseline(wl, name)
-            line["speedup_vs_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
-            # the timed workload's own output (first pair, as the last timed step left it in HBM) against what
-            # the oracle just computed from the same float32 inputs
+        if not args.no_cpu_baseline:
+            # the timed workload's own output (first pair, as the last timed step left it in HBM), fetched before
+            # anything else runs on the handle, against what the oracle computes from the same float32 inputs
             d, t, n, r, nr, out = wl.jobs[0]
             got = d.download(out, (n, 2)).astype(np.float64)
+            line["cpu_baseline"], oracle_out = cpu_baseline(wl, name, all_cores=ranks.world == 1)
+            # (per GPU: the baseline is one host process against one GPU's share of the job)
+            line["speedup_vs_cpu"] = round(value / ranks.world / line["cpu_baseline"]["value"], 1)
             diff = got - oracle_out
             line["parity"] = {"rms": float(np.sqrt(np.mean(diff * diff))), "max_abs": float(np.abs(diff).max()),
                               "tolerance_rms": 1e-5, "ok": bool(np.sqrt(np.mean(diff * diff)) <= 1e-5),
                               "against": "oracle/mastering_oracle.py (float64) on the workload's first pair; the "
                                          "GPU result is the one the last timed step left in HBM"}
-    stuck = False
-    if ranks.world > 1:
-        import threading
-
-        worker = threading.Thread(target=exchange_fir_tables, daemon=True)
-        worker.start()
-        worker.join(120.0)
-        stuck = worker.is_alive()
-        line["rccl_fir_allgather"] = ({"ok": False, "error": "no answer within 120 s"} if stuck
-                                      else exchange.get("result", {"ok": False, "error": "no result"}))
     if ranks.rank == 0:
         print(json.dumps(line), flush=True)
     if stuck:                       # (a rank still inside the collective would keep the others' teardown waiting)
         os._exit(0)
-    ranks.finish()
 
 
 def file_to_file(mg, pair):
@@ -497,7 +577,7 @@ def _oracle_worker(seconds, sample_rate, fft, need, pair):
     return time.perf_counter() - t0, target.shape[0]
 
 
-def cpu_baseline(wl, name):
+def cpu_baseline(wl, name, all_cores=True):
     """The numpy/scipy restatement of stages.main (oracle/, test infrastructure) timed on this box's
     host cores: (i) one process on the workload's own first pair, what a matchering user gets; (ii)
     BASELINE.md section 3's all-host-cores figure, P concurrent processes of one pair each, on a bounded
@@ -528,6 +608,11 @@ def cpu_baseline(wl, name):
     if os.path.exists(ratio_path):
         with open(ratio_path) as fh:
             out["port_vs_reference"] = json.load(fh)
+    out["note"] = ("kind 'port': this is the oracle, not sergree/matchering itself -- the reference tree does not exist "
+                   "on the GPU box.  port_vs_reference is the oracle / reference wall-time ratio measured on ANOTHER "
+                   "machine (the build container, its `host` field), so value / ratio estimates the reference here")
+    if not all_cores:
+        return out, result
     try:
         import concurrent.futures as cf
 

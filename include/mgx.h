@@ -218,22 +218,6 @@ enum mgx_stage {
 int mgx_stage_timing(mgx_handle* h, int32_t enable);
 int mgx_stage_times(mgx_handle* h, float* ms /* [MGX_STAGE_COUNT] */);
 
-/* Measurement aid (bench.py `gpu_state`): the shader clock a kernel actually runs at.  Launches
- * `workgroups` x 256 threads that each issue `iterations` dependent FMAs; one wave reads the shader
- * cycle counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) before and after.
- * out[0] = shader cycles, out[1] = 100 MHz ticks, out[2] = shader MHz = 100 * out[0] / out[1],
- * out[3] = kernel time in ms by HIP events.  workgroups = 1 probes a nearly idle chip, a few
- * thousand a chip whose every SIMD issues VALU.  No reference counterpart: the boxes of a pool differ
- * in the clocks they sustain, and a throughput figure means little without them. */
-int mgx_clock_probe(mgx_handle* h, int32_t workgroups, int32_t iterations, double* out /* [4] */);
-/* The same for the memory system: out[0..2] = nanoseconds per dependent load in working sets of 1 GiB (HBM),
- * 2 MiB (L2) and 8 KiB (first level); out[3] = GB/s of a streaming read of 1 GiB; out[4] = microseconds per
- * launch of 200 empty kernels queued back to back; out[5], out[6] = nanoseconds per instruction of one wave
- * walking 112 KiB of straight-line code, cold and again; out[7] = ns per dependent LDS read; out[8] = ns per
- * workgroup barrier (256 threads); out[9] = ns per returning atomic on one word; out[10..13] = ns per instruction
- * of a wave looping over 16 / 32 / 48 / 64 KiB of code (which footprints the instruction cache holds).
- * Allocates and frees 1 GiB. */
-int mgx_memory_probe(mgx_handle* h, double* out /* [14] */);
 /* Code bytes of the seven big kernel families (analyze, match_curve, conv_prep, conv, correction_round,
  * correction_tail, limit), bytes[family * 16 + variant] with variant = log2 of the transform size (0 / 1 for the
  * 256 / 1024-block limiter, 0 for the untemplated kernels), as read from this library's own device code
@@ -250,6 +234,7 @@ int mgx_last_fir(mgx_handle* h, void** taps_dev, int32_t* taps);
 /* ---- multi-GPU: one process per GPU, FIR taps over RCCL/xGMI ---------------- */
 int mgx_comm_unique_id(void* id128);                                  /* ncclGetUniqueId, 128 bytes */
 int mgx_comm_init(mgx_handle* h, const void* id128, int rank, int world);
+int mgx_comm_count(mgx_handle* h, int32_t* ranks);                    /* ncclCommCount: the ranks RCCL itself sees */
 int mgx_comm_broadcast_f32(mgx_handle* h, float* dev, int64_t count, int root);
 int mgx_comm_allgather_f32(mgx_handle* h, const float* send_dev, float* recv_dev, int64_t count);
 int mgx_comm_destroy(mgx_handle* h);

@@ -98,8 +98,6 @@ SYMBOLS = {
     "mgx_memcpy_d2h_async": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_size_t]),
     "mgx_stage_timing": (ctypes.c_int, [_VP, ctypes.c_int32]),
     "mgx_stage_times": (ctypes.c_int, [_VP, c_float_p]),
-    "mgx_clock_probe": (ctypes.c_int, [_VP, ctypes.c_int32, ctypes.c_int32, c_double_p]),
-    "mgx_memory_probe": (ctypes.c_int, [_VP, c_double_p]),
     "mgx_code_bytes": (ctypes.c_int, [c_int32_p, ctypes.c_int32]),
     "mgx_clipped_piece_sumsq": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int64, ctypes.c_int32,
                                                ctypes.c_double, c_double_p]),
@@ -116,6 +114,7 @@ SYMBOLS = {
     "mgx_last_fir": (ctypes.c_int, [_VP, ctypes.POINTER(_VP), c_int32_p]),
     "mgx_comm_unique_id": (ctypes.c_int, [_VP]),
     "mgx_comm_init": (ctypes.c_int, [_VP, _VP, ctypes.c_int, ctypes.c_int]),
+    "mgx_comm_count": (ctypes.c_int, [_VP, c_int32_p]),
     "mgx_comm_broadcast_f32": (ctypes.c_int, [_VP, _VP, ctypes.c_int64, ctypes.c_int]),
     "mgx_comm_allgather_f32": (ctypes.c_int, [_VP, _VP, _VP, ctypes.c_int64]),
     "mgx_comm_destroy": (ctypes.c_int, [_VP]),

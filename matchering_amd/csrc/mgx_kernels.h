@@ -78,7 +78,7 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 // transform is 38 KB, the limiter 105 KB), and every launch finds them evicted from the L2s by the hundreds of
 // megabytes the previous kernel streamed.  The instruction cache then pulls them in line by line behind the
 // first wave: ~32 ns per 64-byte line on some boxes of the pool and ~170 ns on others (same clocks, same
-// memory latencies; `mgx_memory_probe`, profiles/r03_*_box_class.json) -- the whole difference between a
+// memory latencies; tools/probe, profiles/r03_*_box_class.json) -- the whole difference between a
 // "fast" and a "slow" box.  So the first eight workgroups of a launch -- one per XCD: the L2s are per XCD --
 // read their own kernel's code AS DATA, 4 KB per load instruction and all of it in flight at once, which puts it
 // into the XCD's L2; instruction fetch then finds it there.  (Every workgroup of the first generation doing so was

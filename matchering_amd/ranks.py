@@ -1,0 +1,160 @@
+"""Rendezvous of the rank processes of one node: barrier, max, broadcast and gather of small payloads.
+
+The reference masters one pair per ``process`` call and has no notion of ranks (core.py:32-121); pairs share
+nothing, so the only things rank processes ever tell each other are the 128-byte RCCL id (album mode's FIR
+broadcast, bench.py's all-gather), "I am here" (the barriers around a timed region) and one number (the
+slowest rank's time).  That does not need a collective library: rank 0 listens on a local stream socket, the
+others connect, and every operation is one message to rank 0 and one back (a star; 8 ranks at most per node).
+
+The socket is an abstract-namespace Unix socket named after MASTER_ADDR:MASTER_PORT -- the launcher's own
+store (``torch.distributed.run`` keeps a TCP store on that very port) is left alone, nothing is left behind in
+the file system, and two jobs with different ports do not meet.  ``MGX_RENDEZVOUS=tcp://host:port`` selects a
+TCP socket instead (ranks on several nodes).  Every wait is bounded (``timeout`` seconds).
+"""
+
+import os
+import pickle
+import socket
+import struct
+import time
+
+
+def rank_environment():
+    """(rank, world, local_rank) as a launcher exports them (RANK, WORLD_SIZE, LOCAL_RANK); (0, 1, 0) alone."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world of {world}")
+    return rank, world, local
+
+
+def _address():
+    explicit = os.environ.get("MGX_RENDEZVOUS", "")
+    if explicit.startswith("tcp://"):
+        host, _, port = explicit[6:].rpartition(":")
+        return socket.AF_INET, (host or "127.0.0.1", int(port))
+    key = f"{os.environ.get('MASTER_ADDR', '127.0.0.1')}:{os.environ.get('MASTER_PORT', '29511')}"
+    return socket.AF_UNIX, "\0mgx-ranks-" + key
+
+
+def _send(sock, obj):
+    blob = pickle.dumps(obj, protocol=4)
+    sock.sendall(struct.pack("<Q", len(blob)) + blob)
+
+
+def _recv(sock):
+    def exactly(n):
+        parts = []
+        while n:
+            chunk = sock.recv(n)
+            if not chunk:
+                raise ConnectionError("a rank closed its connection")
+            parts.append(chunk)
+            n -= len(chunk)
+        return b"".join(parts)
+
+    (size,) = struct.unpack("<Q", exactly(8))
+    return pickle.loads(exactly(size))
+
+
+class Ranks:
+    """The rank processes of one job.  With one rank every operation returns at once."""
+
+    def __init__(self, rank=None, world=None, local=None, timeout=600.0):
+        env = rank_environment()
+        self.rank = env[0] if rank is None else int(rank)
+        self.world = env[1] if world is None else int(world)
+        self.local = env[2] if local is None else int(local)
+        self.timeout = timeout
+        self.peers = {}                      # rank 0: rank -> socket
+        self.root = None                     # other ranks: the socket to rank 0
+        self.listener = None
+        if self.world > 1:
+            self._meet()
+
+    # ---- rendezvous ------------------------------------------------------------------------------------
+    def _meet(self):
+        family, address = _address()
+        deadline = time.monotonic() + self.timeout
+        if self.rank == 0:
+            self.listener = socket.socket(family, socket.SOCK_STREAM)
+            if family == socket.AF_INET:
+                self.listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            self.listener.bind(address)
+            self.listener.listen(self.world)
+            while len(self.peers) < self.world - 1:
+                self.listener.settimeout(max(0.1, deadline - time.monotonic()))
+                try:
+                    conn, _ = self.listener.accept()
+                except socket.timeout:
+                    missing = sorted(set(range(1, self.world)) - set(self.peers))
+                    raise TimeoutError(f"ranks {missing} did not arrive within {self.timeout:.0f} s") from None
+                conn.settimeout(self.timeout)
+                who = _recv(conn)
+                self.peers[int(who)] = conn
+            for conn in self.peers.values():
+                _send(conn, "met")
+        else:
+            while True:
+                sock = socket.socket(family, socket.SOCK_STREAM)
+                try:
+                    sock.connect(address)
+                    break
+                except (ConnectionRefusedError, FileNotFoundError):
+                    sock.close()
+                    if time.monotonic() > deadline:
+                        raise TimeoutError(f"rank 0 did not open the rendezvous within {self.timeout:.0f} s") from None
+                    time.sleep(0.02)
+            sock.settimeout(self.timeout)
+            _send(sock, self.rank)
+            self.root = sock
+            _recv(sock)
+
+    # ---- one round trip through rank 0 --------------------------------------------------------------------
+    def _exchange(self, value, reduce):
+        """Every rank contributes ``value``; ``reduce(list indexed by rank)`` runs on rank 0 and its result
+        is what every rank returns."""
+        if self.world == 1:
+            return reduce([value])
+        if self.rank == 0:
+            values = [value] + [None] * (self.world - 1)
+            for r, conn in self.peers.items():
+                values[r] = _recv(conn)
+            out = reduce(values)
+            for conn in self.peers.values():
+                _send(conn, out)
+            return out
+        _send(self.root, value)
+        return _recv(self.root)
+
+    def barrier(self):
+        self._exchange(None, lambda values: None)
+
+    def max(self, value):
+        return float(self._exchange(float(value), max))
+
+    def gather(self, value):
+        """The values of all ranks, in rank order, on every rank."""
+        return self._exchange(value, list)
+
+    def broadcast_bytes(self, payload, size, root=0):
+        """``payload`` of rank ``root`` (``size`` bytes) on every rank."""
+        out = self._exchange(bytes(payload) if self.rank == root else None, lambda values: values[root])
+        if len(out) != size:
+            raise ValueError(f"broadcast payload has {len(out)} bytes, expected {size}")
+        return out
+
+    def finish(self):
+        if self.world > 1:
+            try:
+                self.barrier()               # nobody closes while another rank is still inside an operation
+            except (OSError, ConnectionError, EOFError):
+                pass
+        for conn in list(self.peers.values()) + [self.root, self.listener]:
+            if conn is not None:
+                try:
+                    conn.close()
+                except OSError:
+                    pass
+        self.peers, self.root, self.listener = {}, None, None

@@ -35,6 +35,17 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} is declared in include/mgx.h but not exported by libmgx.so"
 
 
+def test_library_exports_nothing_but_the_header(tmp_path):
+    """include/mgx.h IS the boundary: libmgx.so exports the declared functions and no other `mgx_*` symbol --
+    probes and phase traces are measurement code and live elsewhere (tools/probe/libmgx_probe.so; development
+    builds made with -DMGX_TAIL_TRACE / -DMGX_DEV_LIMITER_PHASES beside the product, never as libmgx.so)."""
+    _native.library()                                   # (builds the library if it is not there yet)
+    listing = subprocess.run(["nm", "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in listing.splitlines() if re.match(r".* [TW] mgx_", ln)})
+    assert exported == declared_functions()
+    assert not [ln for ln in listing.splitlines() if "probe" in ln.lower()]
+
+
 def test_struct_layouts_match_the_c_compiler(tmp_path):
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mgx.h"\n'

@@ -1,9 +1,11 @@
-"""The N>1 path of bench.py on CPU: two processes over gloo (world_size 2).
+"""The N>1 path on CPU: real rank processes (world_size 2 and 8).
 
 Pairs are independent, so the multi-GPU path is: rank r masters pair r, no data-path collective, a
 barrier + max-over-ranks around the timed region, and a broadcast of the 128-byte RCCL id.  Those
-host-side pieces (bench.Ranks, bench.timed_steps, the per-rank synthetic pair) are exercised here
-without a GPU; the RCCL all-gather of the FIR tables itself needs GPUs and runs in bench.py.
+host-side pieces (matchering_amd.ranks.Ranks -- a local socket, no torch --, bench.timed_steps, the
+per-rank synthetic pair) are exercised here without a GPU; the RCCL all-gather of the FIR tables itself
+needs GPUs and runs in bench.py.  The batch front end is run under a two-process ``gloo`` world as a
+launcher-started job would be (``torch.distributed.run`` exports the same RANK / WORLD_SIZE / LOCAL_RANK).
 """
 
 import multiprocessing as mp
@@ -29,7 +31,7 @@ def _worker(rank, world, port, queue):
     import bench
     from matchering_amd.synth import make_pair
 
-    ranks = bench.Ranks()
+    ranks = bench.Ranks()                       # matchering_amd.ranks.Ranks: a local socket, no torch
     try:
         assert ranks.rank == rank and ranks.world == world
 
@@ -39,28 +41,58 @@ def _worker(rank, world, port, queue):
         slow = ranks.max(10.0 + rank)           # the job's time is the slowest rank's
         payload = bytes(range(128)) if rank == 0 else bytes(128)
         uid = ranks.broadcast_bytes(payload, 128)
+        everyone = ranks.gather({"rank": rank})
         target, _ = make_pair(0.05, 44100, pair=ranks.rank)
-        queue.put((rank, slow, uid == bytes(range(128)), float(np.abs(target).sum())))
+        queue.put((rank, slow, uid == bytes(range(128)), float(np.abs(target).sum()), [e["rank"] for e in everyone]))
     finally:
         ranks.finish()
 
 
-def test_two_ranks_over_gloo():
+def _run_world(world):
     ctx = mp.get_context("spawn")
     queue = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, queue)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, queue)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted(queue.get(timeout=300) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, max0, ok0, sum0), (r1, max1, ok1, sum1) = results
+    return results
+
+
+def test_two_ranks_over_the_local_socket():
+    (r0, max0, ok0, sum0, seen0), (r1, max1, ok1, sum1, seen1) = _run_world(2)
     assert (r0, r1) == (0, 1)
     assert max0 == max1 == 11.0                # max over ranks, identical everywhere
     assert ok0 and ok1                          # rank 0's 128-byte id reached rank 1
     assert sum0 != sum1                         # every rank masters its own pair
+    assert seen0 == seen1 == [0, 1]             # gather: everyone, in rank order, everywhere
+
+
+def test_eight_ranks_over_the_local_socket():
+    results = _run_world(8)                     # a node's worth of ranks (the driver's --gpus 8)
+    assert [r[0] for r in results] == list(range(8))
+    assert all(r[1] == 17.0 and r[2] and r[4] == list(range(8)) for r in results)
+    assert len({r[3] for r in results}) == 8
+
+
+def test_a_missing_rank_is_a_timeout_not_a_hang():
+    sys.path.insert(0, ROOT)
+    from matchering_amd.ranks import Ranks
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    try:
+        import pytest
+
+        with pytest.raises(TimeoutError):
+            Ranks(rank=0, world=2, local=0, timeout=0.5)          # rank 1 never comes
+        with pytest.raises(TimeoutError):
+            Ranks(rank=1, world=2, local=1, timeout=0.5)          # rank 0 never listens
+    finally:
+        os.environ.pop("MASTER_PORT", None)
+        os.environ.pop("MASTER_ADDR", None)
 
 
 # ---- the batch front end itself under a real two-process world ---------------

@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--fir-only", action="store_true")
     ap.add_argument("--preheat", type=float, default=0.0,
-                    help="seconds of all-SIMD FMA load (mgx_clock_probe) right before the timed rounds: does the box "
+                    help="seconds of all-SIMD FMA load (tools/mgx_probe.py) right before the timed rounds: does the box "
                          "need waking up?")
     args = ap.parse_args()
 
@@ -78,14 +78,12 @@ def main():
         else:
             print(f"{name:12s} max |diff| vs {variants[0][0]}: {np.abs(got - yardstick).max():.3e}")
     if args.preheat > 0:
-        import ctypes
+        import mgx_probe        # tools/mgx_probe.py (this folder is on sys.path: the script lives in it)
 
-        from matchering_amd import _native
-
-        res = (ctypes.c_double * 4)()
+        res = [0.0] * 4
         t_end = time.perf_counter() + args.preheat
         while time.perf_counter() < t_end:
-            _native.check(_native.library().mgx_clock_probe(dev.handle, 8192, 600000, res))
+            res = mgx_probe.clock(dev.index, 8192, 600000)
         print(f"preheated {args.preheat:.1f} s: shader {res[2]:.0f} MHz under load")
     for _ in range(args.rounds):
         for name, env in variants:

@@ -51,10 +51,12 @@ def main():
 
     stages(2)
     report["stage_us_cold"] = stages(7)
-    res = (ctypes.c_double * 4)()
+    import mgx_probe            # tools/mgx_probe.py (this folder is on sys.path: the script lives in it)
+
+    res = [0.0] * 4
     t_end = time.perf_counter() + 2.0
     while time.perf_counter() < t_end:
-        _native.check(_native.library().mgx_clock_probe(dev.handle, 8192, 600000, res))
+        res = mgx_probe.clock(dev.index, 8192, 600000)
     report["preheat_shader_mhz"] = round(res[2], 1)
     report["stage_us_after_2s_of_load"] = stages(7)
     dev.stage_timing(False)

@@ -6,7 +6,7 @@ HBM-bound ones hardly move.  This collects what can tell the classes apart:
 
 * the driver's view: performance level, clock tables with the active level, power cap and draw,
   compute / memory partition mode (sysfs first, ``rocm-smi --json`` as a second source);
-* the clock kernels really see: ``mgx_clock_probe`` (s_memtime against the constant 100 MHz counter)
+* the clock kernels really see: ``mgx_probe_clock`` (tools/probe/libmgx_probe.so) (s_memtime against the constant 100 MHz counter)
   on a nearly idle chip (one workgroup), on a chip whose every SIMD issues VALU, and straight after a
   pause (how fast the clock comes back).
 
@@ -95,18 +95,22 @@ def smi_state(timeout=20):
     return keep
 
 
-def clock_probe(dev=None):
-    """Shader MHz by mgx_clock_probe: idle chip, loaded chip, and the first kernel after a pause."""
-    from matchering_amd import _native
-    from matchering_amd.device import Device
+def _probe_module():
+    import importlib
 
-    own = dev is None
-    dev = dev or Device(0)
-    lib = _native.library()
-    out = (ctypes.c_double * 4)()
+    here = os.path.dirname(os.path.abspath(__file__))
+    if here not in sys.path:
+        sys.path.insert(0, here)
+    return importlib.import_module("mgx_probe")
+
+
+def clock_probe(dev=None):
+    """Shader MHz by mgx_probe_clock (tools/probe): idle chip, loaded chip, and the first kernel after a pause."""
+    index = 0 if dev is None else dev.index
+    mgx_probe = _probe_module()
 
     def probe(wgs, iters):
-        _native.check(lib.mgx_clock_probe(dev.handle, wgs, iters, out))
+        out = mgx_probe.clock(index, wgs, iters)
         return {"mhz": round(out[2], 1), "ms": round(out[3], 4)}
 
     res = {}
@@ -117,8 +121,6 @@ def clock_probe(dev=None):
     time.sleep(0.5)
     res["after_500ms_pause_short"] = probe(2048, 2000)
     res["then_loaded"] = probe(8192, 60000)
-    if own:
-        dev.close() if hasattr(dev, "close") else None
     return res
 
 
@@ -148,8 +150,6 @@ def compact_state(dev=None):
     """The few numbers that tell one box of the pool from another, for bench.py's JSON line."""
     import threading
 
-    from matchering_amd import _native
-
     out = {}
     sysfs = sysfs_state()
     bus = own_pci_bus()
@@ -170,16 +170,11 @@ def compact_state(dev=None):
     out["gpus_on_node"] = len(sysfs)
     out["other_gpus_clocked_up"] = busy
     try:
-        own = dev is None
-        if own:
-            from matchering_amd.device import Device
-
-            dev = Device(0)
-        lib = _native.library()
-        res = (ctypes.c_double * 4)()
+        index = 0 if dev is None else dev.index
+        mgx_probe = _probe_module()
 
         def probe(wgs, iters):
-            _native.check(lib.mgx_clock_probe(dev.handle, wgs, iters, res))
+            res = mgx_probe.clock(index, wgs, iters)
             return round(res[2], 1), round(res[3], 3)
 
         probe(4096, 20000)
@@ -199,8 +194,7 @@ def compact_state(dev=None):
         out["under_probe"] = seen
         out["shader_mhz_one_workgroup"], _ = probe(1, 200000)
         out["shader_mhz_short_kernel"], out["short_kernel_ms"] = probe(2048, 2000)
-        mem = (ctypes.c_double * 14)()
-        _native.check(lib.mgx_memory_probe(dev.handle, mem))
+        mem = mgx_probe.memory(index)
         out["memory_probe"] = {"ns_per_dependent_load": {"1GiB_hbm": round(mem[0], 1), "2MiB_l2": round(mem[1], 1),
                                                          "8KiB_first_level": round(mem[2], 1)},
                                "stream_read_GBs": round(mem[3], 1), "us_per_empty_launch": round(mem[4], 2),
@@ -209,8 +203,6 @@ def compact_state(dev=None):
                                "ns_per_returning_atomic": round(mem[9], 1),
                                "ns_per_instruction_looping_over_code_of": {"16KiB": round(mem[10], 2), "32KiB": round(mem[11], 2),
                                                                             "48KiB": round(mem[12], 2), "64KiB": round(mem[13], 2)}}
-        if own:
-            dev.close()
     except Exception as exc:                                     # noqa: BLE001
         out["probe_error"] = repr(exc)[:200]
     return out
