@@ -420,14 +420,13 @@ def run(args, ranks):
         stuck = worker.is_alive()
         mine = ({"ok": False, "error": "no answer within 120 s"} if stuck
                 else exchange.get("result", {"ok": False, "error": "no result"}))
-        if not stuck:
-            everyone = ranks.gather(mine)                      # the line carries rank 0's view and how many ranks agree
-            mine = dict(everyone[0], ranks_ok=sum(1 for e in everyone if e.get("ok")))
-        line["rccl_fir_allgather"] = mine
+        # (every rank gets here within its 120 s, stuck or not, so this gather cannot wait for a missing one)
+        everyone = ranks.gather(mine)                          # the line carries rank 0's view and how many ranks agree
+        line["rccl_fir_allgather"] = dict(everyone[0], ranks_ok=sum(1 for e in everyone if e.get("ok")))
     elif ranks.world > 1:
         line["rendezvous"] = {"ranks_seen": len(ranks.gather(ranks.rank)), "transport": "matchering_amd.ranks"}
 
-    if ranks.rank == 0 and not args.stand_in:
+    if ranks.rank == 0 and not args.stand_in and not stuck:
         # ---- rooflines of the two streaming kernels, timed where they run: inside the pipeline ----
         # (at N > 1 the other ranks are idle by now: these legs describe one GPU, as at N = 1)
         stage_ms, n0 = wl.stage_profile(max(5, min(args.steps, 20)))
