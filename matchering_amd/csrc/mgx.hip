@@ -186,6 +186,19 @@ struct mgx_handle {
     int* error_host = nullptr;
     int* error_dev = nullptr;
     int last_taps = 0;
+    // the arguments of the last mgx_master call, kept so that it can be queued again when the level-correction
+    // tail reports that its workgroups were not resident together (check_device_error)
+    struct MasterCall {
+        bool valid = false;
+        const float* target = nullptr;
+        const float* reference = nullptr;
+        const float* fir_given = nullptr;
+        int64_t n_target = 0, n_reference = 0;
+        mgx_config cfg;
+        float* out[3] = {nullptr, nullptr, nullptr};
+    } last_call;
+    bool avoid_tail = false;                // sticky after such a report: rounds 1..K-1 as one launch each
+    bool requeued = false;                  // the last check_device_error queued the call again
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
 };
@@ -290,8 +303,9 @@ static int check_config(const mgx_config* c) {
     if (c->fft_size < 64 || c->fft_size > 32768)
         return fail(MGX_ERR_UNSUPPORTED, "fft_size outside [64, 32768] is not implemented "
                                          "(an analysis segment is one or two transforms that fit one CU's LDS)");
-    if (c->rms_correction_steps < 0 || c->rms_correction_steps > 16)   /* CorrectionState::coeffs, the gain words */
-        return fail(MGX_ERR_UNSUPPORTED, "rms_correction_steps outside [0, 16]");
+    if (c->rms_correction_steps < 0) return fail(MGX_ERR_ARGUMENT, "rms_correction_steps must not be negative");
+    if (c->rms_correction_steps > 4096)      /* (a flag word per round and summing workgroup: 4 MB at 4096) */
+        return fail(MGX_ERR_UNSUPPORTED, "more than 4096 rms_correction_steps are not implemented");
     if (c->lowess_it < 0 || c->lowess_it > 64) return fail(MGX_ERR_ARGUMENT, "lowess_it outside [0, 64]");
     if (!(c->threshold > c->min_value && c->threshold < 1.0 && c->min_value > 0.0))
         return fail(MGX_ERR_ARGUMENT, "threshold/min_value out of range (defaults.py:93-99)");
@@ -806,18 +820,39 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     }
 }
 
-// A bounded device-side wait expired (never seen in normal operation; the spins are bounded so that a lost
-// word cannot hang the GPU, and the audio behind such a wait is wrong).  Called by every entry point that
-// has just waited for the stream -- with or without a report -- so that the failure cannot pass silently;
-// the flag is host memory, reading it costs nothing.  The counters a timed-out kernel may have left
-// half-counted are put back, so the handle is good for the next call.
+// A bounded device-side wait expired (never seen in normal operation; the spins are bounded so that a lost word
+// cannot hang the GPU, and the audio behind such a wait is wrong).  Called by every entry point that has just
+// waited for the stream -- with or without a report -- so that the failure cannot pass silently; the flag is host
+// memory, reading it costs nothing.  The counters a timed-out kernel may have left half-counted are put back, so
+// the handle is good for the next call.
+//   * DEVICE_ERROR_TAIL: k_correction_tail's workgroups (<= 129, spinning on each other's flag words) were not
+//     resident together -- something else held the compute units.  Not a lost word: the last mgx_master call is
+//     queued again with rounds 1..K-1 as one launch each (they wait for nobody), the handle stays that way, and the
+//     call succeeds; mgx_last_error() carries a note.
+//   * anything else (a limiter look-back word that never came): MGX_ERR_HIP.
+static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c);
 static int check_device_error(mgx_handle* h) {
+    h->requeued = false;
     if (!h->error_host || *(volatile int*)h->error_host == 0) return 0;
+    const int what = *(volatile int*)h->error_host;
     *(volatile int*)h->error_host = 0;
     if (h->round_ctr.p) HIP_TRY(hipMemsetAsync(h->round_ctr.p, 0, h->round_ctr.bytes, h->stream));
     if (h->lim_ctrl.p) HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 64, h->stream));
     if (h->conv_queue.p) HIP_TRY(hipMemsetAsync(h->conv_queue.p, 0, 64, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (what == DEVICE_ERROR_TAIL && h->last_call.valid && !h->avoid_tail) {
+        h->avoid_tail = true;
+        const mgx_handle::MasterCall again = h->last_call;
+        MGX_TRY(queue_master(h, again));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (*(volatile int*)h->error_host == 0) {
+            h->requeued = true;
+            g_error = "note: the level-correction tail kernel's workgroups were not resident together (the GPU is shared); "
+                      "the call was run again with one launch per correction round, and this handle keeps doing so";
+            return 0;
+        }
+        *(volatile int*)h->error_host = 0;
+    }
     return fail(MGX_ERR_HIP, "a bounded device-side wait expired (limiter look-back or level-correction round): "
                              "the results of the calls since the last synchronisation are not valid");
 }
@@ -1220,10 +1255,17 @@ int mgx_pcm_encode(mgx_handle* h, const float* x_dev, int64_t samples, int32_t b
 } // extern "C"
 static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target, const float* reference_dev,
                        int64_t n_reference, const mgx_config* cfg, const float* fir_given, float* result_dev,
-                       float* result_no_limiter_dev, float* result_no_limiter_normalized_dev, mgx_report* report) {
-    if (!h || !target_dev || !reference_dev) return fail(MGX_ERR_ARGUMENT, "null argument");
-    MGX_TRY(check_config(cfg));
-    HIP_TRY(hipSetDevice(h->device));
+                       float* result_no_limiter_dev, float* result_no_limiter_normalized_dev, mgx_report* report);
+// every launch of one stages.main, queued on the handle's stream (no host round trip)
+static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
+    const float* target_dev = c.target;
+    const float* reference_dev = c.reference;
+    const float* fir_given = c.fir_given;
+    const int64_t n_target = c.n_target, n_reference = c.n_reference;
+    const mgx_config* cfg = &c.cfg;
+    float* result_dev = c.out[0];
+    float* result_no_limiter_dev = c.out[1];
+    float* result_no_limiter_normalized_dev = c.out[2];
     const int f = cfg->fft_size;
     if (result_dev) {               // validate limiter parameters before any work is queued
         LimiterParams lp;
@@ -1272,9 +1314,12 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
         const size_t ctr_bytes = (size_t)(1 + ra.divisions) * sizeof(unsigned);
         // at most ~128 workgroups in k_correction_tail, at most 64 chunks (the lanes of a wave) per workgroup
         const int tail_groups = std::max((ra.chunks + 63) / 64, std::max(1, std::min(ra.chunks, 128 / ra.divisions)));
-        const int tail_total = cfg->rms_correction_steps > 1 ? ra.divisions * tail_groups : 0;
-        MGX_TRY(ensure(h, h->tail_gains, (16 + (size_t)15 * tail_total) * sizeof(unsigned long long)));
+        const bool use_tail = cfg->rms_correction_steps > 1 && !h->avoid_tail;
+        const int tail_total = use_tail ? ra.divisions * tail_groups : 0;
+        const int tail_rounds = use_tail ? cfg->rms_correction_steps - 1 : 0;
+        MGX_TRY(ensure(h, h->tail_gains, ((size_t)tail_rounds + 1 + (size_t)tail_rounds * tail_total) * sizeof(unsigned long long)));
         ra.tail_total = tail_total;
+        ra.tail_rounds = tail_rounds;
         if (h->round_ctr.bytes < ctr_bytes) {                 // zeroed when (re)allocated, reset by each launch
             MGX_TRY(ensure(h, h->round_ctr, std::max(ctr_bytes, (size_t)4096)));
             HIP_TRY(hipMemsetAsync(h->round_ctr.p, 0, h->round_ctr.bytes, h->stream));
@@ -1300,7 +1345,7 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
         ra.lim_published = nullptr;
         ra.lim_words = 0;
         ra.lim_ticket = nullptr;
-        ra.tail_gains = rounds > 1 ? (unsigned long long*)h->tail_gains.p : nullptr;
+        ra.tail_gains = use_tail ? (unsigned long long*)h->tail_gains.p : nullptr;
         auto with_final = [&](RoundArgs& r) -> int {          // the launch that runs the last round
             r.final_peaks = (const float*)h->block_peak.p;
             return 0;
@@ -1317,7 +1362,19 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
             if (rounds == 1) MGX_TRY(with_final(r0));
             hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, r0);
         }
-        if (rounds > 1) {                                     // every further round inside one small resident grid
+        if (rounds > 1 && !use_tail) {
+            // one launch per round, the last arriver of each decides (k_correction_round without a tail): what a handle
+            // falls back to after its tail kernel found the GPU shared (check_device_error), and MGX_NO_TAIL=1
+            for (int r = 1; r < rounds; ++r) {
+                RoundArgs rr = ra;
+                rr.build_band = 0;
+                rr.step = r;
+                rr.final_peaks = nullptr;
+                if (r == rounds - 1) MGX_TRY(with_final(rr));
+                hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, rr);
+            }
+        }
+        if (use_tail) {                                       // every further round inside one small resident grid
             RoundArgs rt = ra;
             rt.build_band = 0;
             rt.step = 1;
@@ -1351,6 +1408,38 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
         MGX_TRY(run_limiter(h, (const float*)h->y.p, n_target, cfg, &cs->gain, post, &cs->limiter_active, result_dev,
                             limiter_preset));
     }
+    return 0;
+}
+
+static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target, const float* reference_dev,
+                       int64_t n_reference, const mgx_config* cfg, const float* fir_given, float* result_dev,
+                       float* result_no_limiter_dev, float* result_no_limiter_normalized_dev, mgx_report* report) {
+    if (!h || !target_dev || !reference_dev) return fail(MGX_ERR_ARGUMENT, "null argument");
+    MGX_TRY(check_config(cfg));
+    HIP_TRY(hipSetDevice(h->device));
+    if (result_dev) {               // validate limiter parameters before any work is queued
+        LimiterParams lp;
+        const std::string err = limiter_params(*cfg, lp);
+        if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
+    }
+    mgx_handle::MasterCall& call = h->last_call;
+    call.valid = false;
+    call.target = target_dev;
+    call.reference = reference_dev;
+    call.fir_given = fir_given;
+    call.n_target = n_target;
+    call.n_reference = n_reference;
+    call.cfg = *cfg;
+    call.out[0] = result_dev;
+    call.out[1] = result_no_limiter_dev;
+    call.out[2] = result_no_limiter_normalized_dev;
+    if (const char* v = std::getenv("MGX_NO_TAIL"))           // measurement aid: one launch per correction round
+        if (v[0] == '1') h->avoid_tail = true;
+    MGX_TRY(queue_master(h, call));
+    call.valid = true;
+    TrackWork& tw = h->track[0];
+    TrackWork& rw = h->track[1];
+    CorrectionState* cs = (CorrectionState*)h->cstate.p;
     if (report) {
         MGX_TRY(ensure_pinned(h, 1 << 16));
         char* pin = (char*)h->pinned;
@@ -1358,12 +1447,15 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
         TrackStats* st_r = (TrackStats*)(pin + 256);
         CorrectionState* hc = (CorrectionState*)(pin + 512);
         double* c0 = (double*)(pin + 1024);
-        HIP_TRY(hipMemcpyAsync(st_t, tw.stats.p, sizeof(TrackStats), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(st_r, rw.stats.p, sizeof(TrackStats), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(hc, cs, sizeof(CorrectionState), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipMemcpyAsync(c0, h->scalars.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        MGX_TRY(check_device_error(h));
+        for (int attempt = 0; attempt < 2; ++attempt) {      // (a second time when the check queued the call again)
+            HIP_TRY(hipMemcpyAsync(st_t, tw.stats.p, sizeof(TrackStats), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(st_r, rw.stats.p, sizeof(TrackStats), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(hc, cs, sizeof(CorrectionState), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipMemcpyAsync(c0, h->scalars.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            MGX_TRY(check_device_error(h));
+            if (!h->requeued) break;
+        }
         std::memset(report, 0, sizeof(*report));
         report->final_amplitude_coefficient = st_r->amplitude_c;
         report->target_match_rms = st_t->match_rms;

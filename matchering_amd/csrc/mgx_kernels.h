@@ -1257,7 +1257,7 @@ __global__ __launch_bounds__(1024) void k_correction_step(const double* partial,
     decide_loud<1024>(sums, divisions, piece, 1.0, red, nullptr, nullptr, avg, match, count);
     if (threadIdx.x == 0) {
         const double c = *reference_match_rms / fmax(eps, match);      // match_levels.py:106-111
-        cs->coeffs[cs->steps_done] = c;
+        if (cs->steps_done < 16) cs->coeffs[cs->steps_done] = c;
         cs->steps_done += 1;
         cs->gain *= c;
     }
@@ -1333,10 +1333,13 @@ struct RoundArgs {
     unsigned long long* lim_published;
     long long lim_words;
     int* lim_ticket;
-    unsigned long long* tail_gains;   // [16] gains published between the rounds of k_correction_tail, or null; behind
-                                      // them [15][tail_total] words for its workgroups' partial sums (the value is the flag)
+    unsigned long long* tail_gains;   // [tail_rounds + 1] gains published between the rounds of k_correction_tail (slot r:
+                                      // the gain after its round r; slot tail_rounds: the gain after round 0), or null;
+                                      // behind them [tail_rounds][tail_total] words for its workgroups' partial sums
+                                      // (the value is the flag)
     int tail_total;                   // summing workgroups of the k_correction_tail launch that follows (0: none);
                                       // with one, this launch leaves its partials and the decision to that kernel
+    int tail_rounds;                  // rounds that kernel runs (rms_correction_steps - 1; any number: defaults.py:118-120)
     int* error;                       // set when a bounded wait expired
 };
 // The decision of one round (stages.py:149-168), taken by ONE 256-thread workgroup after every partial
@@ -1382,7 +1385,7 @@ __device__ __forceinline__ double correction_decide(const RoundArgs& a, int tota
         const double c = *a.reference_match_rms / fmax(a.eps, match);      // match_levels.py:106-111
         CorrectionState* cs = a.cs;
         new_gain = gain_in * c;
-        cs->coeffs[step] = c;
+        if (step < 16) cs->coeffs[step] = c;
         cs->steps_done = step + 1;
         cs->gain = new_gain;
         if (a.final_peaks) {
@@ -1412,7 +1415,7 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
     const double g = a.cs->gain;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (a.tail_gains && blockIdx.x == 0)                                                         // "not yet": k_correction_tail
-        for (int i = threadIdx.x; i < 16 + 15 * a.tail_total; i += 256) a.tail_gains[i] = ~0ull;
+        for (int i = threadIdx.x; i < a.tail_rounds + 1 + a.tail_rounds * a.tail_total; i += 256) a.tail_gains[i] = ~0ull;
     if (a.lim_published) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.lim_words; i += (long long)gridDim.x * 256)
             a.lim_published[i] = ~0ull;
@@ -1584,23 +1587,39 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
 // coefficients are ratios of two loudness estimates of nearly the same signal).
 // Phase stamps of this kernel and of round 0's last workgroup: profiles/r03_z_correction_phases.txt
 // (-DMGX_TAIL_TRACE, tools/tail_trace.py).
-// one lane's bounded wait for an 8-byte flag word to leave the all-ones pattern (0 and the error word on expiry)
+// Values of the handle's error word.  A limiter look-back that expires (limiter_kernel.h) means a lost word: the
+// audio is wrong and the call fails.  An expired wait of k_correction_tail means its workgroups were not resident
+// together (another process's kernels held the compute units): the host then runs the rounds again as one launch
+// each, which wait for nobody (mgx.hip, check_device_error).
+constexpr int DEVICE_ERROR_LOOKBACK = 1, DEVICE_ERROR_TAIL = 2;
+#ifdef MGX_TEST_TAIL_EXPIRE
+__device__ int g_test_tail_launches;
+#endif
+#ifdef MGX_TEST_TAIL_MAX_SPINS                             // tests/test_device_errors.py: a tail that gives up quickly
+constexpr int TAIL_MAX_SPINS = MGX_TEST_TAIL_MAX_SPINS;
+#else
+constexpr int TAIL_MAX_SPINS = 1 << 20;
+#endif
+// one lane's bounded wait for an 8-byte flag word to leave the all-ones pattern (`on_expiry` and the error word on expiry)
 __device__ __forceinline__ unsigned long long poll_word(const unsigned long long* w, int* error, unsigned long long on_expiry) {
     unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int spins = 0;
-    while (v == ~0ull && spins < (1 << 20)) {
+    while (v == ~0ull && spins < TAIL_MAX_SPINS) {
         if (spins < 64) __builtin_amdgcn_s_sleep(1);
         else __builtin_amdgcn_s_sleep(16);
         v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         ++spins;
     }
     if (v == ~0ull) {
-        *error = 1;
+        *error = DEVICE_ERROR_TAIL;
         v = on_expiry;
     }
     return v;
 }
-constexpr int TAIL_GAIN0 = 15;                   // tail_gains slot of the gain after round 0
+// CorrectionState::coeffs mirrors mgx_report: the first 16 coefficients are kept for the log, the product of all is the gain
+__device__ __forceinline__ void keep_coefficient(CorrectionState* cs, int step, double c) {
+    if (step < 16) __hip_atomic_store(&cs->coeffs[step], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // The deciding workgroup of k_correction_tail (the one past the summing ones).  First round 0's decision from the
 // partials k_correction_round left (the launch boundary made them visible; that kernel skips its own arrival
 // count and decision when a tail follows -- they were 4 us with the whole chip waiting, here they run beside the
@@ -1633,8 +1652,11 @@ __device__ __forceinline__ void tail_decider(const RoundArgs& a, int groups, int
             if (lane == 0) {
                 const double c = *a.reference_match_rms / fmax(a.eps, match);          // match_levels.py:106-111
                 const double next = gain_in * c;
-                __hip_atomic_store(a.tail_gains + TAIL_GAIN0, double_bits(next), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                put(&a.cs->coeffs[a.step - 1], c);
+#ifdef MGX_TEST_TAIL_EXPIRE               // tests/test_device_errors.py: the first tail of the process never hears of round 0's gain
+                if (atomicAdd(&g_test_tail_launches, 1) > 0)
+#endif
+                __hip_atomic_store(a.tail_gains + a.tail_rounds, double_bits(next), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                keep_coefficient(a.cs, a.step - 1, c);
                 decided = next;
             }
         }
@@ -1642,7 +1664,7 @@ __device__ __forceinline__ void tail_decider(const RoundArgs& a, int groups, int
     }
     double g = decided;
     for (int r = 0; r < rounds; ++r) {
-        const unsigned long long* words = a.tail_gains + 16 + (size_t)r * total;
+        const unsigned long long* words = a.tail_gains + a.tail_rounds + 1 + (size_t)r * total;
         const bool last_round = r == rounds - 1;
         for (int k = threadIdx.x; k < total; k += 256) stage[k] = bits_double(poll_word(words + k, a.error, 0ull));
         asm volatile("" ::: "memory");        // the peak words are read AFTER their flag words were seen (compiler order;
@@ -1669,7 +1691,7 @@ __device__ __forceinline__ void tail_decider(const RoundArgs& a, int groups, int
                 if (!last_round)
                     __hip_atomic_store(a.tail_gains + r, double_bits(next), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 CorrectionState* cs = a.cs;
-                put(&cs->coeffs[a.step + r], c);
+                keep_coefficient(cs, a.step + r, c);
                 if (last_round) {
                     puti(&cs->steps_done, a.step + r + 1);
                     put(&cs->gain, next);
@@ -1777,7 +1799,7 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
     double* peak_words = a.partial + (size_t)a.divisions * a.chunks;     // [total], behind round 0's partials
     const float* final_peaks = a.final_peaks;
     TAIL_STAMP(2);
-    if (threadIdx.x == 0) gain_now = bits_double(poll_word(a.tail_gains + TAIL_GAIN0, a.error, double_bits(1.0)));
+    if (threadIdx.x == 0) gain_now = bits_double(poll_word(a.tail_gains + a.tail_rounds, a.error, double_bits(1.0)));
     __syncthreads();
     double g = gain_now;                                                 // round 0's, from the deciding workgroup
     for (int r = 0; r < rounds; ++r) {
@@ -1815,7 +1837,7 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
         // all-ones pattern round 0 left there); the deciding workgroup polls the words, one lane per word.  An
         // arrival counter cost each round the publisher's wait for its store, the atomic's round trip (a hundred
         // of them on one word take a microsecond) and the last arriver's read of the partials.
-        unsigned long long* words = a.tail_gains + 16 + (size_t)r * total;
+        unsigned long long* words = a.tail_gains + a.tail_rounds + 1 + (size_t)r * total;
         const bool last_round = r == rounds - 1;
         if (threadIdx.x == 0) {
             if (last_round && final_peaks) {                             // the peak word first, and landed

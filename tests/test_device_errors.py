@@ -76,3 +76,95 @@ def test_an_expired_lookback_fails_the_next_synchronize_without_a_report():
     assert done.returncode == 0, done.stderr[-2000:]
     assert "raised 0" in done.stdout and "raised 1" in done.stdout, done.stdout + done.stderr[-2000:]
     assert "peak True" in done.stdout
+
+
+# ---- the level-correction tail on a shared GPU ------------------------------------
+# k_correction_tail's <= 129 workgroups spin on each other's flag words, so all of them must be resident; under
+# contention from another process's kernels the bounded polls expire.  That is not a lost word: the call is
+# queued again with one launch per round (no workgroup waits for another) and SUCCEEDS, and the handle stays in
+# that mode.  Forced with a second test build: -DMGX_TEST_TAIL_EXPIRE (the first tail of the process never hears
+# of round 0's gain) -DMGX_TEST_TAIL_MAX_SPINS=64 (its workgroups give up after 64 polls).
+TAIL_VARIANT = os.path.join(ROOT, "matchering_amd", "libmgx_tailexpire.so")
+TAIL_FLAGS = ("-DMGX_TEST_TAIL_EXPIRE", "-DMGX_TEST_TAIL_MAX_SPINS=64")
+
+TAIL_CHILD = r"""
+import sys
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r} + "/oracle")
+import numpy as np
+import mastering_oracle as mo
+import matchering_amd as mg
+from matchering_amd._native import library
+from matchering_amd.device import Device
+from matchering_amd.synth import make_pair
+
+target, reference = make_pair(20.0, 44100, pair=3)
+want = mo.master(target, reference, mo.params(), True, False, False)[0]
+dev = Device(0)
+native = mg.Config().to_native()
+t, r = dev.upload(target), dev.upload(reference)
+out = dev.alloc(target.shape[0] * 8)
+for attempt, with_report in enumerate((False, True, False)):
+    report = dev.master(t, target.shape[0], r, reference.shape[0], native, result=out, want_report=with_report)
+    dev.synchronize()                          # attempt 0: the tail expires, the call is queued again, no error
+    note = library().mgx_last_error().decode()
+    got = dev.download(out, target.shape).astype(np.float64)
+    rms = float(np.sqrt(np.mean((got - want) ** 2)))
+    print("attempt", attempt, "rms_ok", rms <= 1e-5, "note", "not resident together" in note,
+          "coeffs", None if report is None else [round(c, 9) for c in report.correction_coefficients[:4]])
+"""
+
+
+def test_the_tail_test_build_is_not_the_product():
+    sys.path.insert(0, ROOT)
+    from matchering_amd import build as native_build
+
+    assert native_build.source_hash() != native_build.source_hash(TAIL_FLAGS)
+    with open(os.path.join(ROOT, "matchering_amd", "csrc", "mgx_kernels.h")) as fh:
+        text = fh.read()
+    assert "#ifdef MGX_TEST_TAIL_EXPIRE" in text and "#ifdef MGX_TEST_TAIL_MAX_SPINS" in text
+
+
+@pytest.mark.gpu
+def test_an_expired_tail_is_run_again_round_by_round_and_succeeds():
+    sys.path.insert(0, ROOT)
+    from matchering_amd import build as native_build
+
+    lib = native_build.build(out=TAIL_VARIANT, extra_flags=TAIL_FLAGS)
+    done = subprocess.run([sys.executable, "-c", TAIL_CHILD.format(root=ROOT)], env=dict(os.environ, MGX_LIB=lib),
+                          capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("attempt")]
+    assert len(lines) == 3, done.stdout + done.stderr[-2000:]
+    assert all("rms_ok True" in ln for ln in lines), done.stdout            # right audio every time, the first included
+    assert "note True" in lines[0]                                           # ... which says how it got there
+    assert "coeffs [" in lines[1] and "coeffs None" in lines[2]
+
+
+@pytest.mark.gpu
+def test_one_launch_per_round_equals_the_tail_kernel():
+    """MGX_NO_TAIL=1 (the mode a handle falls back to) against the resident tail kernel: the same coefficients."""
+    child = r'''
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import matchering_amd as mg
+from matchering_amd.device import Device
+from matchering_amd.synth import make_pair
+target, reference = make_pair(30.0, 44100, pair=5)
+dev = Device(0)
+native = mg.Config(rms_correction_steps=6).to_native()
+t, r = dev.upload(target), dev.upload(reference)
+out = dev.alloc(target.shape[0] * 8)
+rep = dev.master(t, target.shape[0], r, reference.shape[0], native, result=out)
+print("C", " ".join(repr(c) for c in rep.correction_coefficients[:6]), float(np.abs(dev.download(out, target.shape)).sum()))
+'''.format(root=ROOT)
+    outs = []
+    for flag in ("0", "1"):
+        done = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, MGX_NO_TAIL=flag), capture_output=True,
+                              text=True, timeout=600)
+        assert done.returncode == 0, done.stderr[-2000:]
+        outs.append([float(v) for v in done.stdout.split("C", 1)[1].split()])
+    a, b = outs
+    assert len(a) == 7 and all(abs(x / y - 1.0) <= 1e-12 for x, y in zip(a[:6], b[:6]))
+    assert abs(a[6] / b[6] - 1.0) <= 1e-6
