@@ -328,6 +328,12 @@ def main():
 
 
 def run(args, ranks):
+    # ONE line on standard output, and nothing else: RCCL prints a version banner there when a communicator is
+    # created (through C stdio, flushed at exit -- i.e. AFTER the line).  The line goes to a private copy of the
+    # descriptor; descriptor 1 itself is pointed at standard error for the rest of the process.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     line = {
         "metric": "stereo Msamples/s mastered (44.1 kHz pairs); % HBM roofline @1/2/4/8 GPU",
         "unit": "Msamples/s", "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup,
@@ -499,7 +505,7 @@ def run(args, ranks):
                               "against": "oracle/mastering_oracle.py (float64) on the workload's first pair; the "
                                          "GPU result is the one the last timed step left in HBM"}
     if ranks.rank == 0:
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=line_out, flush=True)
     if stuck:                       # (a rank still inside the collective would keep the others' teardown waiting)
         os._exit(0)
 
