@@ -1304,7 +1304,9 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
         ra.mid = (const float*)h->mid.p;
         ra.piece = tw.piece;
         ra.divisions = tw.divisions;
-        ra.chunks = std::max(1, 1024 / tw.divisions);        // ~1000 workgroups: each pays one publish + ticket
+        int round_wgs = 1024;                                 // ~1000 workgroups: each pays one publish + ticket
+        if (const char* v = std::getenv("MGX_ROUND_WGS")) round_wgs = std::max(64, std::atoi(v));   // measurement aid
+        ra.chunks = std::max(1, round_wgs / tw.divisions);
         // (round 0's partial sums, and behind them the peak words of k_correction_tail's workgroups)
         MGX_TRY(ensure(h, h->partial, (size_t)2 * ra.divisions * ra.chunks * sizeof(double)));
         ra.partial = (double*)h->partial.p;

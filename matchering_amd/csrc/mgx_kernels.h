@@ -343,12 +343,25 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
     __syncthreads();
     int s0, s1;
     AB::chunk_segments(a, ch, s0, s1);
+#ifdef MGX_ANALYZE_PREFETCH
+    // The next segment's frames are asked for as soon as this one's have gone into the first pass and wait in registers
+    // through its four LDS barriers (lds_barrier leaves global loads in flight).  At four workgroups per CU (128 VGPRs) the 32
+    // registers that pins spilled (round 1); built with MGX_ANALYZE_MAX_WGS=3 (168 VGPRs) they fit, and a CU then has
+    // three segments of loads in flight ALL the time instead of four for a quarter of it.
+    typename AB::Raw raw;
+    if (s0 < s1) AB::fetch(tid, (long long)d * a.piece + (long long)s0 * F::N, a, raw);
+#endif
     for (int s = s0; s < s1; ++s) {
+#ifdef MGX_ANALYZE_PREFETCH
+        AB::phase_load(tid, raw, ps, th, lds);                   // (consumes `raw`: its registers take the next segment)
+        if (s + 1 < s1) AB::fetch(tid, (long long)d * a.piece + (long long)(s + 1) * F::N, a, raw);
+#else
         // (a software prefetch of the next segment was tried: at 128 VGPRs the 32 registers it pins
         // spill, which stalls on the very loads it was meant to hide)
         typename AB::Raw raw;
         AB::fetch(tid, (long long)d * a.piece + (long long)s * F::N, a, raw);
         AB::phase_load(tid, raw, ps, th, lds);
+#endif
         lds_barrier();
         if (F::P == 3) {
             AB::phase_fwd_mid(tid, lds, mid_table);
@@ -1985,6 +1998,66 @@ __global__ __launch_bounds__(256) void k_frame_peaks(const float2* x, long long 
 // wave by shuffles (scan order = lane order, or reversed), wave totals through LDS, then every
 // thread composes the totals of the waves before it.  Returns the composition of all maps BEFORE
 // this thread in scan order; `*whole` (if wanted) the composition of everything.
+#ifdef MGX_DPP_SCAN
+// The same two scans on DPP lane shifts and scalar row totals instead of ds_bpermute shuffles: four row_shr / row_shl
+// steps compose inside each row of 16 lanes (a lane without a source keeps the identity), the three row totals that
+// matter are read into scalars (v_readlane) and composed once, every row takes the composition of the rows before
+// it.  A double moves as two 32-bit DPP moves.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double keep, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ Affine readlane_affine(Affine m, int lane) { return Affine{readlane_f64(m.a, lane), readlane_f64(m.b, lane)}; }
+template <bool REVERSE, int D>
+__device__ __forceinline__ Affine row_step(Affine m) {
+    constexpr int CTRL = (REVERSE ? 0x100 : 0x110) + D;          // row_shl:D takes from lane + D, row_shr:D from lane - D
+    const Affine o{dpp_f64<CTRL>(1.0, m.a), dpp_f64<CTRL>(0.0, m.b)};
+    return affine_then(o, m);
+}
+// composition of the rows before this lane's row in scan order, from the row totals of an in-row inclusive scan
+template <bool REVERSE>
+__device__ __forceinline__ Affine rows_before(Affine in_row) {
+    const int row = (threadIdx.x & 63) >> 4;
+    // scan order of the rows: 0 1 2 3 forward, 3 2 1 0 reversed; total of a row sits in its last lane in scan order
+    const Affine t0 = readlane_affine(in_row, REVERSE ? 48 : 15), t1 = readlane_affine(in_row, REVERSE ? 32 : 31),
+                 t2 = readlane_affine(in_row, REVERSE ? 16 : 47);
+    const Affine p2 = affine_then(t0, t1), p3 = affine_then(p2, t2);
+    const int k = REVERSE ? 3 - row : row;                       // rows before this one
+    Affine p = affine_identity();
+    if (k == 1) p = t0;
+    if (k == 2) p = p2;
+    if (k == 3) p = p3;
+    return p;
+}
+template <bool REVERSE>
+__device__ __forceinline__ Affine wave_inclusive(Affine m) {
+    m = row_step<REVERSE, 1>(m);
+    m = row_step<REVERSE, 2>(m);
+    m = row_step<REVERSE, 4>(m);
+    m = row_step<REVERSE, 8>(m);
+    return affine_then(rows_before<REVERSE>(m), m);
+}
+template <bool REVERSE>
+__device__ __forceinline__ Affine wave_exclusive(Affine inclusive) {
+    // the neighbour's inclusive value; the first lane of a row takes the last lane of the row before it, the very
+    // first lane the identity
+    const int row = (threadIdx.x & 63) >> 4;
+    const Affine e0 = readlane_affine(inclusive, REVERSE ? 48 : 15), e1 = readlane_affine(inclusive, REVERSE ? 32 : 31),
+                 e2 = readlane_affine(inclusive, REVERSE ? 16 : 47);
+    const int k = REVERSE ? 3 - row : row;
+    Affine keep = affine_identity();
+    if (k == 1) keep = e0;
+    if (k == 2) keep = e1;
+    if (k == 3) keep = e2;
+    constexpr int CTRL = (REVERSE ? 0x100 : 0x110) + 1;
+    return Affine{dpp_f64<CTRL>(keep.a, inclusive.a), dpp_f64<CTRL>(keep.b, inclusive.b)};
+}
+#else
 template <bool REVERSE>
 __device__ __forceinline__ Affine wave_inclusive(Affine m) {
     const int lane = threadIdx.x & 63;
@@ -2007,6 +2080,7 @@ __device__ __forceinline__ Affine wave_exclusive(Affine inclusive) {
     const bool first = REVERSE ? lane == 63 : lane == 0;
     return first ? affine_identity() : o;
 }
+#endif
 // totals[w] = inclusive total of wave w (written by the caller before the barrier)
 template <bool REVERSE, int WAVES>
 __device__ __forceinline__ Affine compose_waves(const Affine* totals, Affine exclusive_in_wave, Affine* whole) {

@@ -9,10 +9,10 @@ sys.path.insert(0, ROOT)
 from matchering_amd import build as b
 
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-fno-slp-vectorize",
-       "-Rpass-analysis=kernel-resource-usage", "-Wno-unused-value", "-o", "/tmp/libmgx_res.so"] + b.SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-lrocprofiler-sdk-roctx"]
+       "-Rpass-analysis=kernel-resource-usage", "-Wno-unused-value", *[a for a in sys.argv[1:] if a.startswith("-D")], "-o", "/tmp/libmgx_res.so"] + b.SOURCES + ["-L/opt/rocm/lib", "-lrccl", "-lrocprofiler-sdk-roctx"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = {}
-want = sys.argv[1:] or [""]
+want = [a for a in sys.argv[1:] if not a.startswith("-D")] or [""]
 for line in out.splitlines():
     m = re.search(r"remark:\s+(.*?) \[-Rpass", line)
     if not m:
