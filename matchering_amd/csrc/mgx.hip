@@ -116,6 +116,11 @@ static void code_sizes_from_library(int (&bytes)[CODE_KERNELS][CODE_VARIANTS]) {
         for (size_t k = 0; k < count; ++k) {
             if (ELF64_ST_TYPE(sym[k].st_info) != STT_FUNC || sym[k].st_size == 0) continue;
             const char* name = str + sym[k].st_name;
+            if (std::strstr(name, "k_limit_persistentILi")) {             // variant 2 of the limiter family
+                int& slot = bytes[CODE_LIMIT][2];
+                if (slot == 0 || (int)sym[k].st_size < slot) slot = (int)sym[k].st_size;
+                continue;
+            }
             for (int c = 0; c < CODE_KERNELS; ++c) {
                 const char* hit = std::strstr(name, CODE_NAMES[c]);
                 if (!hit) continue;
@@ -749,9 +754,21 @@ static int launch_limiter_general(mgx_handle* h, const LimiterArgs& a, const Lim
     return 0;
 }
 
-// 256-block chunks (four workgroups per CU) unless the configured attack / hold times need 1024
+// 256-block chunks (four workgroups per CU, a persistent grid that fetches a workgroup's next chunk under its current
+// one) unless the configured attack / hold times need 1024
 static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
     const dim3 grid((unsigned)a.nchunks);
+    const char* oneshot = std::getenv("MGX_LIMIT_ONESHOT");          // measurement aid: one workgroup per chunk (round 3)
+    if (threads == 256 && !(oneshot && oneshot[0] == '1')) {
+        int dev_cus = 256;
+        HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        const size_t lds = LimiterBlock<256>::LDS_BYTES_TWO;
+        MGX_TRY((allow_lds(k_limit_persistent<256, 4>, lds)));
+        const unsigned resident = (unsigned)std::min<long long>(a.nchunks, 4ll * dev_cus);
+        hipLaunchKernelGGL((k_limit_persistent<256, 4>), dim3(resident), dim3(256), lds, h->stream, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (threads == 1024) {
         const size_t lds = LimiterBlock<1024>::LDS_BYTES;
         MGX_TRY((allow_lds(k_limit<1024, 1>, lds)));
@@ -1316,7 +1333,9 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
         const size_t ctr_bytes = (size_t)(1 + ra.divisions) * sizeof(unsigned);
         // at most ~128 workgroups in k_correction_tail, at most 64 chunks (the lanes of a wave) per workgroup
         const int tail_groups = std::max((ra.chunks + 63) / 64, std::max(1, std::min(ra.chunks, 128 / ra.divisions)));
-        const bool use_tail = cfg->rms_correction_steps > 1 && !h->avoid_tail;
+        // (MGX_NO_TAIL=1: measurement aid, one launch per correction round for this call)
+        const char* no_tail = std::getenv("MGX_NO_TAIL");
+        const bool use_tail = cfg->rms_correction_steps > 1 && !h->avoid_tail && !(no_tail && no_tail[0] == '1');
         const int tail_total = use_tail ? ra.divisions * tail_groups : 0;
         const int tail_rounds = use_tail ? cfg->rms_correction_steps - 1 : 0;
         MGX_TRY(ensure(h, h->tail_gains, ((size_t)tail_rounds + 1 + (size_t)tail_rounds * tail_total) * sizeof(unsigned long long)));
@@ -1435,8 +1454,6 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
     call.out[0] = result_dev;
     call.out[1] = result_no_limiter_dev;
     call.out[2] = result_no_limiter_normalized_dev;
-    if (const char* v = std::getenv("MGX_NO_TAIL"))           // measurement aid: one launch per correction round
-        if (v[0] == '1') h->avoid_tail = true;
     MGX_TRY(queue_master(h, call));
     call.valid = true;
     TrackWork& tw = h->track[0];
