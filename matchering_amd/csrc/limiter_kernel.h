@@ -153,9 +153,6 @@ struct LimiterBlock {
     static constexpr int TOTALS_FLOATS = 4 * WAVES * 4;                 // four scans x WAVES Affine
     static constexpr int MISC_FLOATS = 16 + TOTALS_FLOATS + 16;        // edge sl[14] | totals | scalars
     static constexpr size_t LDS_BYTES = (size_t)(MISC_OFF + MISC_FLOATS) * 4 + 16;
-    // the persistent kernel keeps two of these side by side: the chunk in work and the one being fetched
-    static constexpr int BUFFER_FLOATS = (int)((LDS_BYTES + 15) / 16 * 4);
-    static constexpr size_t LDS_BYTES_TWO = (size_t)2 * BUFFER_FLOATS * 4;
 
     static MGX_HD float* plane(float* lds) { return lds; }
     static MGX_HD float* block_max(float* lds) { return lds + BM_OFF; }
@@ -249,18 +246,15 @@ struct LimiterBlock {
         }
     }
     static MGX_HD int block_of(int tid, int j) { return (tid >> 3) + (T / 8) * j; }
-    // the same for a chunk inside the track, in two halves: the frames are asked for (`phase_fetch_full`) and turned
-    // into hard-clip gains later (`phase_g0_full`).  The persistent kernel puts a whole phase of another chunk between
-    // the two: the NEXT chunk's frames travel while this chunk's attack smoother runs (mgx_kernels.h, k_limit).
+    // the same for a chunk inside the track, keeping the frames: a quiet chunk (below) stores from them
     struct Reload { float4 q[E / 2]; };
-    static MGX_HD void phase_fetch_full(int tid, long long chunk, const LimiterArgs& a, Reload& kept) {
+    static MGX_HD void phase_load_full(int tid, long long chunk, const LimiterArgs& a, float* lds, float (&pm)[E / 2],
+                                       Reload& kept) {
         const float2* y = a.y + region_start(chunk, a) + 2 * tid;
-        MGX_UNROLL
-        for (int j = 0; j < E / 2; ++j) kept.q[j] = *reinterpret_cast<const float4*>(y + 2 * T * j);
-    }
-    static MGX_HD void phase_g0_full(int tid, const LimiterArgs& a, float* lds, float (&pm)[E / 2], const Reload& kept) {
         const float g = (float)*a.gain;
         float* gp = plane(lds);
+        MGX_UNROLL
+        for (int j = 0; j < E / 2; ++j) kept.q[j] = *reinterpret_cast<const float4*>(y + 2 * T * j);
         MGX_UNROLL
         for (int j = 0; j < E / 2; ++j) {
             const int i = 2 * tid + 2 * T * j;
@@ -271,11 +265,6 @@ struct LimiterBlock {
             gp[gidx(i + 1)] = g1;
             pm[j] = fmaxf(g0, g1);
         }
-    }
-    static MGX_HD void phase_load_full(int tid, long long chunk, const LimiterArgs& a, float* lds, float (&pm)[E / 2],
-                                       Reload& kept) {
-        phase_fetch_full(tid, chunk, a, kept);
-        phase_g0_full(tid, a, lds, pm, kept);
     }
 
     // ---- window maxima from the raw plane -----------------------------------------------------------

@@ -116,11 +116,6 @@ static void code_sizes_from_library(int (&bytes)[CODE_KERNELS][CODE_VARIANTS]) {
         for (size_t k = 0; k < count; ++k) {
             if (ELF64_ST_TYPE(sym[k].st_info) != STT_FUNC || sym[k].st_size == 0) continue;
             const char* name = str + sym[k].st_name;
-            if (std::strstr(name, "k_limit_persistentILi")) {             // variant 2 of the limiter family
-                int& slot = bytes[CODE_LIMIT][2];
-                if (slot == 0 || (int)sym[k].st_size < slot) slot = (int)sym[k].st_size;
-                continue;
-            }
             for (int c = 0; c < CODE_KERNELS; ++c) {
                 const char* hit = std::strstr(name, CODE_NAMES[c]);
                 if (!hit) continue;
@@ -754,21 +749,11 @@ static int launch_limiter_general(mgx_handle* h, const LimiterArgs& a, const Lim
     return 0;
 }
 
-// 256-block chunks (four workgroups per CU, a persistent grid that fetches a workgroup's next chunk under its current
-// one) unless the configured attack / hold times need 1024
+// 256-block chunks (four workgroups per CU) unless the configured attack / hold times need 1024
+// (a persistent grid that fetches a workgroup's next chunk under its current one was built and measured in round 4:
+// 187 against 171 us, profiles/r04_c_persistent_limiter.txt)
 static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
     const dim3 grid((unsigned)a.nchunks);
-    const char* oneshot = std::getenv("MGX_LIMIT_ONESHOT");          // measurement aid: one workgroup per chunk (round 3)
-    if (threads == 256 && !(oneshot && oneshot[0] == '1')) {
-        int dev_cus = 256;
-        HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device));
-        const size_t lds = LimiterBlock<256>::LDS_BYTES_TWO;
-        MGX_TRY((allow_lds(k_limit_persistent<256, 4>, lds)));
-        const unsigned resident = (unsigned)std::min<long long>(a.nchunks, 4ll * dev_cus);
-        hipLaunchKernelGGL((k_limit_persistent<256, 4>), dim3(resident), dim3(256), lds, h->stream, a);
-        HIP_TRY(hipGetLastError());
-        return 0;
-    }
     if (threads == 1024) {
         const size_t lds = LimiterBlock<1024>::LDS_BYTES;
         MGX_TRY((allow_lds(k_limit<1024, 1>, lds)));
@@ -1321,9 +1306,7 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
         ra.mid = (const float*)h->mid.p;
         ra.piece = tw.piece;
         ra.divisions = tw.divisions;
-        int round_wgs = 1024;                                 // ~1000 workgroups: each pays one publish + ticket
-        if (const char* v = std::getenv("MGX_ROUND_WGS")) round_wgs = std::max(64, std::atoi(v));   // measurement aid
-        ra.chunks = std::max(1, round_wgs / tw.divisions);
+        ra.chunks = std::max(1, 1024 / tw.divisions);        // ~1000 workgroups: each pays one publish + ticket
         // (round 0's partial sums, and behind them the peak words of k_correction_tail's workgroups)
         MGX_TRY(ensure(h, h->partial, (size_t)2 * ra.divisions * ra.chunks * sizeof(double)));
         ra.partial = (double*)h->partial.p;

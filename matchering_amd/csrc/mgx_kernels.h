@@ -343,25 +343,14 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
     __syncthreads();
     int s0, s1;
     AB::chunk_segments(a, ch, s0, s1);
-#ifdef MGX_ANALYZE_PREFETCH
-    // The next segment's frames are asked for as soon as this one's have gone into the first pass and wait in registers
-    // through its four LDS barriers (lds_barrier leaves global loads in flight).  At four workgroups per CU (128 VGPRs) the 32
-    // registers that pins spilled (round 1); built with MGX_ANALYZE_MAX_WGS=3 (168 VGPRs) they fit, and a CU then has
-    // three segments of loads in flight ALL the time instead of four for a quarter of it.
-    typename AB::Raw raw;
-    if (s0 < s1) AB::fetch(tid, (long long)d * a.piece + (long long)s0 * F::N, a, raw);
-#endif
     for (int s = s0; s < s1; ++s) {
-#ifdef MGX_ANALYZE_PREFETCH
-        AB::phase_load(tid, raw, ps, th, lds);                   // (consumes `raw`: its registers take the next segment)
-        if (s + 1 < s1) AB::fetch(tid, (long long)d * a.piece + (long long)(s + 1) * F::N, a, raw);
-#else
-        // (a software prefetch of the next segment was tried: at 128 VGPRs the 32 registers it pins
-        // spill, which stalls on the very loads it was meant to hide)
+        // (A software prefetch of the next segment: at 128 VGPRs the 32 registers it pins spill, 152 us; at three
+        // workgroups per CU and 168 VGPRs it fits without scratch and changes nothing -- 100 us with and without it,
+        // against 92 us for four workgroups without: the kernel is bound by what a CU's LDS and VALU pipes get
+        // through per segment, not by the latency of its loads.  profiles/r04_b_ab_variants.txt)
         typename AB::Raw raw;
         AB::fetch(tid, (long long)d * a.piece + (long long)s * F::N, a, raw);
         AB::phase_load(tid, raw, ps, th, lds);
-#endif
         lds_barrier();
         if (F::P == 3) {
             AB::phase_fwd_mid(tid, lds, mid_table);
@@ -1998,69 +1987,9 @@ __global__ __launch_bounds__(256) void k_frame_peaks(const float2* x, long long 
 // wave by shuffles (scan order = lane order, or reversed), wave totals through LDS, then every
 // thread composes the totals of the waves before it.  Returns the composition of all maps BEFORE
 // this thread in scan order; `*whole` (if wanted) the composition of everything.
-#ifdef MGX_DPP_SCAN
-// The same two scans on DPP lane shifts and scalar row totals instead of ds_bpermute shuffles: four row_shr / row_shl
-// steps compose inside each row of 16 lanes (a lane without a source keeps the identity), the three row totals that
-// matter are read into scalars (v_readlane) and composed once, every row takes the composition of the rows before
-// it.  A double moves as two 32-bit DPP moves.
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double keep, double v) {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(v), CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(v), CTRL, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-__device__ __forceinline__ Affine readlane_affine(Affine m, int lane) { return Affine{readlane_f64(m.a, lane), readlane_f64(m.b, lane)}; }
-template <bool REVERSE, int D>
-__device__ __forceinline__ Affine row_step(Affine m) {
-    constexpr int CTRL = (REVERSE ? 0x100 : 0x110) + D;          // row_shl:D takes from lane + D, row_shr:D from lane - D
-    const Affine o{dpp_f64<CTRL>(1.0, m.a), dpp_f64<CTRL>(0.0, m.b)};
-    return affine_then(o, m);
-}
-// composition of the rows before this lane's row in scan order, from the row totals of an in-row inclusive scan
-template <bool REVERSE>
-__device__ __forceinline__ Affine rows_before(Affine in_row) {
-    const int row = (opaque((int)threadIdx.x) & 63) >> 4;
-    // scan order of the rows: 0 1 2 3 forward, 3 2 1 0 reversed; total of a row sits in its last lane in scan order
-    const Affine t0 = readlane_affine(in_row, REVERSE ? 48 : 15), t1 = readlane_affine(in_row, REVERSE ? 32 : 31),
-                 t2 = readlane_affine(in_row, REVERSE ? 16 : 47);
-    const Affine p2 = affine_then(t0, t1), p3 = affine_then(p2, t2);
-    const int k = REVERSE ? 3 - row : row;                       // rows before this one
-    Affine p = affine_identity();
-    if (k == 1) p = t0;
-    if (k == 2) p = p2;
-    if (k == 3) p = p3;
-    return p;
-}
 template <bool REVERSE>
 __device__ __forceinline__ Affine wave_inclusive(Affine m) {
-    m = row_step<REVERSE, 1>(m);
-    m = row_step<REVERSE, 2>(m);
-    m = row_step<REVERSE, 4>(m);
-    m = row_step<REVERSE, 8>(m);
-    return affine_then(rows_before<REVERSE>(m), m);
-}
-template <bool REVERSE>
-__device__ __forceinline__ Affine wave_exclusive(Affine inclusive) {
-    // the neighbour's inclusive value; the first lane of a row takes the last lane of the row before it, the very
-    // first lane the identity
-    const int row = (opaque((int)threadIdx.x) & 63) >> 4;
-    const Affine e0 = readlane_affine(inclusive, REVERSE ? 48 : 15), e1 = readlane_affine(inclusive, REVERSE ? 32 : 31),
-                 e2 = readlane_affine(inclusive, REVERSE ? 16 : 47);
-    const int k = REVERSE ? 3 - row : row;
-    Affine keep = affine_identity();
-    if (k == 1) keep = e0;
-    if (k == 2) keep = e1;
-    if (k == 3) keep = e2;
-    constexpr int CTRL = (REVERSE ? 0x100 : 0x110) + 1;
-    return Affine{dpp_f64<CTRL>(keep.a, inclusive.a), dpp_f64<CTRL>(keep.b, inclusive.b)};
-}
-#else
-template <bool REVERSE>
-__device__ __forceinline__ Affine wave_inclusive(Affine m) {
-    const int lane = opaque((int)threadIdx.x) & 63;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         Affine o;
@@ -2073,18 +2002,17 @@ __device__ __forceinline__ Affine wave_inclusive(Affine m) {
 }
 template <bool REVERSE>
 __device__ __forceinline__ Affine wave_exclusive(Affine inclusive) {
-    const int lane = opaque((int)threadIdx.x) & 63;
+    const int lane = threadIdx.x & 63;
     Affine o;
     o.a = REVERSE ? __shfl_down(inclusive.a, 1, 64) : __shfl_up(inclusive.a, 1, 64);
     o.b = REVERSE ? __shfl_down(inclusive.b, 1, 64) : __shfl_up(inclusive.b, 1, 64);
     const bool first = REVERSE ? lane == 63 : lane == 0;
     return first ? affine_identity() : o;
 }
-#endif
 // totals[w] = inclusive total of wave w (written by the caller before the barrier)
 template <bool REVERSE, int WAVES>
 __device__ __forceinline__ Affine compose_waves(const Affine* totals, Affine exclusive_in_wave, Affine* whole) {
-    const int w = opaque((int)threadIdx.x) >> 6;
+    const int w = threadIdx.x >> 6;
     Affine before = affine_identity(), all = affine_identity();
 #pragma unroll
     for (int i = 0; i < WAVES; ++i) {
@@ -2121,41 +2049,10 @@ __device__ unsigned mgx_dev_phase_ticks[DEV_PHASE_CHUNKS][16];       // [chunk][
 #else
 #define DEV_MARK(k)
 #endif
-// The chunk a persistent workgroup will run next: its frames are asked for at the top of the current chunk, travel
-// while the hold windows are formed (few registers are live there), and become hard-clip gains, block maxima and one
-// busy flag per wave in the workgroup's OTHER buffer once the current chunk's hold word is out (limiter_kernel.h,
-// phase_fetch_full / phase_g0_full).
-struct NextChunk {
-    long long chunk;
-    float* lds;          // the other buffer
-    int* after;          // LDS word that receives the ticket of the chunk after the next one (drawn under the release take)
-    bool on;             // uniform: there is a next chunk and it lies strictly inside the track
-};
-// block maxima (eight neighbouring lanes hold one block) and the wave's "any frame above the threshold" flag
-template <int T>
-__device__ __forceinline__ void store_block_maxima(float* lds, const float (&pm)[LimiterBlock<T>::E / 2]) {
-    using LB = LimiterBlock<T>;
-    const int tid = opaque((int)threadIdx.x);
-    float mine = 0.f;
-#pragma unroll
-    for (int j = 0; j < LB::E / 2; ++j) {
-        mine = fmaxf(mine, pm[j]);
-        const float m = dpp_max8(pm[j]);
-        if ((tid & 7) == 0) LB::block_max(lds)[LB::block_of(tid, j)] = m;
-    }
-    const bool wave_busy = __any(mine > 0.f) != 0;
-    if ((tid & 63) == 0) LB::edge_sl(lds)[tid >> 6] = wave_busy ? 1.f : 0.f;   // (16 floats; the track's ends use them, not these chunks)
-}
-template <int T>
-__device__ __forceinline__ void next_chunk_gains(const LimiterArgs& a, const NextChunk& nx, const typename LimiterBlock<T>::Reload& q) {
-    float pm[LimiterBlock<T>::E / 2];
-    LimiterBlock<T>::phase_g0_full(opaque((int)threadIdx.x), a, nx.lds, pm, q);
-    store_block_maxima<T>(nx.lds, pm);
-}
-
+// one chunk, from the load phase to the store; FULL = the chunk lies strictly inside the track
 // one chunk, from the load phase to the store; FULL = the chunk lies strictly inside the track
 template <int T, bool FULL>
-__device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chunk, float* lds, const NextChunk* nx = nullptr) {
+__device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chunk, float* lds) {
     using LB = LimiterBlock<T>;
     // (opaque: nothing derived from the thread id may be hoisted out of a persistent caller's loop)
     const int tid = opaque((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
@@ -2174,8 +2071,6 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
         __syncthreads();
     }
     DEV_MARK(0);      // load
-    typename LB::Reload ahead;                                   // the next chunk's frames, in flight through the hold windows
-    if (FULL && nx && nx->on) LB::phase_fetch_full(opaque(tid), nx->chunk, a, ahead);
 
     // hold filter first (scan 1): its aggregate is published as early as possible
     typename LB::Thread th;
@@ -2194,7 +2089,6 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     // ask for the predecessors' words now, take them after the attack path (wave 0: hold, wave 1: attack)
     typename LB::Polls polls;
     if (wave == 0) LB::lookback_ask(lane, chunk, 0, a, polls);
-    if (FULL && nx && nx->on) next_chunk_gains<T>(a, *nx, ahead);
     // forward attack smoother (scan 0)
     Affine p0;
     {
@@ -2252,7 +2146,6 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     if (wave == 0) LB::lookback_ask(lane, chunk, 1, a, polls);
     typename LB::Reload again;
     if (FULL) LB::phase_reload(opaque(tid), chunk, a, again);
-    if (FULL && nx && tid == 64) *nx->after = atomicAdd(a.ticket, 1);   // (wave 1: wave 0 is about to poll)
     DEV_MARK(7);      // publish, ask, reload issue
     if (wave == 0) {
         const double s = wave_sum(LB::lookback_take(lane, chunk, 1, a, polls));
@@ -2301,45 +2194,6 @@ __device__ __forceinline__ void limit_chunk_quiet(const LimiterArgs& a, long lon
     }
     __syncthreads();
     LB::phase_quiet_store(tid, chunk, a, kept, hc, ac, LB::scalars(lds)[1]);
-}
-
-// The same inside the persistent kernel: the chunk's gains came from the previous iteration's fetch, so its frames are
-// read again here (from the L2 / Infinity Cache: the fetch was a chunk time ago), under the look-backs, together with
-// the next chunk's.
-template <int T>
-__device__ __forceinline__ void limit_chunk_quiet_ahead(const LimiterArgs& a, long long chunk, float* lds, const NextChunk& nx) {
-    using LB = LimiterBlock<T>;
-    const int tid = opaque((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) {
-        LB::lookback_publish(chunk, 0, a, 0.0);
-        LB::lookback_publish(chunk, 2, a, 0.0);
-    }
-    typename LB::Reload again, ahead;
-    LB::phase_reload(opaque(tid), chunk, a, again);
-    if (nx.on) LB::phase_fetch_full(opaque(tid), nx.chunk, a, ahead);
-    typename LB::Polls polls;
-    if (wave == 0) {
-        LB::lookback_ask(lane, chunk, 0, a, polls);
-        const double s = wave_sum(LB::lookback_take(lane, chunk, 0, a, polls));
-        if (lane == 0) LB::scalars(lds)[0] = s;
-    }
-    if (wave == 1) {
-        LB::lookback_ask(lane, chunk, 2, a, polls);
-        const double s = wave_sum(LB::lookback_take(lane, chunk, 2, a, polls));
-        if (lane == 0) LB::scalars(lds)[2] = s;
-    }
-    __syncthreads();
-    const double hc = LB::scalars(lds)[0], ac = LB::scalars(lds)[2];
-    if (tid == 0) LB::lookback_publish(chunk, 1, a, hc * a.quiet_rel_gain);
-    if (wave == 0) LB::lookback_ask(lane, chunk, 1, a, polls);
-    if (tid == 64) *nx.after = atomicAdd(a.ticket, 1);
-    if (nx.on) next_chunk_gains<T>(a, nx, ahead);
-    if (wave == 0) {
-        const double s = wave_sum(LB::lookback_take(lane, chunk, 1, a, polls));
-        if (lane == 0) LB::scalars(lds)[1] = s;
-    }
-    __syncthreads();
-    LB::phase_quiet_store(tid, chunk, a, again, hc, ac, LB::scalars(lds)[1]);
 }
 
 // ---- PCM at the boundary (loader.py:35 / saver.py:27-33: what soundfile does on the host) ------------
@@ -2615,7 +2469,15 @@ __global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a) {
     {
         float pm[LB::E / 2];
         LB::phase_load_full(opaque(tid), chunk, a, lds, pm, kept);
-        store_block_maxima<T>(lds, pm);
+        float mine = 0.f;
+#pragma unroll
+        for (int j = 0; j < LB::E / 2; ++j) {
+            mine = fmaxf(mine, pm[j]);
+            const float m = dpp_max8(pm[j]);
+            if ((tid & 7) == 0) LB::block_max(lds)[LB::block_of(tid, j)] = m;
+        }
+        const bool wave_busy = __any(mine > 0.f) != 0;
+        if ((tid & 63) == 0) LB::edge_sl(lds)[tid >> 6] = wave_busy ? 1.f : 0.f;   // (16 floats; the track's ends use them, not these chunks)
     }
     __syncthreads();
     bool chunk_busy = false;
@@ -2623,97 +2485,6 @@ __global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a) {
     for (int w = 0; w < LB::WAVES; ++w) chunk_busy = chunk_busy || LB::edge_sl(lds)[w] != 0.f;
     if (!chunk_busy && a.quiet_ok) limit_chunk_quiet<T>(a, chunk, lds, kept);
     else limit_chunk<T, true>(a, chunk, lds);
-}
-
-// The same limiter as a PERSISTENT grid (256-block chunks): a workgroup draws chunk after chunk from the ticket and
-// keeps two LDS buffers, so that the frames of its next chunk travel while the current one computes -- a chunk's
-// 23 us were 4 us of waiting for its own frames with nothing else to do (profiles/r02_limiter_phases.txt), and a CU
-// held loads in flight for a fifth of the time.  The next ticket is drawn at the start of a chunk and the frames
-// asked for after its hold word is out.  Tickets keep the look-back safe: every chunk a workgroup waits for is held
-// by a resident workgroup, either in work or next in line behind a LOWER-numbered chunk, so the lowest unfinished
-// chunk never waits for an unfinished one.  Chunks that touch the ends of the track load for themselves.
-template <int T, int WGS>
-__global__ __launch_bounds__(T, WGS * T / 256) void k_limit_persistent(LimiterArgs a0) {
-    warm_code(CODE_LIMIT, 2);
-    // The arguments are read again from the kernel-argument segment in every iteration, through a pointer the compiler
-    // cannot see through: left alone it computes everything that derives from them ONCE, before the loop -- float
-    // copies of the coefficients, the attack kappa, the gain -- and keeps those ~90 uniform values in vector
-    // registers it does not have (532 bytes of scratch per lane, reloaded one by one inside the loop).
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(4))) const LimiterArgs* KernelArgs;
-    KernelArgs ap = (KernelArgs)__builtin_amdgcn_kernarg_segment_ptr();
-    union ArgWords {
-        LimiterArgs args;
-        unsigned w[(sizeof(LimiterArgs) + 3) / 4];
-    };
-#define MGX_ARGS_NOW(name)                                                                                   \
-    asm volatile("" : "+s"(ap));                                                                             \
-    ArgWords name##_words;                                                                                   \
-    _Pragma("unroll") for (unsigned i_ = 0; i_ < sizeof(LimiterArgs) / 4; ++i_)                              \
-        name##_words.w[i_] = reinterpret_cast<__attribute__((address_space(4))) const unsigned*>(ap)[i_];     \
-    const LimiterArgs& name = name##_words.args
-#else
-    const LimiterArgs* ap = &a0;         // (the host pass only parses this)
-#define MGX_ARGS_NOW(name) LimiterArgs name = *ap
-#endif
-    MGX_ARGS_NOW(a);
-    using LB = LimiterBlock<T>;
-    MGX_LDS;
-    float* const base = reinterpret_cast<float*>(mgx_smem);
-    int* const tickets = reinterpret_cast<int*>(LB::scalars(base) + 4);   // [0], [1]: the first two chunks; [2]: the one after the next
-    const int tid = threadIdx.x;
-    const bool active = a.active ? (*a.active != 0) : true;
-    if (!active) {                       // hyrax.py:83-85: the array passes through, then stages.py:203
-        for (long long c = blockIdx.x; c < a.nchunks; c += gridDim.x) LB::phase_store(tid, c, a, false, base);
-        return;
-    }
-    if (tid == 0) tickets[0] = atomicAdd(a.ticket, 1);
-    if (tid == 64) tickets[1] = atomicAdd(a.ticket, 1);
-    __syncthreads();
-    long long chunk = tickets[0], next = tickets[1];
-    if (chunk > next) {                  // (two lanes asked at once: the smaller number first)
-        const long long t = chunk;
-        chunk = next;
-        next = t;
-    }
-    int cur = 0;
-    bool have = false;                   // uniform: the current buffer already holds this chunk's gains
-    const long long nchunks = a.nchunks;
-    while (chunk < nchunks) {
-        __syncthreads();                 // (tickets[] and both buffers are free of readers from the last iteration)
-        MGX_ARGS_NOW(a);
-        const int tid = opaque((int)threadIdx.x);               // (nothing derived from the thread id outlives an iteration)
-        float* lds = base + cur * LB::BUFFER_FLOATS;
-        NextChunk nx;
-        nx.chunk = next;
-        nx.lds = base + (cur ^ 1) * LB::BUFFER_FLOATS;
-        nx.after = tickets + 2;
-        nx.on = next < a.nchunks && LB::full_chunk(next, a);
-        if (!LB::full_chunk(chunk, a)) {
-            if (tid == 64) tickets[2] = atomicAdd(a.ticket, 1);
-            limit_chunk<T, false>(a, chunk, lds);
-            nx.on = false;
-        } else {
-            if (!have) {
-                typename LB::Reload q;
-                float pm[LB::E / 2];
-                LB::phase_load_full(opaque(tid), chunk, a, lds, pm, q);
-                store_block_maxima<T>(lds, pm);
-                __syncthreads();
-            }
-            bool chunk_busy = false;
-#pragma unroll
-            for (int w = 0; w < LB::WAVES; ++w) chunk_busy = chunk_busy || LB::edge_sl(lds)[w] != 0.f;
-            if (!chunk_busy && a.quiet_ok) limit_chunk_quiet_ahead<T>(a, chunk, lds, nx);
-            else limit_chunk<T, true>(a, chunk, lds, &nx);
-        }
-        __syncthreads();
-        chunk = next;
-        next = tickets[2];
-        have = nx.on;
-        cur ^= 1;
-    }
-#undef MGX_ARGS_NOW
 }
 
 }  // namespace mgx
