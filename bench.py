@@ -153,7 +153,7 @@ def timed_steps(ranks, sync, step, steps, warmup, own=None):
 class Workload:
     """Resident inputs/outputs of one named workload on this rank and the function that runs one step."""
 
-    def __init__(self, name, rank, local, mg, Device, device_count, make_pair):
+    def __init__(self, name, rank, local, mg, Device, device_count, make_pair, world=1):
         self.name = name
         from matchering_amd.batch import choose_lanes, lane_choice_report, lane_device
 
@@ -168,7 +168,7 @@ class Workload:
             # (batch.choose_lanes: a pair's latency-bound stretches -- FIR design, level decisions, the
             # limiter's look-back waits -- are filled by the other pairs' kernels; boxes of the pool disagree
             # on whether the third handle still pays).  Outside the timed region.
-            count = choose_lanes(index)
+            count = choose_lanes(index, world_size=world)      # (ranks that share a GPU share its lane budget)
             self.lane_choice = lane_choice_report(index)
             self.lanes = [lane_device(index, k) for k in range(count)]
         elif name == "96k_16k_full":
@@ -355,7 +355,7 @@ def run(args, ranks):
         name = args.workload
         if name == "auto":
             name = "8min_full" if ranks.world == 1 else "4min_x8_full"
-        wl = Workload(name, ranks.rank, ranks.local, mg, Device, device_count, make_pair)
+        wl = Workload(name, ranks.rank, ranks.local, mg, Device, device_count, make_pair, world=ranks.world)
     spun = spin_up(wl.sync, wl.step, args.spinup)
     own_seconds = []
     elapsed = timed_steps(ranks, wl.sync, wl.step, args.steps, args.warmup, own_seconds)

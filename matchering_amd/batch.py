@@ -123,7 +123,10 @@ def lanes_allowed(world_size=1):
     return max(1, MAX_LANES // sharing)
 
 
-def choose_lanes(device_index=0, candidates=(2, 3), seconds=120.0, pairs=6, master=None):
+_measuring = threading.Lock()
+
+
+def choose_lanes(device_index=0, candidates=(2, 3), seconds=120.0, pairs=6, master=None, world_size=1):
     """How many device handles a batch should run on THIS GPU: measured, once per process and GPU.
 
     Boxes of the pool disagree: on some, three handles beat two by 10 % (1.87 vs 2.11 ms for eight resident
@@ -133,53 +136,70 @@ def choose_lanes(device_index=0, candidates=(2, 3), seconds=120.0, pairs=6, mast
     counts, so neither is handed an uneven share --, full pipeline) is timed through
     each candidate count and the fastest wins; the decision and both timings are kept in
     ``lane_choice_report(device_index)``.  Costs ~1 s of host time for the synthetic material and a few
-    milliseconds of GPU time."""
+    milliseconds of GPU time.  ``MGX_LANES=n`` skips the measurement; candidates above the per-GPU budget of
+    ``lanes_allowed(world_size)`` are not tried (ranks that share a GPU would otherwise measure with more handles
+    than they may use); one measurement at a time per process, each lane's device locked while it runs, and the
+    blocks it recycled are given back afterwards."""
     if master is not None:                       # a stand-in for the GPU (CPU tests): nothing to measure
         return min(candidates[-1], MAX_LANES)
-    with _lane_devices_lock:
-        if device_index in _lane_choice:
-            return _lane_choice[device_index]["lanes"]
-    import time
+    forced = os.environ.get("MGX_LANES", "")
+    if forced.isdigit() and int(forced) > 0:
+        return min(int(forced), lanes_allowed(world_size))
+    budget = lanes_allowed(world_size)
+    candidates = tuple(c for c in candidates if c <= budget) or (budget,)
+    if len(candidates) == 1:
+        return candidates[0]
+    with _measuring:
+        with _lane_devices_lock:
+            if device_index in _lane_choice:
+                return min(_lane_choice[device_index]["lanes"], budget)
+        import time
+        from contextlib import ExitStack
 
-    from .synth import make_pair
+        from .synth import make_pair
 
-    native = Config().to_native()
-    host = [make_pair(seconds, 44100, pair=300 + k) for k in range(pairs)]
-    timings = {}
-    for count in candidates:
-        devs = [lane_device(device_index, lane) for lane in range(count)]
-        jobs = []
-        for k, (t, r) in enumerate(host):
-            d = devs[k % count]
-            jobs.append((d, d.upload(t), t.shape[0], d.upload(r), r.shape[0], d.alloc(t.shape[0] * 8)))
+        native = Config().to_native()
+        host = [make_pair(seconds, 44100, pair=300 + k) for k in range(pairs)]
+        timings = {}
+        for count in candidates:
+            devs = [lane_device(device_index, lane) for lane in range(count)]
+            with ExitStack() as held:
+                for d in devs:
+                    held.enter_context(d.lock)
+                jobs = []
+                for k, (t, r) in enumerate(host):
+                    d = devs[k % count]
+                    jobs.append((d, d.upload(t), t.shape[0], d.upload(r), r.shape[0], d.alloc(t.shape[0] * 8)))
 
-        def step():
-            for d, t, n, r, nr, out in jobs:
-                d.master(t, n, r, nr, native, result=out, want_report=False)
+                def step():
+                    for d, t, n, r, nr, out in jobs:
+                        d.master(t, n, r, nr, native, result=out, want_report=False)
 
-        def sync():
-            for d in devs:
-                d.synchronize()
+                def sync():
+                    for d in devs:
+                        d.synchronize()
 
-        step()
-        sync()
-        best = None
-        for _ in range(3):
-            t0 = time.perf_counter()
-            step()
-            step()
-            sync()
-            took = (time.perf_counter() - t0) / 2
-            best = took if best is None else min(best, took)
-        timings[count] = best
-        for d, t, n, r, nr, out in jobs:
-            for b in (t, r, out):
-                b.release()
-    chosen = min(timings, key=timings.get)
-    with _lane_devices_lock:
-        _lane_choice[device_index] = {"lanes": chosen, "ms_per_batch": {str(k): round(v * 1e3, 3) for k, v in timings.items()},
-                                      "batch": f"{pairs} resident pairs of {seconds:.0f} s"}
-    return chosen
+                step()
+                sync()
+                best = None
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    step()
+                    step()
+                    sync()
+                    took = (time.perf_counter() - t0) / 2
+                    best = took if best is None else min(best, took)
+                timings[count] = best
+                for d, t, n, r, nr, out in jobs:
+                    for b in (t, r, out):
+                        b.release()
+                for d in devs:
+                    d.trim()
+        chosen = min(timings, key=timings.get)
+        with _lane_devices_lock:
+            _lane_choice[device_index] = {"lanes": chosen, "ms_per_batch": {str(k): round(v * 1e3, 3) for k, v in timings.items()},
+                                          "batch": f"{pairs} resident pairs of {seconds:.0f} s"}
+        return chosen
 
 
 def lane_choice_report(device_index=0):
@@ -382,7 +402,7 @@ def process_batch(jobs, config=None, rank=None, world_size=None, device_index=No
             return run
 
         if lanes is None:
-            lanes = choose_lanes(device_index, master=master) if len(mine) > 2 else 2
+            lanes = choose_lanes(device_index, master=master, world_size=w) if len(mine) > 2 else 2
         lanes = min(max(1, lanes), MAX_LANES if master is not None else lanes_allowed(w))
         pool = _Lanes(worker_for, lanes)
         # Host memory stays bounded whatever the batch size: at most `io_threads` decoded pairs wait for

@@ -77,10 +77,19 @@ def build(force=False, verbose=False, out=None, extra_flags=()):
 
 
 def _compile(out, extra_flags, verbose):
+    import shutil
+
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fno-slp-vectorize: packing the butterflies' float pairs into v_pk_* costs more v_mov shuffles
     # than it saves on gfx950 (k_conv 233 -> 196 us, k_analyze 108 -> 65 us, profiles/r01_d_*)
-    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(hipcc)), "lib")
+    # (the library folder follows the compiler's REAL location: HIPCC=hipcc, a bare name on PATH, must not
+    # turn into the relative folder "lib" -- ADVICE round 3)
+    found = shutil.which(hipcc)
+    rocm_lib = None
+    if found:
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(found))), "lib")
+    if not rocm_lib or not os.path.exists(os.path.join(rocm_lib, "librccl.so")):
+        rocm_lib = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
     roctx = (["-lrocprofiler-sdk-roctx"] if os.path.exists(os.path.join(rocm_lib, "librocprofiler-sdk-roctx.so"))
              else ["-DMGX_NO_ROCTX"])             # (ROCm installs without the profiler SDK: the stage markers go)
     cmd = [hipcc, *FLAGS, *extra_flags, *roctx, "-o", out] + SOURCES + [f"-L{rocm_lib}", "-lrccl", f"-Wl,-rpath,{rocm_lib}"]

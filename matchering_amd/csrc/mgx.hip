@@ -300,8 +300,11 @@ static int check_config(const mgx_config* c) {
     if (!c) return fail(MGX_ERR_ARGUMENT, "config is null");
     if (c->internal_sample_rate <= 0) return fail(MGX_ERR_ARGUMENT, "internal_sample_rate must be positive");
     if (ilog2_exact(c->fft_size) < 0) return fail(MGX_ERR_ARGUMENT, "fft_size must be a power of two");
-    if (c->fft_size < 64 || c->fft_size > 32768)
-        return fail(MGX_ERR_UNSUPPORTED, "fft_size outside [64, 32768] is not implemented "
+    if (c->fft_size < 8)          /* (defaults.py:110-112 lets 2 and 4 through; match_frequencies.py:45-58 then fails) */
+        return fail(MGX_ERR_ARGUMENT, "fft_size below 8: the reference's own cubic interpolation of the matching curve "
+                                      "needs at least four points per side and fails there");
+    if (c->fft_size > 32768)
+        return fail(MGX_ERR_UNSUPPORTED, "fft_size above 32768 is not implemented "
                                          "(an analysis segment is one or two transforms that fit one CU's LDS)");
     if (c->rms_correction_steps < 0) return fail(MGX_ERR_ARGUMENT, "rms_correction_steps must not be negative");
     if (c->rms_correction_steps > 4096)      /* (a flag word per round and summing workgroup: 4 MB at 4096) */
@@ -329,6 +332,7 @@ static int check_length(long long n) {
 static int analysis_workgroups_per_cu(int log2f) {
     size_t lds = 0;
     int threads = 64;
+    if (log2f < 6) return 8;                                     // k_analyze_small: 256 threads, a few hundred bytes of LDS
     switch (log2f) {
 #define CASE(L) case L: lds = analysis_lds_bytes<L>(); threads = Fft2<L>::T; break;
         CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
@@ -415,6 +419,8 @@ static int analysis_args(mgx_handle* h, const float* x, long long n, const mgx_c
     a.wg_sumsq = (double*)w.wg_sumsq.p;
     a.wg_peak = (float*)w.wg_peak.p;
     a.wg_spec = (float*)w.wg_spec.p;
+    a.tw = nullptr;
+    if (cfg->fft_size < 64) return 0;                            // k_analyze_small transforms in registers: no table
     // (fft_size 32768 runs on 16384-point transforms: AnalysisDouble)
     return get_twiddles(h, std::min(14, ilog2_exact(cfg->fft_size)), &a.tw);
 }
@@ -432,6 +438,9 @@ static int run_analysis(mgx_handle* h, const mgx_config* cfg, const float* x0, l
     if (w1) MGX_TRY(analysis_args(h, x1, n1, cfg, *w1, a1));
     const int nwg = w0.nwg + (w1 ? w1->nwg : 0);
     switch (ilog2_exact(cfg->fft_size)) {
+#define SMALL(L) case L: hipLaunchKernelGGL(k_analyze_small<L>, dim3(nwg), dim3(256), 0, h->stream, a0, a1, w0.nwg); HIP_TRY(hipGetLastError()); break;
+        SMALL(3) SMALL(4) SMALL(5)
+#undef SMALL
 #define CASE(L) case L: MGX_TRY(launch_analysis<L>(h, a0, a1, w0.nwg, nwg)); break;
         CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
@@ -567,7 +576,7 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
         MGX_TRY(allow_lds(k_match_curve, lds_curve));
         hipLaunchKernelGGL(k_match_curve, dim3((pl.bins + 31) / 32, 2), dim3(1024), lds_curve, h->stream, ct, cr, pl.bins,
                            pl.fft, max_div, cfg->threshold, cfg->min_value, pl.min_value, raw, (double*)h->scalars.p,
-                           (CorrectionState*)h->cstate.p);
+                           (CorrectionState*)h->cstate.p, h->error_dev);
     } else {
         TrackWork& t = const_cast<TrackWork&>(tw);
         TrackWork& r = const_cast<TrackWork&>(rw);
@@ -599,7 +608,12 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
         hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
                            (const int2*)pd.band, (const double*)raw, scratch);
     }
-    if (pl.fft < 64) return fail(MGX_ERR_UNSUPPORTED, "fft_size below 64 is not implemented");
+    if (pl.fft < 64) {                                          // 8 .. 32 taps: the plain cosine sum, one thread per tap
+        hipLaunchKernelGGL(k_fir_taps_direct, dim3(2), dim3(1024), 0, h->stream, pl, (const double*)scratch, (float*)h->taps.p);
+        HIP_TRY(hipGetLastError());
+        h->last_taps = cfg->fft_size;
+        return 0;
+    }
     // tap synthesis: the symmetric cosine sum up to 4096 taps (8 us in one launch -- two launches of the split
     // transform cost 10), the split transform from 8192 taps on (13 us against 47 at 16384;
     // profiles/r03_x_tap_synthesis.txt).  MGX_TAPS_BY_COSINE_SUM=1 forces the sum: the A/B switch of that profile.
@@ -676,6 +690,17 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     const int l = ilog2_exact(taps);
     if (l < 0) return fail(MGX_ERR_ARGUMENT, "FIR length must be a power of two");
     MGX_TRY(check_length(n));
+    if (taps <= CONV_DIRECT_MAX_TAPS) {                          // 2 .. 32 taps: in the time domain (small_fft_kernels.h)
+        const long long tiles = (n + CONV_DIRECT_TILE - 1) / CONV_DIRECT_TILE;
+        MGX_TRY(ensure(h, h->block_peak, (size_t)tiles * sizeof(float)));
+        if (npairs_out) *npairs_out = tiles;
+        StageScope scope(h, MGX_STAGE_CONVOLVE);
+        hipLaunchKernelGGL(k_conv_direct, dim3((unsigned)tiles), dim3(256), 0, h->stream, reinterpret_cast<const float2*>(x),
+                           (long long)n, taps_dev, taps, gain_ptr, gain, reinterpret_cast<float2*>(y), ymid,
+                           (float*)h->block_peak.p);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     int log2b = l + 1;
     if (log2b > 14) log2b = LONG_FIR_LOG2N;
     const size_t nb = (size_t)1 << log2b;
@@ -842,6 +867,9 @@ static int check_device_error(mgx_handle* h) {
     if (h->lim_ctrl.p) HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 64, h->stream));
     if (h->conv_queue.p) HIP_TRY(hipMemsetAsync(h->conv_queue.p, 0, 64, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (what & DEVICE_ERROR_INPUT)
+        return fail(MGX_ERR_ARGUMENT, "the target or the reference holds samples that are not finite numbers (NaN or infinity): "
+                                      "the reference fails on such input too (match_frequencies.py:42)");
     if (what == DEVICE_ERROR_TAIL && h->last_call.valid && !h->avoid_tail) {
         h->avoid_tail = true;
         const mgx_handle::MasterCall again = h->last_call;
@@ -1199,13 +1227,15 @@ int mgx_window_energy(mgx_handle* h, const float* x_dev, int64_t n, int64_t size
     const int64_t windows = (n - size) / step + 1;
     *count = windows;
     if (windows > capacity) return fail(MGX_ERR_ARGUMENT, "energy array too small for the number of windows");
-    if (windows > 65535) return fail(MGX_ERR_UNSUPPORTED, "more than 65535 preview windows");
     const int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(64, size / 16384));
     const size_t bytes = (size_t)windows * chunks * sizeof(double);
     MGX_TRY(ensure(h, h->partial, bytes));
     MGX_TRY(ensure_pinned(h, std::max(bytes, (size_t)1 << 16)));
-    hipLaunchKernelGGL(k_window_energy, dim3(chunks, (unsigned)windows), dim3(256), 0, h->stream, (const float2*)x_dev,
-                       (long long)size, (long long)step, chunks, (double*)h->partial.p);
+    for (int64_t w0 = 0; w0 < windows; w0 += 65535) {          // (a grid's y extent is 16 bits; the reference has no limit)
+        const unsigned rows = (unsigned)std::min<int64_t>(65535, windows - w0);
+        hipLaunchKernelGGL(k_window_energy, dim3(chunks, rows), dim3(256), 0, h->stream, (const float2*)x_dev,
+                           (long long)size, (long long)step, chunks, (double*)h->partial.p, (long long)w0);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h->pinned, h->partial.p, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));

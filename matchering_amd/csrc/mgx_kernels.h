@@ -71,6 +71,20 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
     return r;
 }
 
+}  // namespace mgx
+#include "small_fft_kernels.h"     // fft_size 8 .. 32 (needs the block reductions above)
+namespace mgx {
+
+// Values of the handle's error word.  A limiter look-back that expires (limiter_kernel.h) means a lost word: the
+// audio is wrong and the call fails.  An expired wait of k_correction_tail means its workgroups were not resident
+// together (another process's kernels held the compute units): the host then runs the rounds again as one launch
+// each, which wait for nobody (mgx.hip, check_device_error).  DEVICE_ERROR_INPUT is not a wait at all: the level
+// analysis met a NaN or an infinity (k_match_curve), where the reference raises.
+constexpr int DEVICE_ERROR_LOOKBACK = 1, DEVICE_ERROR_TAIL = 2, DEVICE_ERROR_INPUT = 4;
+#ifdef MGX_TEST_TAIL_EXPIRE
+__device__ int g_test_tail_launches;
+#endif
+
 // ---------------------------------------------------------------------------
 // code warming
 // ---------------------------------------------------------------------------
@@ -90,10 +104,17 @@ constexpr int CODE_VARIANTS = 16;                                  // second ind
 __device__ int g_code_bytes[CODE_KERNELS][CODE_VARIANTS];
 __device__ __forceinline__ void warm_code(int which, int variant = 0) {
     if (blockIdx.x >= 8 || threadIdx.x >= 64) return;             // workgroup b runs on XCD b % 8: one wave per L2
-    const int bytes = g_code_bytes[which][variant] - 1024;         // (s_getpc sits a little behind the entry point)
-    const char* pc = reinterpret_cast<const char*>(__builtin_amdgcn_s_getpc());
+    const int bytes = g_code_bytes[which][variant];
+    // Where this kernel's code starts: dispatch packet -> kernel descriptor -> entry offset (the AMDHSA code object
+    // ABI: hsa_kernel_dispatch_packet_t::kernel_object at byte 32 points at the 64-byte descriptor, whose
+    // kernel_code_entry_byte_offset at byte 16 is relative to the descriptor).  The window read is then exactly
+    // [entry, entry + symbol size): it cannot run past the kernel whatever the compiler did with the block that
+    // holds these loads (the program counter of this block is not the entry point).
+    const char* packet = (const char*)__builtin_amdgcn_dispatch_ptr();      // (constant address space -> generic)
+    const char* descriptor = *reinterpret_cast<const char* const*>(packet + 32);
+    const char* entry = descriptor + *reinterpret_cast<const long long*>(descriptor + 16);
     int acc = 0;
-    for (int off = (int)threadIdx.x * 64; off < bytes; off += 4096) acc += *reinterpret_cast<const volatile int*>(pc + off);
+    for (int off = (int)threadIdx.x * 64; off < bytes; off += 4096) acc += *reinterpret_cast<const volatile int*>(entry + off);
     if (acc == 0x7ffffff1) asm volatile("s_nop 0");                // (the sum is needed: the loads are waited for here)
 }
 
@@ -794,7 +815,7 @@ __host__ __device__ inline size_t match_curve_lds_bytes(int max_div, int rows) {
 __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack tr, int bins, int fft, int max_div,
                                                       double threshold, double eps, double curve_floor,
                                                       double* raw /* [2][bins] */, double* c0_out,
-                                                      CorrectionState* cs_init) {
+                                                      CorrectionState* cs_init, int* error) {
     warm_code(CODE_MATCH_CURVE);
     MGX_LDS;
     const int rows = tt.nwg + tr.nwg;
@@ -854,6 +875,10 @@ __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack 
                 st.loud_count = count;
                 st.piece = t.piece;
                 *t.st = st;
+                // A NaN or an infinity among the samples: no piece is "loud" (every comparison with NaN fails) or
+                // the loud pieces' RMS is not a number.  The reference stops there (match_frequencies.py:42 is
+                // handed an empty selection); here the handle's error word makes the next blocking call fail.
+                if (error && (count == 0 || !(fabs(match) < 1.0e300))) *error = DEVICE_ERROR_INPUT;
             }
         }
     }
@@ -977,6 +1002,13 @@ __global__ __launch_bounds__(256) void k_fir_matvec(FirPlanView pl, const double
         fir_scratch(scratch, pl, 0).smooth[row] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
         fir_scratch(scratch, pl, 1).smooth[row] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
+}
+
+// fft_size 8 .. 32 (small_fft_kernels.h): taps[i] = hann[i] * irfft(smooth)[(i + F/2) mod F] by the plain cosine sum (fir_plan.h, phase_taps); grid = 2
+__global__ __launch_bounds__(1024) void k_fir_taps_direct(FirPlanView pl, const double* scratch, float* taps /* [2][F] */) {
+    const int plane = blockIdx.x;
+    const FirScratch s = fir_scratch(const_cast<double*>(scratch), pl, plane);
+    FirDesign::phase_taps(threadIdx.x, pl, s.smooth, taps + (size_t)plane * pl.fft, nullptr);
 }
 
 // LOWESS regressions: one wave per anchor.  grid = (ceil(anchors/16), 2)
@@ -1589,14 +1621,6 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
 // coefficients are ratios of two loudness estimates of nearly the same signal).
 // Phase stamps of this kernel and of round 0's last workgroup: profiles/r03_z_correction_phases.txt
 // (-DMGX_TAIL_TRACE, tools/tail_trace.py).
-// Values of the handle's error word.  A limiter look-back that expires (limiter_kernel.h) means a lost word: the
-// audio is wrong and the call fails.  An expired wait of k_correction_tail means its workgroups were not resident
-// together (another process's kernels held the compute units): the host then runs the rounds again as one launch
-// each, which wait for nobody (mgx.hip, check_device_error).
-constexpr int DEVICE_ERROR_LOOKBACK = 1, DEVICE_ERROR_TAIL = 2;
-#ifdef MGX_TEST_TAIL_EXPIRE
-__device__ int g_test_tail_launches;
-#endif
 #ifdef MGX_TEST_TAIL_MAX_SPINS                             // tests/test_device_errors.py: a tail that gives up quickly
 constexpr int TAIL_MAX_SPINS = MGX_TEST_TAIL_MAX_SPINS;
 #else
@@ -1928,9 +1952,10 @@ __global__ __launch_bounds__(256) void k_scale_outputs(const float2* y, long lon
 // windows): workgroup (c, w) sums chunk c of window w in float64 (float32 products are exact in float64);
 // the host adds a window's chunks in order and takes the argmax of a few hundred numbers.
 __global__ __launch_bounds__(256) void k_window_energy(const float2* x, long long size, long long step, int chunks,
-                                                       double* partial /* [windows][chunks] */) {
+                                                       double* partial /* [windows][chunks] */, long long first_window) {
     __shared__ double scratch[4];
-    const long long begin = (long long)blockIdx.y * step;
+    partial += (size_t)first_window * chunks;                   // (grids of at most 65535 windows each)
+    const long long begin = (first_window + (long long)blockIdx.y) * step;
     const long long len = (size + chunks - 1) / chunks;
     const long long b = begin + (long long)blockIdx.x * len, e = min(begin + size, b + len);
     double acc = 0.0;

@@ -244,3 +244,29 @@ def test_fuzz_config_and_material(case):
                         -1.0, 1.0).astype(np.float32)
     errs, _, _ = check_against_oracle(target, reference, case["cfg"])
     assert max(errs) <= RMS_TOL, (case, errs)
+
+
+# ------------------------------------------------------------------------------------------------
+# samples that are not numbers
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("where, value", [("target", np.nan), ("target", np.inf), ("reference", np.nan),
+                                          ("reference", -np.inf)])
+def test_non_finite_samples_fail_like_the_reference(where, value):
+    """The reference does not check its input (stages.py:210-272) and does not survive it either: with one NaN or
+    infinity in a track no piece compares as loud, the loud selection is empty and match_frequencies.py:42 raises
+    (the oracle stops one step earlier, mastering_oracle.loud_pieces).  Here the level analysis notices the same
+    thing on the device, and the call -- or, without a report, the next blocking call -- fails with
+    MGX_ERR_ARGUMENT; the handle is good for the next pair."""
+    from matchering_amd import stages
+    from matchering_amd._native import MgxError
+
+    target, reference = make_pair(4.0, 44100, pair=2, reference_seconds=3.5)
+    bad_t, bad_r = target.copy(), reference.copy()
+    (bad_t if where == "target" else bad_r)[50000, 1] = value
+    with pytest.raises(Exception):
+        mo.master(bad_t, bad_r, mo.params(max_piece_size=1.0), True, False, False)
+    with pytest.raises(MgxError, match="not finite") as caught:
+        stages.main(bad_t, bad_r, config_of(dict(max_piece_size=1.0)))
+    assert caught.value.code == -1
+    errs, _, _ = check_against_oracle(target, reference, dict(max_piece_size=1.0))
+    assert max(errs) <= RMS_TOL

@@ -367,6 +367,9 @@ def test_fails_loudly_on_unsupported():
     with pytest.raises(MgxError):
         stages.main(t, r, mg.Config(internal_sample_rate=8000, fft_size=65536, max_piece_size=9.0,
                                     max_length=600))
+    # fft_size 2 and 4 pass defaults.py:110-112 and then fail inside the reference (tests/test_host_vs_reference.py)
+    with pytest.raises(MgxError, match="fft_size below 8"):
+        stages.main(t, r, mg.Config(internal_sample_rate=8000, fft_size=4, max_piece_size=1.0))
     # limiter filters of order 3 and up: ill-conditioned in the reference's own form (limiter_general.h)
     with pytest.raises(MgxError, match="orders above 2"):
         stages.main(t, r, mg.Config(internal_sample_rate=8000, max_piece_size=5.0,
@@ -519,10 +522,11 @@ def test_rccl_single_rank_collectives():
         check(lib.mgx_comm_destroy(dev.handle))
 
 
-@pytest.mark.parametrize("steps", [0, 1, 7])
+@pytest.mark.parametrize("steps", [0, 1, 7, 16, 17, 40])
 def test_correction_step_counts(steps):
     """`rms_correction_steps` other than the default 4 (stages.py:149-168): none at all (the peak and
-    early-out scalars then come from their own kernel), a single round (first and last at once), many."""
+    early-out scalars then come from their own kernel), a single round (first and last at once), many -- and
+    more than the 16 coefficients the report keeps (defaults.py:118-120 allows any number)."""
     import matchering_amd as mg
     from matchering_amd import stages
     from matchering_amd.synth import make_pair
@@ -582,10 +586,11 @@ def test_other_sample_rates(rate):
         assert rms_error(mine, ref) <= RMS_TOL
 
 
-@pytest.mark.parametrize("fft_size", [64, 128, 256, 512, 1024, 2048, 8192])
+@pytest.mark.parametrize("fft_size", [8, 16, 32, 64, 128, 256, 512, 1024, 2048, 8192])
 def test_other_fft_sizes(fft_size):
     """Every transform plan end to end: analysis segments of fft_size frames and convolution blocks of
-    twice that (fft2.h plans 6..14)."""
+    twice that (fft2.h plans 6..14); 8, 16 and 32 -- the smallest sizes the reference itself runs -- take the
+    register transforms and the time-domain filter of small_fft_kernels.h."""
     import matchering_amd as mg
     from matchering_amd import stages
     from matchering_amd.synth import make_pair

@@ -50,3 +50,42 @@ def test_oracle_reproduces_the_reference(name):
     assert np.abs(np.asarray(trace["correction_coefficients"]) / inter["correction_coefficients"] - 1).max() <= 1e-11
     assert np.abs(trace["fir_mid"] - inter["fir_mid"]).max() <= 1e-12 * np.abs(inter["fir_mid"]).max()
     assert np.abs(trace["fir_side"] - inter["fir_side"]).max() <= 1e-12 * np.abs(inter["fir_side"]).max()
+
+
+# ---- the edges of Config the reference itself supports ------------------------------
+@pytest.mark.parametrize("fft_size", [8, 16, 32])
+def test_smallest_fft_sizes_the_reference_runs(fft_size):
+    """defaults.py:110-112 asks only for a power of two above 1.  8, 16 and 32 run in the reference, so they run here
+    (small_fft_kernels.h); the oracle is pinned to the reference there too."""
+    target, reference = make_pair(3.0, 8000, pair=1)
+    cfg = dict(internal_sample_rate=8000, fft_size=fft_size, max_piece_size=1.0)
+    outs_ref, _ = rr.run_reference(target, reference, cfg, capture=False)
+    outs = mo.master(target, reference, mo.params(**cfg), True, True, True)
+    for mine, want in zip(outs, outs_ref):
+        assert np.abs(mine - np.ascontiguousarray(want)).max() <= 1e-11
+
+
+@pytest.mark.parametrize("cfg", [dict(fft_size=2), dict(fft_size=4), dict(limiter=dict(hold=0.25)),
+                                 dict(limiter=dict(hold=0.05))])
+def test_what_the_reference_itself_cannot_run(cfg):
+    """Values that pass the asserts of defaults.py and then fail INSIDE the reference: fft_size 2 and 4 (the cubic
+    interp1d of match_frequencies.py:45-58 has too few points) and limiter hold times below three samples
+    (hyrax.py:35-40: the sliding window is empty).  libmgx refuses them with MGX_ERR_ARGUMENT; they are not
+    gaps against the reference (tests/test_gpu_parity.py::test_fails_loudly_on_unsupported)."""
+    target, reference = make_pair(3.0, 8000, pair=1, reference_gain=3.0)
+    kw = dict(internal_sample_rate=8000, fft_size=256, max_piece_size=1.0)
+    kw.update(cfg)
+    with pytest.raises(Exception):
+        rr.run_reference(target, reference, kw, capture=False)
+
+
+def test_more_than_sixteen_correction_steps():
+    target, reference = make_pair(3.0, 8000, pair=2)
+    cfg = dict(internal_sample_rate=8000, fft_size=256, max_piece_size=1.0, rms_correction_steps=20)
+    outs_ref, inter = rr.run_reference(target, reference, cfg)
+    trace = {}
+    outs = mo.master(target, reference, mo.params(**cfg), True, True, True, trace=trace)
+    assert len(inter["correction_coefficients"]) == 20
+    assert np.abs(np.asarray(trace["correction_coefficients"]) / inter["correction_coefficients"] - 1).max() <= 1e-11
+    for mine, want in zip(outs, outs_ref):
+        assert np.abs(mine - np.ascontiguousarray(want)).max() <= 1e-11
