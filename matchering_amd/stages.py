@@ -77,8 +77,11 @@ def main(target: np.ndarray, reference: np.ndarray, config: Config, need_default
             info(Code.INFO_MATCHING_FREQS)
             debug_line()
             info(Code.INFO_CORRECTING_LEVELS)
-            for step in range(config.rms_correction_steps):
+            kept = len(report.correction_coefficients)               # (mgx_report keeps the first 16 coefficients)
+            for step in range(min(config.rms_correction_steps, kept)):
                 debug(f"correction round {step + 1}: {to_db(report.correction_coefficients[step])}")
+            if config.rms_correction_steps > kept:
+                debug(f"... and {config.rms_correction_steps - kept} more rounds")
             debug_line()
             info(Code.INFO_FINALIZING)
             if need_no_limiter_normalized:
