@@ -345,6 +345,19 @@ struct Fft2 {
             for (int e = 0; e < CNT_; ++e) v[e] = p[e];
         }
     }
+    // elements [E0, E0+CNT) of a row from v[E0 ..] (E0, CNT even)
+    template <int E0, int CNT_>
+    static MGX_HD void store_row_part(const float2 (&v)[RL], int row, float2* lds) {
+        float2* p = lds + base<LAST>(row);
+        if (PADDED) {
+            MGX_UNROLL
+            for (int e = E0; e < E0 + CNT_; e += 2)
+                *reinterpret_cast<float4*>(p + e) = make_float4(v[e].x, v[e].y, v[e + 1].x, v[e + 1].y);
+        } else {
+            MGX_UNROLL
+            for (int e = E0; e < E0 + CNT_; ++e) p[e] = v[e];
+        }
+    }
     static MGX_HD void store_row(const float2 (&v)[RL], int row, float2* lds) {
         float2* p = lds + base<LAST>(row);
         if (PADDED) {

@@ -217,14 +217,15 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
 // (Issuing the NEXT pair's frame loads before the epilogue's stores -- software pipelining -- was
 // built and measured: the 48-96 registers in flight make the 8192-point kernel spill at the 256 a
 // wave has here, and a spilling kernel is far slower than an unpipelined one, 294 vs 153 us.)
-template <int LOG2N, bool MULTI>
+template <int LOG2N, bool MULTI, int TS = 1>
 __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2Args& a,
-                                           const typename Conv2Block<LOG2N>::Persist& ps, float2* lds,
+                                           const typename Conv2Block<LOG2N, TS>::Persist& ps, float2* lds,
                                            const float2* mid_table) {
-    using CB = Conv2Block<LOG2N>;
+    static_assert(!MULTI || TS == 1, "filter partitions run on N = 2P blocks");
+    using CB = Conv2Block<LOG2N, TS>;
     const bool edge = !CB::interior(pair, a.n, a.parts);
     typename CB::Kept kept;
-    if (MULTI) {
+    if constexpr (MULTI) {
         conv_channel_partitioned<LOG2N, false>(tid, pair, edge, a, ps, lds, mid_table);
         CB::phase_keep_mid(tid, ps, lds, kept);
         __syncthreads();
@@ -254,10 +255,10 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2A
 // Two workgroups per CU (LDS): the second launch bound is waves per SIMD, i.e. the register budget.
 // MULTI = more than one filter partition (its own instantiation: the accumulator row costs registers
 // the plain kernel should not pay for)
-template <int LOG2N, bool MULTI>
+template <int LOG2N, bool MULTI, int TS = 1>
 __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) void k_conv(Conv2Args a) {
     warm_code(CODE_CONV, LOG2N);
-    using CB = Conv2Block<LOG2N>;
+    using CB = Conv2Block<LOG2N, TS>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
@@ -281,7 +282,7 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         // not have.  An empty asm makes the values opaque per iteration.
 #pragma unroll
         for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
-        const float pk = conv_pair<LOG2N, MULTI>(tid, pair, a, ps, lds, mid_table);
+        const float pk = conv_pair<LOG2N, MULTI, TS>(tid, pair, a, ps, lds, mid_table);
         const float bp = block_max<F::T>(pk, scratch);
         if (tid == 0) {
             if (a.pair_peak) a.pair_peak[pair] = bp;
@@ -298,11 +299,11 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
 
 // filter spectra: grid = 2 * parts; taps = [2][parts * N/2] float (mid then side), tables =
 // [2][parts][N] float2.  Workgroup (ch, k) transforms partition k of channel ch.
-template <int LOG2N>
+template <int LOG2N, int TS = 1>
 __global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_prep(const float* taps, const float2* tw, float2* tables,
                                                               int parts, const double* gain_ptr, double gain) {
     warm_code(CODE_CONV_PREP, LOG2N);
-    using CB = Conv2Block<LOG2N>;
+    using CB = Conv2Block<LOG2N, TS>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
@@ -365,10 +366,12 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
     int s0, s1;
     AB::chunk_segments(a, ch, s0, s1);
     for (int s = s0; s < s1; ++s) {
-        // (A software prefetch of the next segment: at 128 VGPRs the 32 registers it pins spill, 152 us; at three
-        // workgroups per CU and 168 VGPRs it fits without scratch and changes nothing -- 100 us with and without it,
-        // against 92 us for four workgroups without: the kernel is bound by what a CU's LDS and VALU pipes get
-        // through per segment, not by the latency of its loads.  profiles/r04_b_ab_variants.txt)
+        // (A software prefetch of the next segment, round 4: asked for after pass 0, after the middle pass or after
+        // the row pass, with the thread id opaque per iteration so that nothing is hoisted -- at 128 VGPRs every
+        // variant spills (116 - 172 B: the kernel sits at 124 registers without it) and the spilling kernel ran 152 us;
+        // at three workgroups per CU and 168 VGPRs it fits without scratch and changes nothing: 100 us with and
+        // without it, against 92 us for four workgroups without.  Hiding the loads is worth exactly the fourth
+        // workgroup it costs.  profiles/r04_b_ab_variants.txt)
         typename AB::Raw raw;
         AB::fetch(tid, (long long)d * a.piece + (long long)s * F::N, a, raw);
         AB::phase_load(tid, raw, ps, th, lds);
@@ -377,9 +380,10 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
             AB::phase_fwd_mid(tid, lds, mid_table);
             lds_barrier();
         }
-        AB::phase_row(tid, th, lds);
+        typename AB::Row own;
+        AB::phase_row(tid, own, lds);
         lds_barrier();
-        AB::phase_magnitudes(tid, th, lds);
+        AB::phase_magnitudes(tid, own, th, lds);
         lds_barrier();
     }
     if (ch == a.chunks_per_piece - 1) {

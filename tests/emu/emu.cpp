@@ -163,6 +163,7 @@ static int analyze_impl(const float* x, long long n, const mgx_config* cfg, int 
     a.tw = tw.data();
     std::vector<float2> lds(F::LDS_ELEMS);
     std::vector<typename AB::Thread> th(F::T);
+    std::vector<typename AB::Row> own(F::T);
     std::vector<typename AB::Persist> ps(F::T);
     std::vector<float2> mid_table(F::MID_TABLE + 1);
     FOR_THREADS(F::T) AB::load_persist(tid, a.tw, mid_table.data(), ps[tid]);
@@ -175,8 +176,8 @@ static int analyze_impl(const float* x, long long n, const mgx_config* cfg, int 
             const long long start = d * piece + (long long)s * F::N;
             FOR_THREADS(F::T) { typename AB::Raw raw; AB::fetch(tid, start, a, raw); AB::phase_load(tid, raw, ps[tid], th[tid], lds.data()); }
             mid_pass<F>(false, lds.data(), mid_table.data());
-            FOR_THREADS(F::T) AB::phase_row(tid, th[tid], lds.data());
-            FOR_THREADS(F::T) AB::phase_magnitudes(tid, th[tid], lds.data());
+            FOR_THREADS(F::T) AB::phase_row(tid, own[tid], lds.data());
+            FOR_THREADS(F::T) AB::phase_magnitudes(tid, own[tid], th[tid], lds.data());
         }
         if (ch == a.chunks_per_piece - 1) {
             FOR_THREADS(F::T)
