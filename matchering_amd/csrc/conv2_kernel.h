@@ -52,14 +52,12 @@ struct Conv2Args {
     unsigned* queue;       // [8] pairs handed out per XCD beyond the first round, [8] workgroups done; zero between launches
 };
 
-// TS: log2(N / taps).  1 = the N = 2F plan everything runs on; 2 = N = 4F (three quarters of a block are fresh
-// output: 187 instead of 260 flop per frame), kept for the A/B of DESIGN.md section 3.4 only.
-template <int LOG2N, int TS = 1>
+template <int LOG2N>
 struct Conv2Block {
     using F = Fft2<LOG2N>;
     static constexpr int N = F::N;
     static constexpr int T = F::T;
-    static constexpr int TAPS = N >> TS;              // N = 2F: half of every block is fresh output
+    static constexpr int TAPS = N >> 1;               // N = 2F: half of every block is fresh output
     static constexpr int LOUT = N - TAPS;             // fresh output frames per block
     static constexpr int R0 = F::R0;
     static constexpr int RL = F::RL;

@@ -645,15 +645,15 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     return 0;
 }
 
-template <int LOG2N, bool MULTI, int TS = 1>
+template <int LOG2N, bool MULTI>
 static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr) {
     using F = Fft2<LOG2N>;
     const size_t lds = conv_lds_bytes<LOG2N>();
-    MGX_TRY((allow_lds(k_conv_prep<LOG2N, TS>, lds)));
-    MGX_TRY((allow_lds(k_conv<LOG2N, MULTI, TS>, lds)));
+    MGX_TRY((allow_lds(k_conv_prep<LOG2N>, lds)));
+    MGX_TRY((allow_lds(k_conv<LOG2N, MULTI>, lds)));
     {
         StageScope scope(h, MGX_STAGE_FILTER_SPECTRA);
-        hipLaunchKernelGGL((k_conv_prep<LOG2N, TS>), dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev,
+        hipLaunchKernelGGL((k_conv_prep<LOG2N>), dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev,
                            a.tw, (float2*)h->filt.p, a.parts, gain_ptr, gain);
     }
     HIP_TRY(hipGetLastError());
@@ -672,7 +672,7 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
     const unsigned grid = (unsigned)(((std::min<long long>(a.npairs, cap) + 7) / 8) * 8);
     {
         StageScope scope(h, MGX_STAGE_CONVOLVE);
-        hipLaunchKernelGGL((k_conv<LOG2N, MULTI, TS>), dim3(grid), dim3(F::T), lds, h->stream, a);
+        hipLaunchKernelGGL((k_conv<LOG2N, MULTI>), dim3(grid), dim3(F::T), lds, h->stream, a);
     }
     HIP_TRY(hipGetLastError());
     return 0;

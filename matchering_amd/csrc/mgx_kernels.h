@@ -217,12 +217,11 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
 // (Issuing the NEXT pair's frame loads before the epilogue's stores -- software pipelining -- was
 // built and measured: the 48-96 registers in flight make the 8192-point kernel spill at the 256 a
 // wave has here, and a spilling kernel is far slower than an unpipelined one, 294 vs 153 us.)
-template <int LOG2N, bool MULTI, int TS = 1>
+template <int LOG2N, bool MULTI>
 __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2Args& a,
-                                           const typename Conv2Block<LOG2N, TS>::Persist& ps, float2* lds,
+                                           const typename Conv2Block<LOG2N>::Persist& ps, float2* lds,
                                            const float2* mid_table) {
-    static_assert(!MULTI || TS == 1, "filter partitions run on N = 2P blocks");
-    using CB = Conv2Block<LOG2N, TS>;
+    using CB = Conv2Block<LOG2N>;
     const bool edge = !CB::interior(pair, a.n, a.parts);
     typename CB::Kept kept;
     if constexpr (MULTI) {
@@ -255,10 +254,10 @@ __device__ __forceinline__ float conv_pair(int tid, long long pair, const Conv2A
 // Two workgroups per CU (LDS): the second launch bound is waves per SIMD, i.e. the register budget.
 // MULTI = more than one filter partition (its own instantiation: the accumulator row costs registers
 // the plain kernel should not pay for)
-template <int LOG2N, bool MULTI, int TS = 1>
+template <int LOG2N, bool MULTI>
 __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) void k_conv(Conv2Args a) {
     warm_code(CODE_CONV, LOG2N);
-    using CB = Conv2Block<LOG2N, TS>;
+    using CB = Conv2Block<LOG2N>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
@@ -282,7 +281,7 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         // not have.  An empty asm makes the values opaque per iteration.
 #pragma unroll
         for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
-        const float pk = conv_pair<LOG2N, MULTI, TS>(tid, pair, a, ps, lds, mid_table);
+        const float pk = conv_pair<LOG2N, MULTI>(tid, pair, a, ps, lds, mid_table);
         const float bp = block_max<F::T>(pk, scratch);
         if (tid == 0) {
             if (a.pair_peak) a.pair_peak[pair] = bp;
@@ -299,11 +298,11 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
 
 // filter spectra: grid = 2 * parts; taps = [2][parts * N/2] float (mid then side), tables =
 // [2][parts][N] float2.  Workgroup (ch, k) transforms partition k of channel ch.
-template <int LOG2N, int TS = 1>
+template <int LOG2N>
 __global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_prep(const float* taps, const float2* tw, float2* tables,
                                                               int parts, const double* gain_ptr, double gain) {
     warm_code(CODE_CONV_PREP, LOG2N);
-    using CB = Conv2Block<LOG2N, TS>;
+    using CB = Conv2Block<LOG2N>;
     using F = Fft2<LOG2N>;
     MGX_LDS;
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
