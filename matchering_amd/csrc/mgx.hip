@@ -66,8 +66,7 @@ static int fail(int code, const std::string& msg) {
 #include <iterator>
 
 static const char* const CODE_NAMES[CODE_KERNELS] = {"k_analyzeILi", "k_match_curve", "k_conv_prepILi", "k_convILi",
-                                                     "k_correction_round", "k_correction_tail", "k_limitILi",
-                                                     "k_fir_matvec", "k_fir_tapsE"};
+                                                     "k_correction_round", "k_correction_tail", "k_limitILi"};
 static bool elf_ok(const std::vector<char>& f, size_t at) {
     return at + sizeof(Elf64_Ehdr) <= f.size() && std::memcmp(f.data() + at, ELFMAG, SELFMAG) == 0 &&
            f[at + EI_CLASS] == ELFCLASS64;
@@ -1551,7 +1550,7 @@ int mgx_stage_times(mgx_handle* h, float* ms) {
 }  // extern "C"
 extern "C" {
 int mgx_code_bytes(int32_t* bytes, int32_t capacity) {
-    if (!bytes || capacity < CODE_KERNELS * CODE_VARIANTS) return fail(MGX_ERR_ARGUMENT, "need room for 9 x 16 sizes");
+    if (!bytes || capacity < CODE_KERNELS * CODE_VARIANTS) return fail(MGX_ERR_ARGUMENT, "need room for 7 x 16 sizes");
     int found[CODE_KERNELS][CODE_VARIANTS];
     code_sizes_from_library(found);
     for (int c = 0; c < CODE_KERNELS; ++c)

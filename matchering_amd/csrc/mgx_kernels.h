@@ -99,12 +99,9 @@ __device__ int g_test_tail_launches;
 // measured: the limiter lost 14 us to the wait; so was warming again every 16th or 64th workgroup of an XCD, in
 // case the streamed audio pushes the code out of the L2 again: +6 / +13 us.)  Sizes come from the code object's
 // symbol table (mgx.hip, code_sizes_from_library); zero = no warming.
-enum { CODE_ANALYZE = 0, CODE_MATCH_CURVE, CODE_CONV_PREP, CODE_CONV, CODE_ROUND, CODE_TAIL, CODE_LIMIT, CODE_FIR_MATVEC,
-       CODE_FIR_TAPS, CODE_KERNELS };
+enum { CODE_ANALYZE = 0, CODE_MATCH_CURVE, CODE_CONV_PREP, CODE_CONV, CODE_ROUND, CODE_TAIL, CODE_LIMIT, CODE_KERNELS };
 constexpr int CODE_VARIANTS = 16;                                  // second index: log2 of the transform; 0 / 1 = 256 / 1024-block limiter
 __device__ int g_code_bytes[CODE_KERNELS][CODE_VARIANTS];
-// where each kernel's code starts, noted by the kernel itself the first time it runs (warm_code): what warm_next reads
-__device__ unsigned long long g_code_entry[CODE_KERNELS][CODE_VARIANTS];
 __device__ __forceinline__ void warm_code(int which, int variant = 0) {
     if (blockIdx.x >= 8 || threadIdx.x >= 64) return;             // workgroup b runs on XCD b % 8: one wave per L2
     const int bytes = g_code_bytes[which][variant];
@@ -116,30 +113,9 @@ __device__ __forceinline__ void warm_code(int which, int variant = 0) {
     const char* packet = (const char*)__builtin_amdgcn_dispatch_ptr();      // (constant address space -> generic)
     const char* descriptor = *reinterpret_cast<const char* const*>(packet + 32);
     const char* entry = descriptor + *reinterpret_cast<const long long*>(descriptor + 16);
-    if (blockIdx.x == 0 && threadIdx.x == 0) g_code_entry[which][variant] = reinterpret_cast<unsigned long long>(entry);
     int acc = 0;
     for (int off = (int)threadIdx.x * 64; off < bytes; off += 4096) acc += *reinterpret_cast<const volatile int*>(entry + off);
     if (acc == 0x7ffffff1) asm volatile("s_nop 0");                // (the sum is needed: the loads are waited for here)
-}
-
-// The NEXT kernel's code, read as data by eight workgroups of the current one (`slot` = 0..7, one per XCD; others
-// return at once): the launches of one mgx_master follow each other in a fixed order, and between the end of one
-// kernel and the first instruction fetches of the next nothing streams through the L2s -- the lines are still there
-// when the instruction caches ask for them.  The dependent chain of small kernels (level decisions, FIR design,
-// filter spectra) is mostly first-pass instruction fetch: 13 KB of k_match_curve are 1600 instructions at 4 ns each
-// from HBM on a fast box, 20 - 31 ns on a slow one, against 2 / 4 - 6 ns from the L2.  Addresses
-// come from g_code_entry, i.e. from the second call of a process on (the first call warms nothing ahead).
-__device__ __forceinline__ void warm_next(int slot, int which, int variant = 0) {
-#ifdef MGX_NO_WARM_NEXT                  // A/B builds only (python -m matchering_amd.build --variant nonext -DMGX_NO_WARM_NEXT)
-    return;
-#endif
-    if (slot < 0 || slot >= 8 || threadIdx.x >= 64) return;
-    const char* entry = reinterpret_cast<const char*>(g_code_entry[which][variant]);
-    const int bytes = g_code_bytes[which][variant];
-    if (!entry) return;
-    int acc = 0;
-    for (int off = (int)threadIdx.x * 64; off < bytes; off += 4096) acc += *reinterpret_cast<const volatile int*>(entry + off);
-    if (acc == 0x7ffffff1) asm volatile("s_nop 0");
 }
 
 // ---------------------------------------------------------------------------
@@ -314,7 +290,6 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         __syncthreads();
         pair = xcd * per + slots + *next_slot;
     }
-    warm_next((int)blockIdx.x, CODE_ROUND);                    // what runs next: round 0 of the level correction
     // the last workgroup to run out of pairs leaves the counters at zero for the next launch
     if (tid == 0 && atomicAdd(a.queue + 8, 1u) == gridDim.x - 1) {
         for (int i = 0; i < 9; ++i) a.queue[i] = 0;
@@ -423,13 +398,6 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
         a.wg_sumsq[wg] = ss;
         a.wg_peak[wg] = pk;
     }
-    // the last eight workgroups (consecutive numbers: one per XCD) pull in what runs next: the level decisions, the
-    // FIR design and the filter spectra
-    const int slot = (int)blockIdx.x - ((int)gridDim.x - 8);
-    warm_next(slot, CODE_MATCH_CURVE);
-    warm_next(slot, CODE_FIR_MATVEC);
-    warm_next(slot, CODE_FIR_TAPS);
-    warm_next(slot, CODE_CONV_PREP, LOG2N + 1);
 }
 
 // fft_size = 2 * Fft2<LOG2H>::N (analysis2_kernel.h, AnalysisDouble): the same grid layout and outputs, two
@@ -1006,13 +974,6 @@ __global__ __launch_bounds__(256) void k_fir_band(const double* M, int bins, int
 // row, both channels per pass, ten loads per thread in flight
 __global__ __launch_bounds__(256) void k_fir_matvec(FirPlanView pl, const double* M, const int2* band,
                                                     const double* raw, double* scratch) {
-    warm_code(CODE_FIR_MATVEC);
-    // (workgroups 8 .. 15, one per XCD: the convolution kernel's code, two launches and ~20 us ahead of its first fetch)
-    {
-        int log2f = 0;
-        while ((1 << log2f) < pl.fft) ++log2f;
-        warm_next((int)blockIdx.x - 8, CODE_CONV, log2f + 1);
-    }
     __shared__ double red[2][4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const double* m = M + (size_t)row * pl.bins;
@@ -1091,7 +1052,6 @@ __global__ __launch_bounds__(1024) void k_fir_b(FirPlanView pl, double* scratch)
 // it per workgroup was most of this kernel's time) and no gather through the L2.
 constexpr int TAP_ROWS = 8, TAP_SLICES = 1024 / TAP_ROWS;
 __global__ __launch_bounds__(1024) void k_fir_taps(FirPlanView pl, const double* scratch, float* taps /* [2][F] */) {
-    warm_code(CODE_FIR_TAPS);
     MGX_LDS;
     double* sm = reinterpret_cast<double*>(mgx_smem);       // [bins]
     double* red = sm + pl.bins;                             // [2][1024]: even-k and odd-k partial sums
@@ -1624,14 +1584,6 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
         }
     }
     const double s = block_sum<256>(acc, red);
-    if (a.build_band) {
-        // round 0 is the last kernel that streams before the limiter: its last eight workgroups (one per XCD) pull in
-        // the tail kernel's and the limiter's code -- the tail in between touches a few megabytes, the L2s keep both
-        const int slot = (int)blockIdx.x - ((int)gridDim.x - 8);
-        warm_next(slot, CODE_TAIL);
-        warm_next(slot, CODE_LIMIT, 0);
-        warm_next(slot, CODE_LIMIT, 1);
-    }
     if (a.build_band && a.tail_total > 0) {                              // uniform: k_correction_tail decides round 0
         if (threadIdx.x == 0) a.partial[blockIdx.x] = s;
         return;
