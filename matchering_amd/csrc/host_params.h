@@ -251,9 +251,10 @@ inline void limiter_fill(const LimiterParams& p, float threshold, LimiterArgs& a
     // quiet chunks: sum_{k<C} ar^(C-1-k) br ah^k = br (ar^C - ah^C) / (ar - ah), in extended precision
     const Wide ar = p.rel_f.alpha, ah = p.hold_f.alpha, gap = ar - ah;
     // (phase_quiet_store forms beta_r hc (ar^k - ah^k) / (ar - ah) in float32 from two v_exp_f32 results, 2e-7 relative
-    // each: the difference is good to ~4e-7 beta_r / |ar - ah| of hc.  Poles closer than 40 beta_r -- 1e-8 of hc --
-    // take the ordinary path, which runs the recurrence instead.  ADVICE round 3.)
-    a.quiet_ok = std::fabs((double)gap) > std::max(1e-9, 40.0 * std::fabs(p.rel_f.beta)) ? 1 : 0;
+    // each: the difference is good to ~4e-7 beta_r / |ar - ah| of hc.  Poles closer than 4 beta_r -- an error of 1e-7
+    // of the hold carry, a tenth of the limiter tests' bound -- take the ordinary path, which runs the recurrence
+    // instead; the default filters are 25 beta_r apart (1.6e-8).  ADVICE round 3.)
+    a.quiet_ok = std::fabs((double)gap) > std::max(1e-9, 4.0 * std::fabs(p.rel_f.beta)) ? 1 : 0;
     a.quiet_rel_gain = a.quiet_ok ? (double)((Wide)p.rel_f.beta * (std::pow(ar, (Wide)p.geo.chunk) - std::pow(ah, (Wide)p.geo.chunk)) / gap) : 0.0;
     a.log2_hold = (float)std::log2(p.hold_f.alpha);
     a.log2_rel = (float)std::log2(p.rel_f.alpha);

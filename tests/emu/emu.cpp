@@ -560,3 +560,13 @@ extern "C" int emu_spline(const double* x, const double* y, int n, const double*
     cubic_spline_nak(x, y, n, xq, nq, out);
     return 0;
 }
+
+// 1 when the closed-form quiet-chunk path of the limiter applies to these parameters, 0 when the pole gap is too small
+// for its float32 difference of exponentials, < 0 when the parameters are refused (host_params.h: limiter_fill)
+extern "C" int emu_limiter_quiet_ok(const mgx_config* cfg) {
+    LimiterParams lp;
+    if (!limiter_params(*cfg, lp).empty()) return -1;
+    LimiterArgs a;
+    limiter_fill(lp, (float)cfg->threshold, a);
+    return a.quiet_ok;
+}

@@ -359,3 +359,17 @@ def test_limiter_lengths_around_chunk_edges(emu, n):
     assert rc == 0
     want = mo.limit(y.astype(np.float64), mo.params())
     assert np.abs(out - want).max() <= 5e-6
+
+
+def test_quiet_chunk_path_applies_to_the_default_filters_and_not_to_close_poles(emu):
+    """limiter_fill (host_params.h) lets the closed-form quiet chunks run only where their float32 difference of two
+    exponentials is good to 1e-7 of the hold carry: |alpha_release - alpha_hold| > 4 beta_release.  The default
+    filters (7 Hz hold, 0.27 Hz release) are 25 beta apart and must qualify -- a stricter bound once switched the path
+    off for every default call, which only the HBM counters noticed (448 instead of 392 MB per limiter launch)."""
+    import matchering_amd as mg
+
+    assert emu.emu_limiter_quiet_ok(ctypes.byref(mg.Config().to_native())) == 1
+    assert emu.emu_limiter_quiet_ok(ctypes.byref(mg.Config(internal_sample_rate=96000).to_native())) == 1
+    # release pole moved onto the hold pole: 0.27 Hz * 26 = 7 Hz
+    close = mg.Config(limiter=mg.LimiterConfig(release_filter_coefficient=7.0 * 3000.0 * 1.0001))
+    assert emu.emu_limiter_quiet_ok(ctypes.byref(close.to_native())) == 0
