@@ -234,3 +234,30 @@ def test_gpu_six_lanes_side_by_side():
             if b < 4:
                 assert np.array_equal(triple[0], single[b][0])
             assert np.isfinite(triple[0]).all() and np.abs(triple[0]).max() <= 1.0
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_and_rccl_sees_them():
+    """``python bench.py --gpus 2`` with no launcher in front of it, on whatever GPUs
+    this box has: the script starts two rank processes, they meet over matchering_amd.ranks, master their own pairs
+    between two barriers, all-gather the FIR tables over RCCL and rank 0 prints ONE line.  On a one-GPU box the
+    ranks share the GPU and RCCL runs over its loop-back socket transport (bench.share_one_gpu_over_rccl)."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--workload", "8min_fir_only", "--no-traffic", "--no-gpu-state", "--no-cpu-baseline",
+                          "--no-secondary", "--spinup", "0.05"], capture_output=True, text=True, timeout=600, env=clean)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = run.stdout.splitlines()
+    assert len(lines) == 1, run.stdout[:2000]                    # the line and nothing else (RCCL's banner goes to stderr)
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["launch"] == "self" and line["value"] > 0
+    assert len(line["rank_seconds"]) == 2
+    exchange = line["rccl_fir_allgather"]
+    assert exchange["ok"] and exchange["ranks_seen"] == 2 and exchange["ranks_ok"] == 2 and exchange["distinct_tables"] == 2
+    assert line["roofline"]["frac"] > 0.0
