@@ -125,7 +125,10 @@ struct Analysis2Block {
         }
     }
     static MGX_HD void phase_fwd_mid(int tid, float2* lds, const float2* mid_table) {
-        if (F::P == 3) F::fwd_mid(tid, lds, mid_table);
+        if (F::P >= 3) F::fwd_mid(tid, lds, mid_table);
+    }
+    static MGX_HD void phase_fwd_mid2(int tid, float2* lds, const float2* mid_table) {
+        if (F::P == 4) F::fwd_mid2(tid, lds, mid_table);
     }
     // last forward pass on the thread's row.  Only the UPPER half of the row goes back to LDS (position order): that is
     // what the thread of the mirror row reads; the lower half -- and element RL/2, the self-mirrored bin on row 0 --

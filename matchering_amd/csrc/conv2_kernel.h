@@ -195,10 +195,17 @@ struct Conv2Block {
 
     // ---- middle passes --------------------------------------------------------------------------
     static MGX_HD void phase_fwd_mid(int tid, float2* lds, const float2* mid_table) {
-        if (F::P == 3) F::fwd_mid(tid, lds, mid_table);
+        if (F::P >= 3) F::fwd_mid(tid, lds, mid_table);
+    }
+    // the second middle pass of a four-pass plan (a barrier apart from the first)
+    static MGX_HD void phase_fwd_mid2(int tid, float2* lds, const float2* mid_table) {
+        if (F::P == 4) F::fwd_mid2(tid, lds, mid_table);
+    }
+    static MGX_HD void phase_inv_mid2(int tid, float2* lds, const float2* mid_table) {
+        if (F::P == 4) F::inv_mid2(tid, lds, mid_table);
     }
     static MGX_HD void phase_inv_mid(int tid, float2* lds, const float2* mid_table) {
-        if (F::P == 3) F::inv_mid(tid, lds, mid_table);
+        if (F::P >= 3) F::inv_mid(tid, lds, mid_table);
     }
 
     // ---- phase FPI: last forward pass, times H, first inverse pass, on the thread's row -------

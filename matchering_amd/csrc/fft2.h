@@ -1,7 +1,7 @@
 // LDS-resident complex FFT building blocks for gfx950 (wave64), float32 -- second generation.
 //
 // A transform of N = 2^LOG2N points lives in one workgroup's LDS as N float2 plus padding.
-// It is computed in P <= 3 passes of register radix-R butterflies, R in {8,16,32}; between
+// It is computed in P <= 4 passes of register radix-R butterflies, R in {8,16,32}; between
 // passes the data makes one round trip through LDS.  The forward transform is
 // decimation-in-frequency (natural order in, "position order" out), the inverse is its exact
 // mirror (decimation-in-time, position order in, natural order out), so nothing is ever
@@ -123,21 +123,30 @@ MGX_HD void dft_regs(float2 (&v)[R]) {
 // ---------------------------------------------------------------------------
 template <int LOG2N>
 struct Fft2Plan;
-#define MGX_PLAN(L, NP, A, B_, C_)                          \
+#define MGX_PLAN(L, NP, A, B_, C_, D_)                      \
     template <>                                             \
     struct Fft2Plan<L> {                                    \
         static constexpr int P = NP;                        \
-        static constexpr int LR[3] = {A, B_, C_};           \
+        static constexpr int LR[4] = {A, B_, C_, D_};       \
     };
-MGX_PLAN(6, 2, 3, 3, 0)
-MGX_PLAN(7, 2, 3, 4, 0)
-MGX_PLAN(8, 2, 4, 4, 0)
-MGX_PLAN(9, 2, 4, 5, 0)
-MGX_PLAN(10, 2, 5, 5, 0)
-MGX_PLAN(11, 3, 3, 3, 5)
-MGX_PLAN(12, 3, 4, 4, 4)
-MGX_PLAN(13, 3, 4, 4, 5)
-MGX_PLAN(14, 3, 4, 5, 5)
+MGX_PLAN(6, 2, 3, 3, 0, 0)
+MGX_PLAN(7, 2, 3, 4, 0, 0)
+MGX_PLAN(8, 2, 4, 4, 0, 0)
+MGX_PLAN(9, 2, 4, 5, 0, 0)
+MGX_PLAN(10, 2, 5, 5, 0, 0)
+MGX_PLAN(11, 3, 3, 3, 5, 0)
+MGX_PLAN(12, 3, 4, 4, 4, 0)
+MGX_PLAN(13, 3, 4, 4, 5, 0)
+// 16384 = 16 * 8 * 8 * 16 on 1024 threads (16 points per thread and pass: 128 VGPRs, four waves per SIMD) since round 4.
+// Until then 16 * 32 * 32 on 512 threads (32 points, 256 VGPRs, two waves per SIMD, 388 - 532 B of scratch in the
+// convolution kernels): one more round trip through LDS buys half the registers -- the plain 8192-tap convolution
+// went from 200 to 126 us, the partitioned 16384-tap one from 544 to 495, the analysis from 154 to 150
+// (profiles/r04_l_fft14_four_passes.txt).  -DMGX_FFT14_THREE_PASSES builds the old plan for an A/B.
+#ifdef MGX_FFT14_THREE_PASSES
+MGX_PLAN(14, 3, 4, 5, 5, 0)
+#else
+MGX_PLAN(14, 4, 4, 3, 3, 4)
+#endif
 #undef MGX_PLAN
 
 template <int LOG2N>
@@ -191,6 +200,8 @@ struct Fft2 {
     static_assert(!PADDED || P == 1 || S(0) % RL == 0, "padded strides are multiples of the row length");
     static_assert(P < 3 || T % S(1) == 0, "one middle-pass twiddle set per thread");
     static_assert(!PADDED || P < 3 || S(1) % RL == 0, "padded strides are multiples of the row length");
+    static_assert(P < 4 || (T % S(2) == 0 && (!PADDED || S(2) % RL == 0)), "the same for the second middle pass");
+    static_assert(P <= 4, "at most two middle passes");
 
     // twiddle exponent (units of 2*pi/N) for output q of butterfly u in pass p: (u % S)*q*(N/M)
     template <int PASS>
@@ -222,14 +233,22 @@ struct Fft2 {
             f.w[q - 1] = q == hb ? t.b[ilog2(hb)] : cmul(t.b[ilog2(hb)], f.w[q - hb - 1]);
         }
     }
-    // middle pass (P == 3): (R1-1)*S1 entries in LDS, [q-1][n]
-    static constexpr int MID = 1;
-    static constexpr int MID_TABLE = P == 3 ? (R(1) - 1) * S(1) : 0;
+    // middle passes (P >= 3): (R_p - 1) * S_p entries in LDS per pass, [q-1][n]; the second pass's table (P == 4)
+    // follows the first
+    static constexpr int MID = 1, MID2 = P == 4 ? 2 : 1;
+    static constexpr int MID_TABLE1 = P >= 3 ? (R(1) - 1) * S(1) : 0;
+    static constexpr int MID_TABLE = MID_TABLE1 + (P == 4 ? (R(2) - 1) * S(2) : 0);
     static MGX_HD void fill_mid_table(int tid, const float2* tw, float2* table) {
-        if (P == 3) {
-            for (int e = tid; e < MID_TABLE; e += T) {
+        if (P >= 3) {
+            for (int e = tid; e < MID_TABLE1; e += T) {
                 const int q = e / S(MID) + 1, n = e % S(MID);
                 table[e] = tw[tw_index<MID>(n, q)];
+            }
+        }
+        if (P == 4) {
+            for (int e = tid; e < MID_TABLE - MID_TABLE1; e += T) {
+                const int q = e / S(MID2) + 1, n = e % S(MID2);
+                table[MID_TABLE1 + e] = tw[tw_index<MID2>(n, q)];
             }
         }
     }
@@ -268,49 +287,56 @@ struct Fft2 {
         dft_regs<R0, true>(v);
     }
 
-    // ---- middle pass (P == 3), LDS -> LDS ---------------------------------------------------
-    static MGX_HD void fwd_mid(int tid, float2* lds, const float2* table) {
-        constexpr int r = R(MID), bits = lr(MID), s = S(MID);
+    // ---- middle passes (P >= 3), LDS -> LDS --------------------------------------------------
+    template <int PASS>
+    static MGX_HD void fwd_mid_pass(int tid, float2* lds, const float2* table) {
+        constexpr int r = R(PASS), bits = lr(PASS), s = S(PASS);
         float2 w[r - 1];
         const int n = tid % s;
         MGX_UNROLL
         for (int q = 1; q < r; ++q) w[q - 1] = table[(q - 1) * s + n];
         MGX_UNROLL
-        for (int c = 0; c < CNT(MID); ++c) {
-            float2* p = lds + base<MID>(tid + c * T);
+        for (int c = 0; c < CNT(PASS); ++c) {
+            float2* p = lds + base<PASS>(tid + c * T);
             float2 v[r];
             MGX_UNROLL
-            for (int j = 0; j < r; ++j) v[j] = p[off<MID>(j)];
+            for (int j = 0; j < r; ++j) v[j] = p[off<PASS>(j)];
             dft_regs<r, false>(v);
             MGX_UNROLL
             for (int q = 0; q < r; ++q) {
                 float2 x = v[bitrev(q, bits)];
                 if (q != 0) x = cmul(x, w[q - 1]);
-                p[off<MID>(q)] = x;
+                p[off<PASS>(q)] = x;
             }
         }
     }
-    static MGX_HD void inv_mid(int tid, float2* lds, const float2* table) {
-        constexpr int r = R(MID), bits = lr(MID), s = S(MID);
+    template <int PASS>
+    static MGX_HD void inv_mid_pass(int tid, float2* lds, const float2* table) {
+        constexpr int r = R(PASS), bits = lr(PASS), s = S(PASS);
         float2 w[r - 1];
         const int n = tid % s;
         MGX_UNROLL
         for (int q = 1; q < r; ++q) w[q - 1] = table[(q - 1) * s + n];
         MGX_UNROLL
-        for (int c = 0; c < CNT(MID); ++c) {
-            float2* p = lds + base<MID>(tid + c * T);
+        for (int c = 0; c < CNT(PASS); ++c) {
+            float2* p = lds + base<PASS>(tid + c * T);
             float2 v[r];
             MGX_UNROLL
             for (int q = 0; q < r; ++q) {
-                float2 x = p[off<MID>(q)];
+                float2 x = p[off<PASS>(q)];
                 if (q != 0) x = cmulc(x, w[q - 1]);
                 v[bitrev(q, bits)] = x;
             }
             dft_regs<r, true>(v);
             MGX_UNROLL
-            for (int j = 0; j < r; ++j) p[off<MID>(j)] = v[j];
+            for (int j = 0; j < r; ++j) p[off<PASS>(j)] = v[j];
         }
     }
+    // pass 1 (P >= 3) and pass 2 (P == 4); a barrier belongs between any two of them
+    static MGX_HD void fwd_mid(int tid, float2* lds, const float2* table) { fwd_mid_pass<MID>(tid, lds, table); }
+    static MGX_HD void inv_mid(int tid, float2* lds, const float2* table) { inv_mid_pass<MID>(tid, lds, table); }
+    static MGX_HD void fwd_mid2(int tid, float2* lds, const float2* table) { fwd_mid_pass<MID2>(tid, lds, table + MID_TABLE1); }
+    static MGX_HD void inv_mid2(int tid, float2* lds, const float2* table) { inv_mid_pass<MID2>(tid, lds, table + MID_TABLE1); }
 
     // ---- last pass: one contiguous row per thread -------------------------------------------
     static MGX_HD bool has_row(int tid) { return !partial(LAST) || tid < L; }

@@ -163,13 +163,21 @@ __device__ __forceinline__ void conv_channel(int tid, const Conv2Args& a, float2
     __builtin_amdgcn_sched_barrier(0);
     CB::fetch_filter(tid, SIDE ? a.h_side : a.h_mid, rf);      // a phase early: the middle pass hides its latency
     __syncthreads();
-    if (F::P == 3) {
+    if (F::P >= 3) {
         CB::phase_fwd_mid(opaque(tid), lds, mid_table);
+        __syncthreads();
+    }
+    if (F::P == 4) {
+        CB::phase_fwd_mid2(opaque(tid), lds, mid_table);
         __syncthreads();
     }
     CB::phase_filter(tid, rf, lds);
     __syncthreads();
-    if (F::P == 3) {
+    if (F::P == 4) {
+        CB::phase_inv_mid2(opaque(tid), lds, mid_table);
+        __syncthreads();
+    }
+    if (F::P >= 3) {
         CB::phase_inv_mid(opaque(tid), lds, mid_table);
         __syncthreads();
     }
@@ -194,8 +202,12 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
         __builtin_amdgcn_sched_barrier(0);
         if (!LATE_FILTER) CB::fetch_filter(tid, h + (size_t)k * F::N, rf);
         __syncthreads();
-        if (F::P == 3) {
+        if (F::P >= 3) {
             CB::phase_fwd_mid(opaque(tid), lds, mid_table);
+            __syncthreads();
+        }
+        if (F::P == 4) {
+            CB::phase_fwd_mid2(opaque(tid), lds, mid_table);
             __syncthreads();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -207,7 +219,11 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
     CB::phase_finish_row(tid, acc, lds);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (F::P == 3) {
+    if (F::P == 4) {
+        CB::phase_inv_mid2(opaque(tid), lds, mid_table);
+        __syncthreads();
+    }
+    if (F::P >= 3) {
         CB::phase_inv_mid(opaque(tid), lds, mid_table);
         __syncthreads();
     }
@@ -313,8 +329,12 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_prep(const float* tap
     CB::load_persist(tid, tw, mid_table, ps);
     CB::phase_load_taps(tid, taps + ((size_t)ch * parts + k) * CB::TAPS, ps, lds);
     __syncthreads();
-    if (F::P == 3) {
+    if (F::P >= 3) {
         CB::phase_fwd_mid(tid, lds, mid_table);
+        __syncthreads();
+    }
+    if (F::P == 4) {
+        CB::phase_fwd_mid2(tid, lds, mid_table);
         __syncthreads();
     }
     CB::phase_write_filter(tid, lds, (float)(g / (double)F::N), tables + ((size_t)ch * parts + k) * F::N);
@@ -325,7 +345,8 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_prep(const float* tap
 // ---------------------------------------------------------------------------
 template <int LOG2N>
 constexpr size_t analysis_lds_bytes() {
-    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 128;
+    // (+ 16 doubles and 16 floats of reduction scratch: one slot per wave of a workgroup of up to 1024 threads)
+    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 192;
 }
 
 // waves per SIMD the LDS footprint admits (4 SIMDs per CU): the register budget follows from it
@@ -352,7 +373,7 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
     float2* mid_table = lds + F::LDS_ELEMS;
     double* dscratch = reinterpret_cast<double*>(mid_table + F::MID_TABLE);
-    float* fscratch = reinterpret_cast<float*>(dscratch + 8);
+    float* fscratch = reinterpret_cast<float*>(dscratch + 16);      // (16 wave slots each: 1024-thread plans)
     const bool second = (int)blockIdx.x >= nwg0;                 // uniform
     const AnalysisArgs& a = second ? a1 : a0;
     const int tid = threadIdx.x, wg = second ? blockIdx.x - nwg0 : blockIdx.x;
@@ -375,8 +396,12 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
         AB::fetch(tid, (long long)d * a.piece + (long long)s * F::N, a, raw);
         AB::phase_load(tid, raw, ps, th, lds);
         lds_barrier();
-        if (F::P == 3) {
+        if (F::P >= 3) {
             AB::phase_fwd_mid(tid, lds, mid_table);
+            lds_barrier();
+        }
+        if (F::P == 4) {
+            AB::phase_fwd_mid2(tid, lds, mid_table);
             lds_barrier();
         }
         typename AB::Row own;
@@ -412,7 +437,7 @@ __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) v
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
     float2* mid_table = lds + F::LDS_ELEMS;
     double* dscratch = reinterpret_cast<double*>(mid_table + F::MID_TABLE);
-    float* fscratch = reinterpret_cast<float*>(dscratch + 8);
+    float* fscratch = reinterpret_cast<float*>(dscratch + 16);      // (16 wave slots each: 1024-thread plans)
     const bool second = (int)blockIdx.x >= nwg0;                 // uniform
     const AnalysisArgs& a = second ? a1 : a0;
     const int tid = threadIdx.x, wg = second ? blockIdx.x - nwg0 : blockIdx.x;
@@ -428,8 +453,12 @@ __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) v
         const long long start = (long long)d * a.piece + (long long)s * 2 * F::N;
         AD::template phase_load<false>(tid, start, a, ps, th, lds);
         lds_barrier();
-        if (F::P == 3) {
+        if (F::P >= 3) {
             AD::AB::phase_fwd_mid(tid, lds, mid_table);
+            lds_barrier();
+        }
+        if (F::P == 4) {
+            AD::AB::phase_fwd_mid2(tid, lds, mid_table);
             lds_barrier();
         }
         AD::phase_row(tid, lds);
@@ -438,8 +467,12 @@ __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) v
         lds_barrier();
         AD::template phase_load<true>(tid, start, a, ps, th, lds);
         lds_barrier();
-        if (F::P == 3) {
+        if (F::P >= 3) {
             AD::AB::phase_fwd_mid(tid, lds, mid_table);
+            lds_barrier();
+        }
+        if (F::P == 4) {
+            AD::AB::phase_fwd_mid2(tid, lds, mid_table);
             lds_barrier();
         }
         AD::phase_row(tid, lds);

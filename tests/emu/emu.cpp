@@ -32,10 +32,13 @@ static std::vector<float2> twiddles(int n) {
 // on the GPU) is emulated as its two halves in separate thread loops.
 template <class F>
 static void mid_pass(bool inverse, float2* lds, const float2* table) {
-    if (F::P != 3) return;
-    {
-        if (inverse) { FOR_THREADS(F::T) F::inv_mid(tid, lds, table); }
-        else { FOR_THREADS(F::T) F::fwd_mid(tid, lds, table); }
+    if (F::P < 3) return;
+    if (inverse) {
+        if (F::P == 4) { FOR_THREADS(F::T) F::inv_mid2(tid, lds, table); }
+        FOR_THREADS(F::T) F::inv_mid(tid, lds, table);
+    } else {
+        FOR_THREADS(F::T) F::fwd_mid(tid, lds, table);
+        if (F::P == 4) { FOR_THREADS(F::T) F::fwd_mid2(tid, lds, table); }
     }
 }
 

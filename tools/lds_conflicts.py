@@ -41,7 +41,7 @@ def cycles(byte_addr_of_lane, kind):
     return total, len(groups)
 
 
-PLANS = {9: (4, 5), 10: (5, 5), 11: (3, 3, 5), 12: (4, 4, 4), 13: (4, 4, 5), 14: (4, 5, 5)}   # fft2.h
+PLANS = {9: (4, 5), 10: (5, 5), 11: (3, 3, 5), 12: (4, 4, 4), 13: (4, 4, 5), 14: (4, 3, 3, 4)}   # fft2.h
 
 
 def pad(i, lrl):
