@@ -136,7 +136,11 @@ MGX_PLAN(9, 2, 4, 5, 0, 0)
 MGX_PLAN(10, 2, 5, 5, 0, 0)
 MGX_PLAN(11, 3, 3, 3, 5, 0)
 MGX_PLAN(12, 3, 4, 4, 4, 0)
+#ifdef MGX_FFT13_FOUR_PASSES          // A/B build: 8192 = 8 * 8 * 8 * 16 on 512 threads (16 points per thread)
+MGX_PLAN(13, 4, 3, 3, 3, 4)
+#else
 MGX_PLAN(13, 3, 4, 4, 5, 0)
+#endif
 // 16384 = 16 * 8 * 8 * 16 on 1024 threads (16 points per thread and pass: 128 VGPRs, four waves per SIMD) since round 4.
 // Until then 16 * 32 * 32 on 512 threads (32 points, 256 VGPRs, two waves per SIMD, 388 - 532 B of scratch in the
 // convolution kernels): one more round trip through LDS buys half the registers -- the plain 8192-tap convolution

@@ -123,7 +123,8 @@ __device__ __forceinline__ void warm_code(int which, int variant = 0) {
 // ---------------------------------------------------------------------------
 template <int LOG2N>
 constexpr size_t conv_lds_bytes() {
-    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 128;
+    // (+ 16 floats for block_max and one int, the next pair's number: see k_conv)
+    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 80;
 }
 
 // The phases of a kernel share index arithmetic (LDS addresses derived from the thread id).  Left
@@ -345,8 +346,8 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_prep(const float* tap
 // ---------------------------------------------------------------------------
 template <int LOG2N>
 constexpr size_t analysis_lds_bytes() {
-    // (+ 16 doubles and 16 floats of reduction scratch: one slot per wave of a workgroup of up to 1024 threads)
-    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + 192;
+    // (+ a double and a float of reduction scratch per wave of the workgroup)
+    return ((size_t)Fft2<LOG2N>::LDS_ELEMS + Fft2<LOG2N>::MID_TABLE) * sizeof(float2) + (Fft2<LOG2N>::T / 64) * 12;
 }
 
 // waves per SIMD the LDS footprint admits (4 SIMDs per CU): the register budget follows from it
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
     float2* mid_table = lds + F::LDS_ELEMS;
     double* dscratch = reinterpret_cast<double*>(mid_table + F::MID_TABLE);
-    float* fscratch = reinterpret_cast<float*>(dscratch + 16);      // (16 wave slots each: 1024-thread plans)
+    float* fscratch = reinterpret_cast<float*>(dscratch + F::T / 64);   // (one slot per wave each)
     const bool second = (int)blockIdx.x >= nwg0;                 // uniform
     const AnalysisArgs& a = second ? a1 : a0;
     const int tid = threadIdx.x, wg = second ? blockIdx.x - nwg0 : blockIdx.x;
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) v
     float2* lds = reinterpret_cast<float2*>(mgx_smem);
     float2* mid_table = lds + F::LDS_ELEMS;
     double* dscratch = reinterpret_cast<double*>(mid_table + F::MID_TABLE);
-    float* fscratch = reinterpret_cast<float*>(dscratch + 16);      // (16 wave slots each: 1024-thread plans)
+    float* fscratch = reinterpret_cast<float*>(dscratch + F::T / 64);   // (one slot per wave each)
     const bool second = (int)blockIdx.x >= nwg0;                 // uniform
     const AnalysisArgs& a = second ? a1 : a0;
     const int tid = threadIdx.x, wg = second ? blockIdx.x - nwg0 : blockIdx.x;
