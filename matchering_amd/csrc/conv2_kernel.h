@@ -50,6 +50,7 @@ struct Conv2Args {
     long long npairs;      // ceil(n / N)
     float* pair_peak;      // [npairs] max(|yL|,|yR|) per pair, or nullptr
     unsigned* queue;       // [8] pairs handed out per XCD beyond the first round, [8] workgroups done; zero between launches
+    int run;               // k_conv_delay: blocks per workgroup (npairs counts blocks there)
 };
 
 template <int LOG2N>

@@ -678,6 +678,39 @@ static int launch_conv(mgx_handle* h, Conv2Args a, const float* taps_dev, double
     return 0;
 }
 
+// taps = N in two partitions (config #5: 16384 taps on N = 16384 blocks): the frequency-domain delay line of
+// conv_delay_kernel.h, a run of consecutive blocks per workgroup (one workgroup per CU: every run costs one extra
+// forward transform, so runs are as long as the chip allows).  a.npairs counts blocks on return.
+template <int LOG2N>
+static int launch_conv_delay(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr) {
+    using F = Fft2<LOG2N>;
+    const size_t lds = conv_lds_bytes<LOG2N>();
+    MGX_TRY((allow_lds(k_conv_prep<LOG2N>, lds)));
+    MGX_TRY((allow_lds(k_conv_delay<LOG2N>, lds)));
+    {
+        StageScope scope(h, MGX_STAGE_FILTER_SPECTRA);
+        hipLaunchKernelGGL((k_conv_prep<LOG2N>), dim3(2 * a.parts), dim3(F::T), lds, h->stream, taps_dev,
+                           a.tw, (float2*)h->filt.p, a.parts, gain_ptr, gain);
+    }
+    HIP_TRY(hipGetLastError());
+    a.npairs = (a.n + ConvDelay<LOG2N>::HOP - 1) / ConvDelay<LOG2N>::HOP;
+    MGX_TRY(ensure(h, h->block_peak, (size_t)a.npairs * sizeof(float)));
+    a.pair_peak = (float*)h->block_peak.p;
+    a.queue = nullptr;
+    int dev_cus = 256;
+    HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    const int per_cu = std::max(1, std::min(2048 / F::T, (int)((size_t)160 * 1024 / lds)));
+    const long long cap = (long long)dev_cus * per_cu;
+    a.run = (int)std::max<long long>(1, (a.npairs + cap - 1) / cap);
+    const unsigned grid = (unsigned)((a.npairs + a.run - 1) / a.run);
+    {
+        StageScope scope(h, MGX_STAGE_CONVOLVE);
+        hipLaunchKernelGGL((k_conv_delay<LOG2N>), dim3(grid), dim3(F::T), lds, h->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // taps_dev: [2][F] float (mid then side) already on the device.  F <= 8192: one overlap-save block of
 // N = 2F per filter; longer filters (config #5: 16 k taps at 96 kHz) are cut into K = F/8192
 // partitions on N = 16384 blocks (uniformly partitioned overlap-save), because N = 2F no longer fits
@@ -720,6 +753,12 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
     a.npairs = (n + pair_frames - 1) / pair_frames;
     a.pair_peak = nullptr;
     MGX_TRY(get_twiddles(h, log2b, &a.tw));
+    a.run = 0;
+    const char* no_delay = std::getenv("MGX_NO_CONV_DELAY");
+    if (parts == 2 && !(no_delay && no_delay[0] == '1')) {      // (the variable: A/B against the partitioned kernel)
+        if (npairs_out) *npairs_out = (n + (long long)nb / 2 - 1) / ((long long)nb / 2);
+        return launch_conv_delay<LONG_FIR_LOG2N>(h, a, taps_dev, gain, gain_ptr);
+    }
     if (npairs_out) *npairs_out = a.npairs;
     if (parts > 1) return launch_conv<LONG_FIR_LOG2N, true>(h, a, taps_dev, gain, gain_ptr);
     switch (log2b) {

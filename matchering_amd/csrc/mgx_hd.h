@@ -30,6 +30,31 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 #endif
 #endif
 
+// A point the compiler's scheduler may not move instructions across (device code only): keeps a phase's
+// global loads from being issued all at once when the registers to hold them do not exist.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_HOST_EMU)
+#define MGX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MGX_SCHED_FENCE() ((void)0)
+#endif
+
+// A value the compiler must take as new at this point (device code only): whatever is derived from it -- a load's
+// address -- cannot be computed, or the load issued, any earlier.
+static MGX_HD int mgx_opaque(int v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_HOST_EMU)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
+// ... and a value that must EXIST at this point: keeps the arithmetic that produces it from sinking below later
+// loads (whose results would then all be alive at once).
+static MGX_HD void mgx_pin(float2& v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_HOST_EMU)
+    asm volatile("" : "+v"(v.x), "+v"(v.y));
+#endif
+}
+
 // float32 complex helpers: their adds may fuse with the multiply that feeds them (fft2.h: the one place
 // of a library built with -ffp-contract=off where contraction is let in)
 #if defined(__clang__)

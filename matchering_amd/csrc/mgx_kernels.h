@@ -8,6 +8,7 @@
 
 #include "analysis2_kernel.h"
 #include "conv2_kernel.h"
+#include "conv_delay_kernel.h"
 #include "fir_plan.h"
 #include "limiter_general.h"
 
@@ -310,6 +311,65 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
     // the last workgroup to run out of pairs leaves the counters at zero for the next launch
     if (tid == 0 && atomicAdd(a.queue + 8, 1u) == gridDim.x - 1) {
         for (int i = 0; i < 9; ++i) a.queue[i] = 0;
+    }
+}
+
+// A filter of two partitions as a frequency-domain delay line (conv_delay_kernel.h): workgroup w takes blocks
+// [w * run, (w + 1) * run) one after the other, the partition-1 product of a block carried to the next in registers;
+// it starts with the forward transform of block w * run - 1 (carry only).  a.npairs counts BLOCKS here and
+// pair_peak has one entry per block.
+template <int LOG2N>
+__global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) void k_conv_delay(Conv2Args a) {
+    using CD = ConvDelay<LOG2N>;
+    using CB = Conv2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
+    MGX_LDS;
+    float2* lds = reinterpret_cast<float2*>(mgx_smem);
+    float2* mid_table = lds + F::LDS_ELEMS;
+    float* scratch = reinterpret_cast<float*>(mid_table + F::MID_TABLE);
+    const int tid = threadIdx.x;
+    typename CB::Persist ps;
+    CB::load_persist(tid, a.tw, mid_table, ps);
+    __syncthreads();
+    const long long first = (long long)blockIdx.x * a.run;
+    const long long end = min(a.npairs, first + a.run);
+    typename CD::Carry carry;
+    CD::clear(carry);
+    for (long long b = first - 1; b < end; ++b) {
+        // (as in k_conv: nothing derived from the pass-0 twiddles or the thread id may be hoisted out of the loop)
+#pragma unroll
+        for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
+        CD::phase_load(opaque(tid), b, a, ps, lds);
+        __syncthreads();
+        if (F::P >= 3) {
+            CB::phase_fwd_mid(opaque(tid), lds, mid_table);
+            __syncthreads();
+        }
+        if (F::P == 4) {
+            CB::phase_fwd_mid2(opaque(tid), lds, mid_table);
+            __syncthreads();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        typename CD::Row own;
+        CD::phase_row(opaque(tid), own, lds);
+        __syncthreads();
+        CD::phase_multiply(opaque(tid), a, own, carry, lds);
+        __syncthreads();                    // every mirror row has been read: the rows may be written again
+        __builtin_amdgcn_sched_barrier(0);
+        if (b < first) continue;            // (uniform) the block in front of the run: its carry only
+        CD::phase_row_back(opaque(tid), own, lds);
+        __syncthreads();
+        if (F::P == 4) {
+            CB::phase_inv_mid2(opaque(tid), lds, mid_table);
+            __syncthreads();
+        }
+        if (F::P >= 3) {
+            CB::phase_inv_mid(opaque(tid), lds, mid_table);
+            __syncthreads();
+        }
+        const float pk = CD::phase_store(opaque(tid), b, a, ps, lds);
+        const float bp = block_max<F::T>(pk, scratch);          // (a barrier inside: the LDS is free for the next block)
+        if (tid == 0 && a.pair_peak) a.pair_peak[b] = bp;
     }
 }
 

@@ -13,6 +13,7 @@
 
 #include "../../matchering_amd/csrc/analysis2_kernel.h"
 #include "../../matchering_amd/csrc/conv2_kernel.h"
+#include "../../matchering_amd/csrc/conv_delay_kernel.h"
 #include "../../matchering_amd/csrc/fir_design.h"
 #include "../../matchering_amd/csrc/host_params.h"
 
@@ -136,6 +137,71 @@ extern "C" int emu_convolve_blocked(const float* x, long long n, const double* f
 extern "C" int emu_convolve(const float* x, long long n, const double* fir_mid, const double* fir_side,
                             int taps, double gain, float* y, float* ymid, double* peak) {
     return emu_convolve_blocked(x, n, fir_mid, fir_side, taps, gain, y, ymid, peak, 0);
+}
+
+// ---------------------------------------------------------------------------
+// taps = N in two partitions as a frequency-domain delay line (conv_delay_kernel.h): the phase sequence of
+// k_conv_delay in mgx_kernels.h, workgroups of `run` consecutive blocks each
+template <int LOG2N>
+static int conv_delay_impl(const float* x, long long n, const double* fir_mid, const double* fir_side, int taps,
+                           double gain, float* y, float* ymid, float* block_peak, int run) {
+    using CD = ConvDelay<LOG2N>;
+    using CB = Conv2Block<LOG2N>;
+    using F = typename CB::F;
+    if (taps != F::N || run < 1) return -1;
+    const int parts = 2;
+    const std::vector<float2> tw = twiddles(F::N);
+    std::vector<float2> lds(F::LDS_ELEMS), mid_table(F::MID_TABLE + 1), tables((size_t)2 * parts * F::N);
+    std::vector<float> h(2 * taps);
+    for (int i = 0; i < taps; ++i) { h[i] = (float)fir_mid[i]; h[taps + i] = (float)fir_side[i]; }
+    std::vector<typename CB::Persist> ps(F::T);
+    FOR_THREADS(F::T) CB::load_persist(tid, tw.data(), mid_table.data(), ps[tid]);
+    for (int ch = 0; ch < 2; ++ch)
+        for (int k = 0; k < parts; ++k) {
+            FOR_THREADS(F::T) CB::phase_load_taps(tid, h.data() + ((size_t)ch * parts + k) * CB::TAPS, ps[tid], lds.data());
+            mid_pass<F>(false, lds.data(), mid_table.data());
+            FOR_THREADS(F::T) CB::phase_write_filter(tid, lds.data(), (float)(gain / F::N),
+                                                     tables.data() + ((size_t)ch * parts + k) * F::N);
+        }
+    Conv2Args a;
+    a.x = reinterpret_cast<const float2*>(x);
+    a.n = n;
+    a.y = reinterpret_cast<float2*>(y);
+    a.ymid = ymid;
+    a.h_mid = tables.data();
+    a.h_side = tables.data() + (size_t)parts * F::N;
+    a.tw = tw.data();
+    a.parts = parts;
+    a.npairs = (n + CD::HOP - 1) / CD::HOP;              // blocks
+    a.pair_peak = nullptr;
+    std::vector<typename CD::Row> own(F::T);
+    std::vector<typename CD::Carry> carry(F::T);
+    for (long long first = 0; first < a.npairs; first += run) {          // one workgroup
+        const long long end = std::min<long long>(a.npairs, first + run);
+        FOR_THREADS(F::T) CD::clear(carry[tid]);
+        for (long long b = first - 1; b < end; ++b) {
+            FOR_THREADS(F::T) CD::phase_load(tid, b, a, ps[tid], lds.data());
+            mid_pass<F>(false, lds.data(), mid_table.data());
+            FOR_THREADS(F::T) CD::phase_row(tid, own[tid], lds.data());
+            FOR_THREADS(F::T) CD::phase_multiply(tid, a, own[tid], carry[tid], lds.data());
+            if (b < first) continue;                                       // the block in front of the run: carry only
+            FOR_THREADS(F::T) CD::phase_row_back(tid, own[tid], lds.data());
+            mid_pass<F>(true, lds.data(), mid_table.data());
+            float pk = 0.f;
+            FOR_THREADS(F::T) pk = std::fmax(pk, CD::phase_store(tid, b, a, ps[tid], lds.data()));
+            if (block_peak) block_peak[b] = pk;
+        }
+    }
+    return 0;
+}
+extern "C" int emu_convolve_delay(const float* x, long long n, const double* fir_mid, const double* fir_side, int taps,
+                                  double gain, float* y, float* ymid, float* block_peak, int run) {
+    switch (ilog2_exact(taps)) {
+#define CASE(L) case L: return conv_delay_impl<L>(x, n, fir_mid, fir_side, taps, gain, y, ymid, block_peak, run);
+        CASE(11) CASE(12) CASE(13) CASE(14)
+#undef CASE
+        default: return -4;
+    }
 }
 
 // ---------------------------------------------------------------------------

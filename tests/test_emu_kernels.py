@@ -87,6 +87,32 @@ def test_partitioned_convolution_phases(emu, taps, block_log2, n):
     assert abs(peak.value - np.abs(y).max()) <= 1e-6
 
 
+@pytest.mark.parametrize("taps,n,run", [(2048, 1, 1), (2048, 1024, 1), (2048, 9001, 3), (4096, 30000, 4),
+                                        (8192, 8 * 4096 + 77, 2), (16384, 5 * 8192 + 1234, 3), (16384, 3000, 11)])
+def test_delay_line_convolution_phases(emu, taps, n, run):
+    """A filter of two partitions (taps = N, config #5's 16384 taps) as a frequency-domain delay line:
+    mid + j side in ONE transform per block, un-mixed through the mirror bin at the multiply, partition 1's
+    product carried to the next block of the workgroup's run (conv_delay_kernel.h).  Against the same direct
+    convolution as the kernels above, over runs that end inside and beyond the track."""
+    rng = np.random.RandomState(taps + n)
+    x = np.ascontiguousarray((0.3 * rng.randn(n, 2)).astype(np.float32))
+    hm, hs = rng.randn(taps) / np.sqrt(taps), rng.randn(taps) / np.sqrt(taps)
+    y = np.zeros((n, 2), dtype=np.float32)
+    ymid = np.zeros(n, dtype=np.float32)
+    nblocks = (n + taps // 2 - 1) // (taps // 2)
+    peaks = np.zeros(nblocks, dtype=np.float32)
+    rc = emu.emu_convolve_delay(_fp(x), ctypes.c_longlong(n), _dp(hm), _dp(hs), ctypes.c_int(taps),
+                                ctypes.c_double(0.8), _fp(y), _fp(ymid), _fp(peaks), ctypes.c_int(run))
+    assert rc == 0
+    mid, side = mo.mid_side(x.astype(np.float64))
+    want, want_mid = mo.convolve_same(mid * 0.8, hm, side * 0.8, hs)
+    assert rms_error(y, want) <= 1e-6
+    assert rms_error(ymid, want_mid) <= 1e-6
+    hop = taps // 2
+    for b in range(nblocks):
+        assert abs(peaks[b] - np.abs(y[b * hop:(b + 1) * hop]).max()) <= 1e-6
+
+
 def test_convolution_identity(emu):
     # scipy "same" centring (match_frequencies.py:112): delta at (F-1)//2 is the identity
     rng = np.random.RandomState(5)

@@ -177,6 +177,28 @@ def test_partitioned_convolution_stage(taps):
     assert abs(peak - np.abs(y).max()) <= 1e-6
 
 
+@pytest.mark.parametrize("n", [1, 8191, 8192, 3 * 8192, 300 * 8192 + 4321, 1500 * 8192 + 17])
+def test_two_partition_filter_as_a_delay_line(n, monkeypatch):
+    """16384 taps on 16384-point blocks (config #5): one transform per block for both channels, partition 1's
+    product carried from block to block of a workgroup's run (k_conv_delay).  Track lengths from one frame to runs of
+    six blocks per workgroup, against fftconvolve and against the partitioned kernel it replaces."""
+    from matchering_amd import kernels
+
+    taps = 16384
+    rng = np.random.RandomState(n % 100000)
+    x = (0.3 * rng.randn(n, 2)).astype(np.float32)
+    hm, hs = rng.randn(taps) / np.sqrt(taps), rng.randn(taps) / np.sqrt(taps)
+    y, ymid, peak = kernels.convolve(x, hm, hs, gain=0.9)
+    mid, side = mo.mid_side(x.astype(np.float64))
+    want, want_mid = mo.convolve_same(mid * 0.9, hm, side * 0.9, hs)
+    assert rms_error(y, want) <= 1e-6
+    assert rms_error(ymid, want_mid) <= 1e-6
+    assert abs(peak - np.abs(y).max()) <= 1e-6
+    monkeypatch.setenv("MGX_NO_CONV_DELAY", "1")
+    y2, ymid2, peak2 = kernels.convolve(x, hm, hs, gain=0.9)
+    assert np.abs(y - y2).max() <= 5e-6 and np.abs(ymid - ymid2).max() <= 5e-6 and abs(peak - peak2) <= 5e-6
+
+
 def test_master_long_fir_96k():
     """BASELINE config #5 in miniature: 96 kHz, fft_size 16384 (16 k-tap matching FIR), full pipeline
     against the oracle."""
