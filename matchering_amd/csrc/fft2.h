@@ -16,9 +16,9 @@
 // Design rules (tools/lds_conflicts.py checks the LDS ones against the gfx950 bank model):
 //  * The last pass has S = 1: a thread owns ONE contiguous row of RL float2 (RL = 32, or 16 for
 //    N = 4096) which it moves with 16-byte LDS accesses; T = N/RL threads (>= 64).  Thread t owns
-//    butterflies u = t + c*T, c < CNT_p, in the other passes, so consecutive lanes touch
-//    consecutive float2 (ds_read_b64 / ds_write_b64) and the twiddle index n = u % S_p is the
-//    same for all c (T is a multiple of S_p for p >= 1).
+//    butterflies u = t + c*T, c < CNT_p, in pass 0; in the middle passes a WAVE owns a contiguous run
+//    of butterflies (mid_butterfly) -- the points its rows cover -- so that only pass 0 exchanges data
+//    between waves.  Consecutive lanes touch consecutive float2 either way (ds_read_b64 / ds_write_b64).
 //  * Two float2 of padding follow every row: pad(i) = i + 2*(i / RL).  A row is then 272 (144)
 //    bytes, ds_read_b128 / ds_write_b128 of rows are conflict-free and so are all strided
 //    writes; only the strided reads of the 4096-point plan pay a 2-way conflict.
@@ -202,10 +202,25 @@ struct Fft2 {
         return PADDED ? e * S(PASS) + (((e * S(PASS)) >> LRL) << 1) : e * S(PASS);
     }
     static_assert(!PADDED || P == 1 || S(0) % RL == 0, "padded strides are multiples of the row length");
-    static_assert(P < 3 || T % S(1) == 0, "one middle-pass twiddle set per thread");
     static_assert(!PADDED || P < 3 || S(1) % RL == 0, "padded strides are multiples of the row length");
-    static_assert(P < 4 || (T % S(2) == 0 && (!PADDED || S(2) % RL == 0)), "the same for the second middle pass");
+    static_assert(P < 4 || !PADDED || S(2) % RL == 0, "the same for the second middle pass");
     static_assert(P <= 4, "at most two middle passes");
+
+    // ---- who works on what after pass 0 -----------------------------------------------------------
+    // Pass 0 leaves R0 independent sub-transforms of M(1) = N/R0 contiguous points.  The W = T/64 wavefronts of
+    // the workgroup share them out in order -- wave w owns points [w N/W, (w+1) N/W) -- and every later pass
+    // (the middle passes and the row pass, in both directions) deals its butterflies to the waves in the same
+    // contiguous runs.  A wave then reads only what it wrote itself between pass 0 and the inverse of pass 0,
+    // so the passes in between need no workgroup barrier, only program order within the wave (pass_sync()
+    // in mgx_kernels.h): one barrier per transform and direction instead of one per pass.
+    static constexpr int W = T / 64;
+    static constexpr bool WAVE_LOCAL = P >= 3 && R0 % W == 0;
+    template <int PASS>
+    static MGX_HD int mid_butterfly(int tid, int c) {       // butterfly c of the thread in a middle pass
+        static_assert(P < 3 || !partial(PASS), "every thread owns a butterfly of a middle pass");
+        return (tid >> 6) * (CNT(PASS) * 64) + (tid & 63) + 64 * c;
+    }
+    static_assert(P < 3 || (CNT(1) * 64) % S(1) == 0 || S(1) % (CNT(1) * 64) == 0, "a wave's run starts on a twiddle period");
 
     // twiddle exponent (units of 2*pi/N) for output q of butterfly u in pass p: (u % S)*q*(N/M)
     template <int PASS>
@@ -295,13 +310,17 @@ struct Fft2 {
     template <int PASS>
     static MGX_HD void fwd_mid_pass(int tid, float2* lds, const float2* table) {
         constexpr int r = R(PASS), bits = lr(PASS), s = S(PASS);
+        constexpr bool same = s <= 64;                   // the twiddle index n = u % s is the same for all c
         float2 w[r - 1];
-        const int n = tid % s;
-        MGX_UNROLL
-        for (int q = 1; q < r; ++q) w[q - 1] = table[(q - 1) * s + n];
         MGX_UNROLL
         for (int c = 0; c < CNT(PASS); ++c) {
-            float2* p = lds + base<PASS>(tid + c * T);
+            const int u = mid_butterfly<PASS>(tid, c);
+            if (c == 0 || !same) {
+                const int n = u % s;
+                MGX_UNROLL
+                for (int q = 1; q < r; ++q) w[q - 1] = table[(q - 1) * s + n];
+            }
+            float2* p = lds + base<PASS>(u);
             float2 v[r];
             MGX_UNROLL
             for (int j = 0; j < r; ++j) v[j] = p[off<PASS>(j)];
@@ -317,13 +336,17 @@ struct Fft2 {
     template <int PASS>
     static MGX_HD void inv_mid_pass(int tid, float2* lds, const float2* table) {
         constexpr int r = R(PASS), bits = lr(PASS), s = S(PASS);
+        constexpr bool same = s <= 64;
         float2 w[r - 1];
-        const int n = tid % s;
-        MGX_UNROLL
-        for (int q = 1; q < r; ++q) w[q - 1] = table[(q - 1) * s + n];
         MGX_UNROLL
         for (int c = 0; c < CNT(PASS); ++c) {
-            float2* p = lds + base<PASS>(tid + c * T);
+            const int u = mid_butterfly<PASS>(tid, c);
+            if (c == 0 || !same) {
+                const int n = u % s;
+                MGX_UNROLL
+                for (int q = 1; q < r; ++q) w[q - 1] = table[(q - 1) * s + n];
+            }
+            float2* p = lds + base<PASS>(u);
             float2 v[r];
             MGX_UNROLL
             for (int q = 0; q < r; ++q) {

@@ -20,6 +20,21 @@ namespace mgx {
 // (__syncthreads() would drain vmcnt as well and serialise a software prefetch).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Between two phases of a transform that lie between pass 0 and the inverse of pass 0.  In a plan with
+// Fft2::WAVE_LOCAL every wave reads there only what it wrote itself, and the LDS executes one wave's instructions in
+// program order: all that is needed is that the COMPILER keeps the order (a memory clobber), no s_barrier.  With
+// sixteen waves per workgroup and one workgroup per CU (the 16384-point kernels) a barrier idles the whole CU
+// until the last wave arrives; this takes them from ten per block to five.  Other plans get the barrier.
+template <class F>
+__device__ __forceinline__ void pass_sync() {
+#ifdef MGX_PASS_BARRIERS                     // A/B build: a workgroup barrier between all passes, as until round 4
+    lds_barrier();
+#else
+    if constexpr (F::WAVE_LOCAL) asm volatile("" ::: "memory");
+    else lds_barrier();
+#endif
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
@@ -167,22 +182,22 @@ __device__ __forceinline__ void conv_channel(int tid, const Conv2Args& a, float2
     __syncthreads();
     if (F::P >= 3) {
         CB::phase_fwd_mid(opaque(tid), lds, mid_table);
-        __syncthreads();
+        pass_sync<F>();
     }
     if (F::P == 4) {
         CB::phase_fwd_mid2(opaque(tid), lds, mid_table);
-        __syncthreads();
+        pass_sync<F>();
     }
     CB::phase_filter(tid, rf, lds);
-    __syncthreads();
     if (F::P == 4) {
+        pass_sync<F>();
         CB::phase_inv_mid2(opaque(tid), lds, mid_table);
-        __syncthreads();
     }
     if (F::P >= 3) {
+        pass_sync<F>();
         CB::phase_inv_mid(opaque(tid), lds, mid_table);
-        __syncthreads();
     }
+    __syncthreads();
     __builtin_amdgcn_sched_barrier(0);      // keeps the next phase's LDS reads from being lifted into this one
 }
 // uniformly partitioned overlap-save: one forward transform per filter partition, products
@@ -206,29 +221,29 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
         __syncthreads();
         if (F::P >= 3) {
             CB::phase_fwd_mid(opaque(tid), lds, mid_table);
-            __syncthreads();
+            pass_sync<F>();
         }
         if (F::P == 4) {
             CB::phase_fwd_mid2(opaque(tid), lds, mid_table);
-            __syncthreads();
+            pass_sync<F>();
         }
         __builtin_amdgcn_sched_barrier(0);
         if (LATE_FILTER) CB::fetch_filter(opaque(tid), h + (size_t)k * F::N, rf);
         CB::phase_accumulate(tid, rf, lds, acc);
-        __syncthreads();
+        __syncthreads();                    // (the next partition's pass 0 writes everywhere)
         __builtin_amdgcn_sched_barrier(0);
     }
     CB::phase_finish_row(tid, acc, lds);
-    __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     if (F::P == 4) {
+        pass_sync<F>();
         CB::phase_inv_mid2(opaque(tid), lds, mid_table);
-        __syncthreads();
     }
     if (F::P >= 3) {
+        pass_sync<F>();
         CB::phase_inv_mid(opaque(tid), lds, mid_table);
-        __syncthreads();
     }
+    __syncthreads();
 }
 
 // One pair of output blocks: mid channel, then side channel + epilogue.
@@ -343,11 +358,11 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         __syncthreads();
         if (F::P >= 3) {
             CB::phase_fwd_mid(opaque(tid), lds, mid_table);
-            __syncthreads();
+            pass_sync<F>();
         }
         if (F::P == 4) {
             CB::phase_fwd_mid2(opaque(tid), lds, mid_table);
-            __syncthreads();
+            pass_sync<F>();
         }
         __builtin_amdgcn_sched_barrier(0);
         typename CD::Row own;
@@ -358,15 +373,15 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         __builtin_amdgcn_sched_barrier(0);
         if (b < first) continue;            // (uniform) the block in front of the run: its carry only
         CD::phase_row_back(opaque(tid), own, lds);
-        __syncthreads();
         if (F::P == 4) {
+            pass_sync<F>();
             CB::phase_inv_mid2(opaque(tid), lds, mid_table);
-            __syncthreads();
         }
         if (F::P >= 3) {
+            pass_sync<F>();
             CB::phase_inv_mid(opaque(tid), lds, mid_table);
-            __syncthreads();
         }
+        __syncthreads();
         const float pk = CD::phase_store(opaque(tid), b, a, ps, lds);
         const float bp = block_max<F::T>(pk, scratch);          // (a barrier inside: the LDS is free for the next block)
         if (tid == 0 && a.pair_peak) a.pair_peak[b] = bp;
@@ -392,11 +407,11 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_prep(const float* tap
     __syncthreads();
     if (F::P >= 3) {
         CB::phase_fwd_mid(tid, lds, mid_table);
-        __syncthreads();
+        pass_sync<F>();
     }
     if (F::P == 4) {
         CB::phase_fwd_mid2(tid, lds, mid_table);
-        __syncthreads();
+        pass_sync<F>();
     }
     CB::phase_write_filter(tid, lds, (float)(g / (double)F::N), tables + ((size_t)ch * parts + k) * F::N);
 }
@@ -459,11 +474,11 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
         lds_barrier();
         if (F::P >= 3) {
             AB::phase_fwd_mid(tid, lds, mid_table);
-            lds_barrier();
+            pass_sync<F>();
         }
         if (F::P == 4) {
             AB::phase_fwd_mid2(tid, lds, mid_table);
-            lds_barrier();
+            pass_sync<F>();
         }
         typename AB::Row own;
         AB::phase_row(tid, own, lds);
@@ -516,11 +531,11 @@ __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) v
         lds_barrier();
         if (F::P >= 3) {
             AD::AB::phase_fwd_mid(tid, lds, mid_table);
-            lds_barrier();
+            pass_sync<F>();
         }
         if (F::P == 4) {
             AD::AB::phase_fwd_mid2(tid, lds, mid_table);
-            lds_barrier();
+            pass_sync<F>();
         }
         AD::phase_row(tid, lds);
         lds_barrier();
@@ -530,11 +545,11 @@ __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) v
         lds_barrier();
         if (F::P >= 3) {
             AD::AB::phase_fwd_mid(tid, lds, mid_table);
-            lds_barrier();
+            pass_sync<F>();
         }
         if (F::P == 4) {
             AD::AB::phase_fwd_mid2(tid, lds, mid_table);
-            lds_barrier();
+            pass_sync<F>();
         }
         AD::phase_row(tid, lds);
         lds_barrier();

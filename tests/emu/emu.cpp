@@ -9,6 +9,7 @@
 // matchering_amd.
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "../../matchering_amd/csrc/analysis2_kernel.h"
@@ -29,19 +30,42 @@ static std::vector<float2> twiddles(int n) {
 
 #define FOR_THREADS(T_) for (int tid = 0; tid < (T_); ++tid)
 
-// Middle pass of a transform.  A split pass (fft2.h: two lanes share a butterfly and run in lockstep
-// on the GPU) is emulated as its two halves in separate thread loops.
+// What runs between pass 0 and the inverse of pass 0 touches, in every wave, only points that wave owns (fft2.h,
+// WAVE_LOCAL), and the kernels rely on it: no workgroup barrier separates those phases.  The emulation therefore
+// runs such a sequence of phases WAVE BY WAVE -- wave 0 through all of them, then wave 1, ... -- so that a phase
+// which reads another wave's points sees stale data here as it could on the GPU.  Plans without the property
+// (and their kernels) keep a barrier per phase: phase by phase over all threads.
+using Phase = std::function<void(int)>;
 template <class F>
-static void mid_pass(bool inverse, float2* lds, const float2* table) {
-    if (F::P < 3) return;
-    if (inverse) {
-        if (F::P == 4) { FOR_THREADS(F::T) F::inv_mid2(tid, lds, table); }
-        FOR_THREADS(F::T) F::inv_mid(tid, lds, table);
+static void local_phases(const std::vector<Phase>& phases) {
+    if (F::WAVE_LOCAL) {
+        for (int w = 0; w < F::T / 64; ++w)
+            for (const Phase& ph : phases)
+                for (int tid = 64 * w; tid < 64 * w + 64; ++tid) ph(tid);
     } else {
-        FOR_THREADS(F::T) F::fwd_mid(tid, lds, table);
-        if (F::P == 4) { FOR_THREADS(F::T) F::fwd_mid2(tid, lds, table); }
+        for (const Phase& ph : phases) { FOR_THREADS(F::T) ph(tid); }
     }
 }
+// the middle passes of a transform as phases
+template <class F>
+static std::vector<Phase> mid_phases(bool inverse, float2* lds, const float2* table) {
+    std::vector<Phase> out;
+    if (F::P < 3) return out;
+    if (inverse) {
+        if (F::P == 4) out.push_back([=](int tid) { F::inv_mid2(tid, lds, table); });
+        out.push_back([=](int tid) { F::inv_mid(tid, lds, table); });
+    } else {
+        out.push_back([=](int tid) { F::fwd_mid(tid, lds, table); });
+        if (F::P == 4) out.push_back([=](int tid) { F::fwd_mid2(tid, lds, table); });
+    }
+    return out;
+}
+static std::vector<Phase> operator+(std::vector<Phase> a, const std::vector<Phase>& b) {
+    a.insert(a.end(), b.begin(), b.end());
+    return a;
+}
+template <class F>
+static void mid_pass(bool inverse, float2* lds, const float2* table) { local_phases<F>(mid_phases<F>(inverse, lds, table)); }
 
 // ---------------------------------------------------------------------------
 template <int LOG2N>
@@ -59,9 +83,10 @@ static int conv_impl(const float* x, long long n, const double* fir_mid, const d
     for (int ch = 0; ch < 2; ++ch)
         for (int k = 0; k < parts; ++k) {
             FOR_THREADS(F::T) CB::phase_load_taps(tid, h.data() + ((size_t)ch * parts + k) * CB::TAPS, ps[tid], lds.data());
-            mid_pass<F>(false, lds.data(), mid_table.data());
-            FOR_THREADS(F::T) CB::phase_write_filter(tid, lds.data(), (float)(gain / F::N),
-                                                     tables.data() + ((size_t)ch * parts + k) * F::N);
+            float2* table = tables.data() + ((size_t)ch * parts + k) * F::N;
+            local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) + std::vector<Phase>{[&](int tid) {
+                                CB::phase_write_filter(tid, lds.data(), (float)(gain / F::N), table);
+                            }});
         }
     Conv2Args a;
     a.x = reinterpret_cast<const float2*>(x);
@@ -91,23 +116,29 @@ static int conv_impl(const float* x, long long n, const double* fir_mid, const d
                     CB::phase_pass0_mid(tid, raw, ps[tid], lds.data(), held[tid]);
                 }
             }
-            mid_pass<F>(false, lds.data(), mid_table.data());
-            FOR_THREADS(F::T) { typename CB::RowFilter rf; CB::fetch_filter(tid, hh, rf); CB::phase_filter(tid, rf, lds.data()); }
+            // (k_conv: no barrier between the middle passes and the row, in either direction)
+            local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) +
+                            std::vector<Phase>{[&](int tid) {
+                                typename CB::RowFilter rf;
+                                CB::fetch_filter(tid, hh, rf);
+                                CB::phase_filter(tid, rf, lds.data());
+                            }} +
+                            mid_phases<F>(true, lds.data(), mid_table.data()));
+            return;
         } else {
             FOR_THREADS(F::T) CB::clear_acc(acc[tid]);
             for (int k = 0; k < parts; ++k) {
                 if (side) { FOR_THREADS(F::T) CB::template phase_load<true>(tid, pair, edge, a, ps[tid], lds.data(), k); }
                 else { FOR_THREADS(F::T) CB::template phase_load<false>(tid, pair, edge, a, ps[tid], lds.data(), k); }
-                mid_pass<F>(false, lds.data(), mid_table.data());
-                FOR_THREADS(F::T) {
-                    typename CB::RowFilter rf;
-                    CB::fetch_filter(tid, hh + (size_t)k * F::N, rf);
-                    CB::phase_accumulate(tid, rf, lds.data(), acc[tid]);
-                }
+                local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) + std::vector<Phase>{[&](int tid) {
+                                    typename CB::RowFilter rf;
+                                    CB::fetch_filter(tid, hh + (size_t)k * F::N, rf);
+                                    CB::phase_accumulate(tid, rf, lds.data(), acc[tid]);
+                                }});
             }
-            FOR_THREADS(F::T) CB::phase_finish_row(tid, acc[tid], lds.data());
+            local_phases<F>(std::vector<Phase>{[&](int tid) { CB::phase_finish_row(tid, acc[tid], lds.data()); }} +
+                            mid_phases<F>(true, lds.data(), mid_table.data()));
         }
-        mid_pass<F>(true, lds.data(), mid_table.data());
     };
     for (long long pair = 0; pair < a.npairs; ++pair) {
         const bool edge = !CB::interior(pair, n, parts);
@@ -159,9 +190,10 @@ static int conv_delay_impl(const float* x, long long n, const double* fir_mid, c
     for (int ch = 0; ch < 2; ++ch)
         for (int k = 0; k < parts; ++k) {
             FOR_THREADS(F::T) CB::phase_load_taps(tid, h.data() + ((size_t)ch * parts + k) * CB::TAPS, ps[tid], lds.data());
-            mid_pass<F>(false, lds.data(), mid_table.data());
-            FOR_THREADS(F::T) CB::phase_write_filter(tid, lds.data(), (float)(gain / F::N),
-                                                     tables.data() + ((size_t)ch * parts + k) * F::N);
+            float2* table = tables.data() + ((size_t)ch * parts + k) * F::N;
+            local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) + std::vector<Phase>{[&](int tid) {
+                                CB::phase_write_filter(tid, lds.data(), (float)(gain / F::N), table);
+                            }});
         }
     Conv2Args a;
     a.x = reinterpret_cast<const float2*>(x);
@@ -181,12 +213,12 @@ static int conv_delay_impl(const float* x, long long n, const double* fir_mid, c
         FOR_THREADS(F::T) CD::clear(carry[tid]);
         for (long long b = first - 1; b < end; ++b) {
             FOR_THREADS(F::T) CD::phase_load(tid, b, a, ps[tid], lds.data());
-            mid_pass<F>(false, lds.data(), mid_table.data());
-            FOR_THREADS(F::T) CD::phase_row(tid, own[tid], lds.data());
-            FOR_THREADS(F::T) CD::phase_multiply(tid, a, own[tid], carry[tid], lds.data());
+            local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) +
+                            std::vector<Phase>{[&](int tid) { CD::phase_row(tid, own[tid], lds.data()); }});
+            FOR_THREADS(F::T) CD::phase_multiply(tid, a, own[tid], carry[tid], lds.data());   // (mirror rows: a barrier either side)
             if (b < first) continue;                                       // the block in front of the run: carry only
-            FOR_THREADS(F::T) CD::phase_row_back(tid, own[tid], lds.data());
-            mid_pass<F>(true, lds.data(), mid_table.data());
+            local_phases<F>(std::vector<Phase>{[&](int tid) { CD::phase_row_back(tid, own[tid], lds.data()); }} +
+                            mid_phases<F>(true, lds.data(), mid_table.data()));
             float pk = 0.f;
             FOR_THREADS(F::T) pk = std::fmax(pk, CD::phase_store(tid, b, a, ps[tid], lds.data()));
             if (block_peak) block_peak[b] = pk;
@@ -244,8 +276,8 @@ static int analyze_impl(const float* x, long long n, const mgx_config* cfg, int 
         for (int s = s0; s < s1; ++s) {
             const long long start = d * piece + (long long)s * F::N;
             FOR_THREADS(F::T) { typename AB::Raw raw; AB::fetch(tid, start, a, raw); AB::phase_load(tid, raw, ps[tid], th[tid], lds.data()); }
-            mid_pass<F>(false, lds.data(), mid_table.data());
-            FOR_THREADS(F::T) AB::phase_row(tid, own[tid], lds.data());
+            local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) +
+                            std::vector<Phase>{[&](int tid) { AB::phase_row(tid, own[tid], lds.data()); }});
             FOR_THREADS(F::T) AB::phase_magnitudes(tid, own[tid], th[tid], lds.data());
         }
         if (ch == a.chunks_per_piece - 1) {
@@ -330,12 +362,12 @@ static int analyze_double_impl(const float* x, long long n, const mgx_config* cf
         for (int s = s0; s < s1; ++s) {
             const long long start = d * piece + (long long)s * fft;
             FOR_THREADS(F::T) AD::template phase_load<false>(tid, start, a, ps[tid], th[tid], lds.data());
-            mid_pass<F>(false, lds.data(), mid_table.data());
-            FOR_THREADS(F::T) AD::phase_row(tid, lds.data());
+            local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) +
+                            std::vector<Phase>{[&](int tid) { AD::phase_row(tid, lds.data()); }});
             FOR_THREADS(F::T) AD::template phase_magnitudes<false>(tid, th[tid], lds.data());
             FOR_THREADS(F::T) AD::template phase_load<true>(tid, start, a, ps[tid], th[tid], lds.data());
-            mid_pass<F>(false, lds.data(), mid_table.data());
-            FOR_THREADS(F::T) AD::phase_row(tid, lds.data());
+            local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) +
+                            std::vector<Phase>{[&](int tid) { AD::phase_row(tid, lds.data()); }});
             FOR_THREADS(F::T) AD::template phase_magnitudes<true>(tid, th[tid], lds.data());
         }
         if (ch == a.chunks_per_piece - 1) {
