@@ -116,6 +116,10 @@ static void code_sizes_from_library(int (&bytes)[CODE_KERNELS][CODE_VARIANTS]) {
         for (size_t k = 0; k < count; ++k) {
             if (ELF64_ST_TYPE(sym[k].st_info) != STT_FUNC || sym[k].st_size == 0) continue;
             const char* name = str + sym[k].st_name;
+            if (std::strstr(name, "k_conv_delayILi")) {              // the delay-line convolution: CODE_CONV's last variant
+                bytes[CODE_CONV][CODE_VARIANT_CONV_DELAY] = (int)sym[k].st_size;
+                continue;
+            }
             for (int c = 0; c < CODE_KERNELS; ++c) {
                 const char* hit = std::strstr(name, CODE_NAMES[c]);
                 if (!hit) continue;

@@ -117,6 +117,7 @@ __device__ int g_test_tail_launches;
 // symbol table (mgx.hip, code_sizes_from_library); zero = no warming.
 enum { CODE_ANALYZE = 0, CODE_MATCH_CURVE, CODE_CONV_PREP, CODE_CONV, CODE_ROUND, CODE_TAIL, CODE_LIMIT, CODE_KERNELS };
 constexpr int CODE_VARIANTS = 16;                                  // second index: log2 of the transform; 0 / 1 = 256 / 1024-block limiter
+constexpr int CODE_VARIANT_CONV_DELAY = 15;                        // [CODE_CONV][15]: k_conv_delay<14>
 __device__ int g_code_bytes[CODE_KERNELS][CODE_VARIANTS];
 __device__ __forceinline__ void warm_code(int which, int variant = 0) {
     if (blockIdx.x >= 8 || threadIdx.x >= 64) return;             // workgroup b runs on XCD b % 8: one wave per L2
@@ -335,6 +336,7 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
 // pair_peak has one entry per block.
 template <int LOG2N>
 __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) void k_conv_delay(Conv2Args a) {
+    warm_code(CODE_CONV, CODE_VARIANT_CONV_DELAY);
     using CD = ConvDelay<LOG2N>;
     using CB = Conv2Block<LOG2N>;
     using F = Fft2<LOG2N>;

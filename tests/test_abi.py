@@ -121,6 +121,7 @@ def test_code_sizes_are_read_from_the_librarys_own_code_object():
     assert seen["_ZN3mgx7k_limitILi256ELi4EEEvNS_11LimiterArgsE"] == limit[0]
     assert seen["_ZN3mgx9k_analyzeILi12EEEvNS_12AnalysisArgsES1_i"] == analyze[12]
     assert min(seen["_ZN3mgx6k_convILi14ELb0EEEvNS_9Conv2ArgsE"], seen["_ZN3mgx6k_convILi14ELb1EEEvNS_9Conv2ArgsE"]) == conv[14]
+    assert seen["_ZN3mgx12k_conv_delayILi14EEEvNS_9Conv2ArgsE"] == conv[15]        # the delay-line kernel's own slot
 
 
 def test_the_hot_kernels_do_not_spill():
