@@ -306,6 +306,54 @@ struct Fft2 {
         dft_regs<R0, true>(v);
     }
 
+    // ---- pass 0 with the twiddles built as they are used (one butterfly per thread: nothing to reuse) ------
+    // w_q for q < R0/2 from the bases as expand_tw0 does (R0/2 - 1 values alive), w_q = w_{R0/2} w_{q-R0/2} for
+    // the upper half on the fly: the same complex multiplies in another order, sixteen registers fewer at the
+    // point where the whole butterfly is in registers too.  For kernels that have none to spare.
+    struct Tw0Low {
+        float2 w[R0 / 2 - 1];
+    };
+    static MGX_HD void expand_tw0_low(const Tw0& t, Tw0Low& f) {
+        MGX_UNROLL
+        for (int q = 1; q < R0 / 2; ++q) {
+            int hb = 1;
+            while (hb * 2 <= q) hb *= 2;
+            f.w[q - 1] = q == hb ? t.b[ilog2(hb)] : cmul(t.b[ilog2(hb)], f.w[q - hb - 1]);
+        }
+    }
+    static MGX_HD float2 tw0_at(const Tw0& t, const Tw0Low& f, int q) {         // q = 1 .. R0-1, compile-time after unrolling
+        if (q < R0 / 2) return f.w[q - 1];
+        if (q == R0 / 2) return t.b[LB0 - 1];
+        return cmul(t.b[LB0 - 1], f.w[q - R0 / 2 - 1]);
+    }
+    static MGX_HD void fwd0_store_lean(float2 (&v)[R0], int tid, const Tw0& t, float2* lds) {
+        static_assert(CNT(0) == 1 || P == 1, "one pass-0 butterfly per thread");
+        constexpr int bits = lr(0);
+        float2* p = lds + base<0>(tid);
+        dft_regs<R0, false>(v);
+        Tw0Low low;
+        expand_tw0_low(t, low);
+        MGX_UNROLL
+        for (int q = 0; q < R0; ++q) {
+            float2 x = v[bitrev(q, bits)];
+            if (P > 1 && q != 0) x = cmul(x, tw0_at(t, low, q));
+            p[off<0>(q)] = x;
+        }
+    }
+    static MGX_HD void inv0_load_lean(float2 (&v)[R0], int tid, const Tw0& t, const float2* lds) {
+        constexpr int bits = lr(0);
+        const float2* p = lds + base<0>(tid);
+        Tw0Low low;
+        expand_tw0_low(t, low);
+        MGX_UNROLL
+        for (int q = 0; q < R0; ++q) {
+            float2 x = p[off<0>(q)];
+            if (P > 1 && q != 0) x = cmulc(x, tw0_at(t, low, q));
+            v[bitrev(q, bits)] = x;
+        }
+        dft_regs<R0, true>(v);
+    }
+
     // ---- middle passes (P >= 3), LDS -> LDS --------------------------------------------------
     template <int PASS>
     static MGX_HD void fwd_mid_pass(int tid, float2* lds, const float2* table) {

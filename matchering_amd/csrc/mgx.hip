@@ -1573,6 +1573,11 @@ int mgx_stage_timing(mgx_handle* h, int32_t enable) {
     for (bool& u : h->stage_used) u = false;
     return 0;
 }
+#ifdef MGX_DEV_CONV_PHASES           // development builds only (tools/conv_delay_phases.py)
+int mgx_dev_conv_ticks_read(unsigned* out, int blocks) {        // out: [blocks][8]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx::mgx_dev_conv_ticks), (size_t)blocks * 8 * sizeof(unsigned)) != hipSuccess;
+}
+#endif
 #ifdef MGX_DEV_LIMITER_PHASES        // development builds only (tools/limiter_phases.py)
 int mgx_dev_phase_ticks_read(unsigned* out, int chunks) {       // out: [chunks][16]
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx::mgx_dev_phase_ticks), (size_t)chunks * 16 * sizeof(unsigned)) != hipSuccess;

@@ -330,6 +330,20 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
     }
 }
 
+#ifdef MGX_DEV_CONV_PHASES         // development builds only: where a block's time goes (tools/conv_delay_phases.py)
+constexpr int DEV_CONV_BLOCKS = 16384;
+__device__ unsigned mgx_dev_conv_ticks[DEV_CONV_BLOCKS][8];          // [block][mark]: ticks since the previous mark; [7] = start
+#define DEV_CONV_MARK(k)                                                                             \
+    do {                                                                                             \
+        if (threadIdx.x == 0 && b >= 0 && b < DEV_CONV_BLOCKS) {                                     \
+            const long long now = wall_clock64();                                                    \
+            mgx_dev_conv_ticks[b][k] = (unsigned)(now - dev_last);                                   \
+            dev_last = now;                                                                          \
+        }                                                                                            \
+    } while (0)
+#else
+#define DEV_CONV_MARK(k)
+#endif
 // A filter of two partitions as a frequency-domain delay line (conv_delay_kernel.h): workgroup w takes blocks
 // [w * run, (w + 1) * run) one after the other, the partition-1 product of a block carried to the next in registers;
 // it starts with the forward transform of block w * run - 1 (carry only).  a.npairs counts BLOCKS here and
@@ -352,12 +366,25 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
     const long long end = min(a.npairs, first + a.run);
     typename CD::Carry carry;
     CD::clear(carry);
+    // the older half of a block's window is the newer half of the block before: kept in registers (as mid / side),
+    // and the newer half is asked for a block ahead -- every frame is fetched once per run and its latency lies under
+    // the end of the block before (275 us with the whole window loaded at the top of a block, 262 with the older half
+    // kept, 243 with the newer half asked for ahead: profiles/r04_v_conv_delay_pairs.txt)
+    typename CD::HeldFrames held;
+    typename CD::HalfFrames newer;
+    CD::prime(tid, first - 1, a, held);
+    CD::template fetch_half<CD::R0 / 2>(tid, first - 1, a, newer);
     for (long long b = first - 1; b < end; ++b) {
         // (as in k_conv: nothing derived from the pass-0 twiddles or the thread id may be hoisted out of the loop)
 #pragma unroll
         for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
-        CD::phase_load(opaque(tid), b, a, ps, lds);
+#ifdef MGX_DEV_CONV_PHASES
+        long long dev_last = wall_clock64();
+        if (threadIdx.x == 0 && b >= 0 && b < DEV_CONV_BLOCKS) mgx_dev_conv_ticks[b][7] = (unsigned)dev_last;
+#endif
+        CD::phase_pass0_held(opaque(tid), ps, held, newer, lds);       // (the newer half was asked for a block ago)
         __syncthreads();
+        DEV_CONV_MARK(0);                   // frames, pass 0, barrier
         if (F::P >= 3) {
             CB::phase_fwd_mid(opaque(tid), lds, mid_table);
             pass_sync<F>();
@@ -367,14 +394,19 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
             pass_sync<F>();
         }
         __builtin_amdgcn_sched_barrier(0);
-        typename CD::Row own;
-        CD::phase_row(opaque(tid), own, lds);
+        DEV_CONV_MARK(1);                   // middle passes
+        CD::phase_row(opaque(tid), lds);
         __syncthreads();
-        CD::phase_multiply(opaque(tid), a, own, carry, lds);
+        DEV_CONV_MARK(2);                   // row forward, barrier
+        CD::phase_multiply(opaque(tid), a, carry, lds);
         __syncthreads();                    // every mirror row has been read: the rows may be written again
         __builtin_amdgcn_sched_barrier(0);
-        if (b < first) continue;            // (uniform) the block in front of the run: its carry only
-        CD::phase_row_back(opaque(tid), own, lds);
+        DEV_CONV_MARK(3);                   // multiply, barrier
+        if (b < first) {                    // (uniform) the block in front of the run: its carry only
+            CD::template fetch_half<CD::R0 / 2>(opaque(tid), b + 1, a, newer);
+            continue;
+        }
+        CD::phase_row_back(opaque(tid), lds);
         if (F::P == 4) {
             pass_sync<F>();
             CB::phase_inv_mid2(opaque(tid), lds, mid_table);
@@ -383,10 +415,15 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
             pass_sync<F>();
             CB::phase_inv_mid(opaque(tid), lds, mid_table);
         }
+        // the newer half of the next block's window: asked for here, its latency under the last inverse pass and the
+        // stores (asked for a phase earlier, behind the multiply, it costs 24 B more scratch and 11 us)
+        CD::template fetch_half<CD::R0 / 2>(opaque(tid), b + 1, a, newer);
         __syncthreads();
+        DEV_CONV_MARK(4);                   // row back, inverse middle passes, barrier
         const float pk = CD::phase_store(opaque(tid), b, a, ps, lds);
         const float bp = block_max<F::T>(pk, scratch);          // (a barrier inside: the LDS is free for the next block)
         if (tid == 0 && a.pair_peak) a.pair_peak[b] = bp;
+        DEV_CONV_MARK(5);                   // inverse pass 0, stores, peak
     }
 }
 

@@ -206,18 +206,23 @@ static int conv_delay_impl(const float* x, long long n, const double* fir_mid, c
     a.parts = parts;
     a.npairs = (n + CD::HOP - 1) / CD::HOP;              // blocks
     a.pair_peak = nullptr;
-    std::vector<typename CD::Row> own(F::T);
     std::vector<typename CD::Carry> carry(F::T);
+    std::vector<typename CD::HeldFrames> held(F::T);
     for (long long first = 0; first < a.npairs; first += run) {          // one workgroup
         const long long end = std::min<long long>(a.npairs, first + run);
         FOR_THREADS(F::T) CD::clear(carry[tid]);
         for (long long b = first - 1; b < end; ++b) {
-            FOR_THREADS(F::T) CD::phase_load(tid, b, a, ps[tid], lds.data());
+            if (b == first - 1) { FOR_THREADS(F::T) CD::prime(tid, b, a, held[tid]); }
+            FOR_THREADS(F::T) {
+                typename CD::HalfFrames newer;
+                CD::template fetch_half<CD::R0 / 2>(tid, b, a, newer);
+                CD::phase_pass0_held(tid, ps[tid], held[tid], newer, lds.data());
+            }
             local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) +
-                            std::vector<Phase>{[&](int tid) { CD::phase_row(tid, own[tid], lds.data()); }});
-            FOR_THREADS(F::T) CD::phase_multiply(tid, a, own[tid], carry[tid], lds.data());   // (mirror rows: a barrier either side)
+                            std::vector<Phase>{[&](int tid) { CD::phase_row(tid, lds.data()); }});
+            FOR_THREADS(F::T) CD::phase_multiply(tid, a, carry[tid], lds.data());   // (mirror rows: a barrier either side)
             if (b < first) continue;                                       // the block in front of the run: carry only
-            local_phases<F>(std::vector<Phase>{[&](int tid) { CD::phase_row_back(tid, own[tid], lds.data()); }} +
+            local_phases<F>(std::vector<Phase>{[&](int tid) { CD::phase_row_back(tid, lds.data()); }} +
                             mid_phases<F>(true, lds.data(), mid_table.data()));
             float pk = 0.f;
             FOR_THREADS(F::T) pk = std::fmax(pk, CD::phase_store(tid, b, a, ps[tid], lds.data()));
