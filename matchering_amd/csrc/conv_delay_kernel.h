@@ -16,16 +16,17 @@
 //    to the next block in registers (RL float2 per thread): Y_b = Z_b P0 + conj(Zm_b) Q0 + C_{b-1}.
 //    A run starts with one forward transform of the block before it (the carry only).
 //
-// Two transforms per block instead of three, every frame fetched once (the older half of a window stays in
-// registers from the block before) instead of six times, at the price of one more trip of the row through
-// LDS (the mirror bins live on another thread) and two more barriers per block.
-//  * A thread multiplies PAIRS of bins: the lower half of its own row and their mirrors, which are the upper half of
+//  * a thread multiplies PAIRS of bins: the lower half of its own row and their mirrors, which are the upper half of
 //    the mirror row (fft2.h: (row, q) <-> (mirror_row, RL-1-q)).  The filters are real sequences' spectra, so the
 //    four filter values at bin N-k are the conjugates of those at k: one fetch serves both bins of a pair, which
 //    halves what the phase moves from the L2 -- and that, not arithmetic or latency, is what the phase takes
-//    (profiles/r04_u_conv_delay_phases.txt).  (Keeping the newer half of a
-// window in 16 registers for the next block -- every frame fetched once -- was built and measured: the kernel has
-// no register to spare, 341 against 312 us.)
+//    (profiles/r04_u_conv_delay_phases.txt);
+//  * the older half of a block's window is the newer half of the block before: it stays in registers, and the newer
+//    half is asked for a block ahead (k_conv_delay in mgx_kernels.h; profiles/r04_v_conv_delay_pairs.txt).
+//
+// Two transforms per block instead of three, every frame fetched once instead of six times, half the filter
+// values, at the price of one more trip of the row through LDS (the mirror bins live on another thread) and two
+// more barriers per block.
 #pragma once
 
 #include "conv2_kernel.h"
