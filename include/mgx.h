@@ -221,7 +221,8 @@ int mgx_stage_times(mgx_handle* h, float* ms /* [MGX_STAGE_COUNT] */);
 /* Code bytes of the seven big kernel families (analyze, match_curve, conv_prep, conv, correction_round,
  * correction_tail, limit), bytes[family * 16 + variant] with variant = log2 of the transform size (0 / 1 for the
  * 256 / 1024-block limiter, 0 for the untemplated kernels, 15 in the conv family for the two-partition
- * delay-line kernel), as read from this library's own device code
+ * delay-line kernel, 6 in the conv and conv_prep families for the N = 4F kernel of 4096 taps), as read from this
+ * library's own device code
  * object -- what the kernels' first workgroups read as data to put their code into the L2 ahead of the
  * instruction cache ("fast and slow boxes").  Returns the number of families; needs no
  * GPU.  Zeros mean the code object could not be read and the kernels do not warm. */

@@ -120,6 +120,14 @@ static void code_sizes_from_library(int (&bytes)[CODE_KERNELS][CODE_VARIANTS]) {
                 bytes[CODE_CONV][CODE_VARIANT_CONV_DELAY] = (int)sym[k].st_size;
                 continue;
             }
+            if (std::strstr(name, "k_conv_wide_prepILi")) {          // ... and its filter preparation
+                bytes[CODE_CONV_PREP][CODE_VARIANT_CONV_WIDE] = (int)sym[k].st_size;
+                continue;
+            }
+            if (std::strstr(name, "k_conv_wideILi")) {               // N = 4F: the slot no k_conv<L> uses
+                bytes[CODE_CONV][CODE_VARIANT_CONV_WIDE] = (int)sym[k].st_size;
+                continue;
+            }
             for (int c = 0; c < CODE_KERNELS; ++c) {
                 const char* hit = std::strstr(name, CODE_NAMES[c]);
                 if (!hit) continue;
@@ -715,6 +723,39 @@ static int launch_conv_delay(mgx_handle* h, Conv2Args a, const float* taps_dev, 
     return 0;
 }
 
+// F taps on N = 4F blocks (conv_wide_kernel.h; F = 4096 on N = 16384, one workgroup per CU, blocks dealt round-robin).
+// a.npairs counts blocks of 3N/4 frames on return.
+template <int LOG2N>
+static int launch_conv_wide(mgx_handle* h, Conv2Args a, const float* taps_dev, double gain, const double* gain_ptr) {
+    using F = Fft2<LOG2N>;
+    const size_t lds = conv_lds_bytes<LOG2N>();
+    MGX_TRY((allow_lds(k_conv_wide_prep<LOG2N>, lds)));
+    MGX_TRY((allow_lds(k_conv_wide<LOG2N>, lds)));
+    {
+        StageScope scope(h, MGX_STAGE_FILTER_SPECTRA);
+        hipLaunchKernelGGL((k_conv_wide_prep<LOG2N>), dim3(2), dim3(F::T), lds, h->stream, taps_dev, a.tw,
+                           (float2*)h->filt.p, gain_ptr, gain);
+    }
+    HIP_TRY(hipGetLastError());
+    a.parts = 1;
+    a.h_mid = (const float2*)h->filt.p;
+    a.h_side = (const float2*)h->filt.p + F::N;
+    a.npairs = (a.n + ConvWide<LOG2N>::HOP - 1) / ConvWide<LOG2N>::HOP;
+    MGX_TRY(ensure(h, h->block_peak, (size_t)a.npairs * sizeof(float)));
+    a.pair_peak = (float*)h->block_peak.p;
+    a.queue = nullptr;
+    int dev_cus = 256;
+    HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device));
+    const int per_cu = std::max(1, std::min(2048 / F::T, (int)((size_t)160 * 1024 / lds)));
+    const unsigned grid = (unsigned)std::min<long long>(a.npairs, (long long)dev_cus * per_cu);
+    {
+        StageScope scope(h, MGX_STAGE_CONVOLVE);
+        hipLaunchKernelGGL((k_conv_wide<LOG2N>), dim3(grid), dim3(F::T), lds, h->stream, a);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // taps_dev: [2][F] float (mid then side) already on the device.  F <= 8192: one overlap-save block of
 // N = 2F per filter; longer filters (config #5: 16 k taps at 96 kHz) are cut into K = F/8192
 // partitions on N = 16384 blocks (uniformly partitioned overlap-save), because N = 2F no longer fits
@@ -737,6 +778,24 @@ static int run_conv(mgx_handle* h, const float* x, long long n, int taps, const 
                            (float*)h->block_peak.p);
         HIP_TRY(hipGetLastError());
         return 0;
+    }
+    {
+        // 4096 taps (the reference's default fft_size) on 16384-point blocks, three quarters of a block fresh output
+        // (the variable: A/B against N = 2F)
+        const char* no_wide = std::getenv("MGX_NO_CONV_WIDE");
+        if (taps == 4096 && !(no_wide && no_wide[0] == '1')) {
+            constexpr int WIDE = 14;
+            MGX_TRY(ensure(h, h->filt, 2 * ((size_t)1 << WIDE) * sizeof(float2)));
+            Conv2Args a;
+            a.x = reinterpret_cast<const float2*>(x);
+            a.n = n;
+            a.y = reinterpret_cast<float2*>(y);
+            a.ymid = ymid;
+            a.run = 0;
+            MGX_TRY(get_twiddles(h, WIDE, &a.tw));
+            if (npairs_out) *npairs_out = (n + ConvWide<WIDE>::HOP - 1) / ConvWide<WIDE>::HOP;
+            return launch_conv_wide<WIDE>(h, a, taps_dev, gain, gain_ptr);
+        }
     }
     int log2b = l + 1;
     if (log2b > 14) log2b = LONG_FIR_LOG2N;

@@ -9,6 +9,7 @@
 #include "analysis2_kernel.h"
 #include "conv2_kernel.h"
 #include "conv_delay_kernel.h"
+#include "conv_wide_kernel.h"
 #include "fir_plan.h"
 #include "limiter_general.h"
 
@@ -74,6 +75,19 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     }
     return r;
 }
+// the same behind an LDS-only barrier: global loads asked for earlier (a software prefetch) stay in flight
+template <int THREADS>
+__device__ __forceinline__ float block_max_lds(float v, float* scratch) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    lds_barrier();
+    float r = 0.f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < THREADS / 64; ++w) r = fmaxf(r, scratch[w]);
+    }
+    return r;
+}
 template <int THREADS>
 __device__ __forceinline__ double block_sum(double v, double* scratch) {
     v = wave_sum(v);
@@ -118,6 +132,7 @@ __device__ int g_test_tail_launches;
 enum { CODE_ANALYZE = 0, CODE_MATCH_CURVE, CODE_CONV_PREP, CODE_CONV, CODE_ROUND, CODE_TAIL, CODE_LIMIT, CODE_KERNELS };
 constexpr int CODE_VARIANTS = 16;                                  // second index: log2 of the transform; 0 / 1 = 256 / 1024-block limiter
 constexpr int CODE_VARIANT_CONV_DELAY = 15;                        // [CODE_CONV][15]: k_conv_delay<14>
+constexpr int CODE_VARIANT_CONV_WIDE = 6;                          // [CODE_CONV][6]: k_conv_wide<14> (there is no k_conv<6>)
 __device__ int g_code_bytes[CODE_KERNELS][CODE_VARIANTS];
 __device__ __forceinline__ void warm_code(int which, int variant = 0) {
     if (blockIdx.x >= 8 || threadIdx.x >= 64) return;             // workgroup b runs on XCD b % 8: one wave per L2
@@ -383,7 +398,7 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         if (threadIdx.x == 0 && b >= 0 && b < DEV_CONV_BLOCKS) mgx_dev_conv_ticks[b][7] = (unsigned)dev_last;
 #endif
         CD::phase_pass0_held(opaque(tid), ps, held, newer, lds);       // (the newer half was asked for a block ago)
-        __syncthreads();
+        lds_barrier();
         DEV_CONV_MARK(0);                   // frames, pass 0, barrier
         if (F::P >= 3) {
             CB::phase_fwd_mid(opaque(tid), lds, mid_table);
@@ -396,10 +411,10 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         __builtin_amdgcn_sched_barrier(0);
         DEV_CONV_MARK(1);                   // middle passes
         CD::phase_row(opaque(tid), lds);
-        __syncthreads();
+        lds_barrier();
         DEV_CONV_MARK(2);                   // row forward, barrier
         CD::phase_multiply(opaque(tid), a, carry, lds);
-        __syncthreads();                    // every mirror row has been read: the rows may be written again
+        lds_barrier();                    // every mirror row has been read: the rows may be written again
         __builtin_amdgcn_sched_barrier(0);
         DEV_CONV_MARK(3);                   // multiply, barrier
         if (b < first) {                    // (uniform) the block in front of the run: its carry only
@@ -418,13 +433,111 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         // the newer half of the next block's window: asked for here, its latency under the last inverse pass and the
         // stores (asked for a phase earlier, behind the multiply, it costs 24 B more scratch and 11 us)
         CD::template fetch_half<CD::R0 / 2>(opaque(tid), b + 1, a, newer);
-        __syncthreads();
+        lds_barrier();                      // (every barrier of the loop orders LDS traffic only: a __syncthreads() would
+                                            // wait for these loads, and for the stores below, which nobody here reads)
         DEV_CONV_MARK(4);                   // row back, inverse middle passes, barrier
         const float pk = CD::phase_store(opaque(tid), b, a, ps, lds);
-        const float bp = block_max<F::T>(pk, scratch);          // (a barrier inside: the LDS is free for the next block)
+        const float bp = block_max_lds<F::T>(pk, scratch);      // (a barrier inside: the LDS is free for the next block)
         if (tid == 0 && a.pair_peak) a.pair_peak[b] = bp;
         DEV_CONV_MARK(5);                   // inverse pass 0, stores, peak
     }
+}
+
+// F taps on N = 4F blocks (conv_wide_kernel.h): workgroup w takes blocks w, w + G, w + 2G, ... and asks for the frames of
+// its next block while the current one is in its inverse transform.  a.npairs counts BLOCKS of 3N/4 frames here and
+// pair_peak has one entry per block.
+template <int LOG2N>
+__global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) void k_conv_wide(Conv2Args a) {
+    warm_code(CODE_CONV, CODE_VARIANT_CONV_WIDE);
+    using CW = ConvWide<LOG2N>;
+    using CB = Conv2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
+    MGX_LDS;
+    float2* lds = reinterpret_cast<float2*>(mgx_smem);
+    float2* mid_table = lds + F::LDS_ELEMS;
+    float* scratch = reinterpret_cast<float*>(mid_table + F::MID_TABLE);
+    const int tid = threadIdx.x;
+    typename CB::Persist ps;
+    CB::load_persist(tid, a.tw, mid_table, ps);
+    typename CW::Frames frames;
+    CW::fetch(tid, blockIdx.x, a, frames);
+    __syncthreads();
+    for (long long b = blockIdx.x; b < a.npairs; b += gridDim.x) {
+        // (as in k_conv: nothing derived from the pass-0 twiddles or the thread id may be hoisted out of the loop)
+#pragma unroll
+        for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
+#ifdef MGX_DEV_CONV_PHASES
+        long long dev_last = wall_clock64();
+        if (threadIdx.x == 0 && b < DEV_CONV_BLOCKS) mgx_dev_conv_ticks[b][7] = (unsigned)dev_last;
+#endif
+        CW::phase_pass0(opaque(tid), ps, frames, lds);
+        lds_barrier();
+        DEV_CONV_MARK(0);                   // pass 0, barrier
+        if (F::P >= 3) {
+            CB::phase_fwd_mid(opaque(tid), lds, mid_table);
+            pass_sync<F>();
+        }
+        if (F::P == 4) {
+            CB::phase_fwd_mid2(opaque(tid), lds, mid_table);
+            pass_sync<F>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        DEV_CONV_MARK(1);                   // middle passes
+        typename CW::Filters filt;
+        CW::fetch_filters(opaque(tid), a, filt);          // needed behind the next barrier
+        CW::phase_row(opaque(tid), lds);
+        lds_barrier();
+        DEV_CONV_MARK(2);                   // row forward, barrier
+        CW::phase_multiply(opaque(tid), filt, lds);
+        lds_barrier();                    // the partner has written this row's upper half
+        __builtin_amdgcn_sched_barrier(0);
+        DEV_CONV_MARK(3);                   // multiply, barrier
+        CW::phase_row_back(opaque(tid), lds);
+        if (F::P == 4) {
+            pass_sync<F>();
+            CB::phase_inv_mid2(opaque(tid), lds, mid_table);
+        }
+        if (F::P >= 3) {
+            pass_sync<F>();
+            CB::phase_inv_mid(opaque(tid), lds, mid_table);
+        }
+        // the next block's window: its latency under the last inverse pass and the stores -- the barriers from here
+        // to the top of the loop order LDS traffic only (a __syncthreads() would wait for these loads)
+        CW::fetch(opaque(tid), b + gridDim.x, a, frames);
+        lds_barrier();
+        DEV_CONV_MARK(4);                   // row back, inverse middle passes, barrier
+        const float pk = CW::phase_store(opaque(tid), b, a, ps, lds);
+        const float bp = block_max_lds<F::T>(pk, scratch);      // (a barrier inside: the LDS is free for the next block)
+        if (tid == 0 && a.pair_peak) a.pair_peak[b] = bp;
+        DEV_CONV_MARK(5);                   // inverse pass 0, stores, peak
+    }
+}
+// its filter spectra: grid = 2 (mid, side); taps = [2][N/4] float
+template <int LOG2N>
+__global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_wide_prep(const float* taps, const float2* tw, float2* tables,
+                                                                   const double* gain_ptr, double gain) {
+    warm_code(CODE_CONV_PREP, CODE_VARIANT_CONV_WIDE);
+    using CW = ConvWide<LOG2N>;
+    using CB = Conv2Block<LOG2N>;
+    using F = Fft2<LOG2N>;
+    MGX_LDS;
+    float2* lds = reinterpret_cast<float2*>(mgx_smem);
+    float2* mid_table = lds + F::LDS_ELEMS;
+    const int tid = threadIdx.x, ch = blockIdx.x;
+    const double g = gain_ptr ? *gain_ptr * gain : gain;
+    typename CB::Persist ps;
+    CB::load_persist(tid, tw, mid_table, ps);
+    CW::phase_load_taps(tid, taps + (size_t)ch * CW::TAPS, ps, lds);
+    __syncthreads();
+    if (F::P >= 3) {
+        CB::phase_fwd_mid(tid, lds, mid_table);
+        pass_sync<F>();
+    }
+    if (F::P == 4) {
+        CB::phase_fwd_mid2(tid, lds, mid_table);
+        pass_sync<F>();
+    }
+    CB::phase_write_filter(tid, lds, (float)(g / (double)F::N), tables + (size_t)ch * F::N);
 }
 
 // filter spectra: grid = 2 * parts; taps = [2][parts * N/2] float (mid then side), tables =

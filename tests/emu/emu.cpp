@@ -15,6 +15,7 @@
 #include "../../matchering_amd/csrc/analysis2_kernel.h"
 #include "../../matchering_amd/csrc/conv2_kernel.h"
 #include "../../matchering_amd/csrc/conv_delay_kernel.h"
+#include "../../matchering_amd/csrc/conv_wide_kernel.h"
 #include "../../matchering_amd/csrc/fir_design.h"
 #include "../../matchering_amd/csrc/host_params.h"
 
@@ -235,6 +236,69 @@ extern "C" int emu_convolve_delay(const float* x, long long n, const double* fir
                                   double gain, float* y, float* ymid, float* block_peak, int run) {
     switch (ilog2_exact(taps)) {
 #define CASE(L) case L: return conv_delay_impl<L>(x, n, fir_mid, fir_side, taps, gain, y, ymid, block_peak, run);
+        CASE(11) CASE(12) CASE(13) CASE(14)
+#undef CASE
+        default: return -4;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// F taps on N = 4F blocks (conv_wide_kernel.h): the phase sequence of k_conv_wide in mgx_kernels.h
+template <int LOG2N>
+static int conv_wide_impl(const float* x, long long n, const double* fir_mid, const double* fir_side, int taps,
+                          double gain, float* y, float* ymid, float* block_peak) {
+    using CW = ConvWide<LOG2N>;
+    using CB = Conv2Block<LOG2N>;
+    using F = typename CB::F;
+    if (taps != CW::TAPS) return -1;
+    const std::vector<float2> tw = twiddles(F::N);
+    std::vector<float2> lds(F::LDS_ELEMS), mid_table(F::MID_TABLE + 1), tables((size_t)2 * F::N);
+    std::vector<float> h(2 * taps);
+    for (int i = 0; i < taps; ++i) { h[i] = (float)fir_mid[i]; h[taps + i] = (float)fir_side[i]; }
+    std::vector<typename CB::Persist> ps(F::T);
+    FOR_THREADS(F::T) CB::load_persist(tid, tw.data(), mid_table.data(), ps[tid]);
+    for (int ch = 0; ch < 2; ++ch) {
+        FOR_THREADS(F::T) CW::phase_load_taps(tid, h.data() + (size_t)ch * taps, ps[tid], lds.data());
+        float2* table = tables.data() + (size_t)ch * F::N;
+        local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) + std::vector<Phase>{[&](int tid) {
+                            CB::phase_write_filter(tid, lds.data(), (float)(gain / F::N), table);
+                        }});
+    }
+    Conv2Args a;
+    a.x = reinterpret_cast<const float2*>(x);
+    a.n = n;
+    a.y = reinterpret_cast<float2*>(y);
+    a.ymid = ymid;
+    a.h_mid = tables.data();
+    a.h_side = tables.data() + F::N;
+    a.tw = tw.data();
+    a.parts = 1;
+    a.npairs = (n + CW::HOP - 1) / CW::HOP;              // blocks
+    a.pair_peak = nullptr;
+    for (long long b = 0; b < a.npairs; ++b) {
+        FOR_THREADS(F::T) {
+            typename CW::Frames fr;
+            CW::fetch(tid, b, a, fr);
+            CW::phase_pass0(tid, ps[tid], fr, lds.data());
+        }
+        std::vector<typename CW::Filters> filt(F::T);
+        local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) + std::vector<Phase>{[&](int tid) {
+                            CW::fetch_filters(tid, a, filt[tid]);
+                            CW::phase_row(tid, lds.data());
+                        }});
+        FOR_THREADS(F::T) CW::phase_multiply(tid, filt[tid], lds.data());   // (mirror rows: a barrier either side)
+        local_phases<F>(std::vector<Phase>{[&](int tid) { CW::phase_row_back(tid, lds.data()); }} +
+                        mid_phases<F>(true, lds.data(), mid_table.data()));
+        float pk = 0.f;
+        FOR_THREADS(F::T) pk = std::fmax(pk, CW::phase_store(tid, b, a, ps[tid], lds.data()));
+        if (block_peak) block_peak[b] = pk;
+    }
+    return 0;
+}
+extern "C" int emu_convolve_wide(const float* x, long long n, const double* fir_mid, const double* fir_side, int taps,
+                                 double gain, float* y, float* ymid, float* block_peak) {
+    switch (ilog2_exact(taps)) {
+#define CASE(L) case L - 2: return conv_wide_impl<L>(x, n, fir_mid, fir_side, taps, gain, y, ymid, block_peak);
         CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         default: return -4;

@@ -122,6 +122,8 @@ def test_code_sizes_are_read_from_the_librarys_own_code_object():
     assert seen["_ZN3mgx9k_analyzeILi12EEEvNS_12AnalysisArgsES1_i"] == analyze[12]
     assert min(seen["_ZN3mgx6k_convILi14ELb0EEEvNS_9Conv2ArgsE"], seen["_ZN3mgx6k_convILi14ELb1EEEvNS_9Conv2ArgsE"]) == conv[14]
     assert seen["_ZN3mgx12k_conv_delayILi14EEEvNS_9Conv2ArgsE"] == conv[15]        # the delay-line kernel's own slot
+    assert seen["_ZN3mgx11k_conv_wideILi14EEEvNS_9Conv2ArgsE"] == conv[6]          # N = 4F: the slot no k_conv<L> uses
+    assert conv_prep[6] > 2000                                                     # ... and its filter preparation
 
 
 def test_the_hot_kernels_do_not_spill():
@@ -142,7 +144,8 @@ def test_the_hot_kernels_do_not_spill():
         return hits[0]
 
     assert scratch("k_conv_delayILi14E") <= 64                  # config #5: 16384 taps (a dozen dwords around the store phase)
-    assert scratch("6k_convILi13ELb0E") == 0                    # the headline workload: 4096 taps
+    assert scratch("11k_conv_wideILi14E") == 0                  # the headline workload: 4096 taps on 16384-point blocks
+    assert scratch("6k_convILi13ELb0E") == 0                    # ... and on 8192-point blocks (MGX_NO_CONV_WIDE=1)
     assert scratch("k_analyzeILi12E") == 0 and scratch("k_analyzeILi14E") == 0
     assert scratch("k_limitILi256ELi4E") <= 16                  # (two spilled scalars of the look-back)
     assert scratch("k_correction_tail") == 0

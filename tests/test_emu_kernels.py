@@ -113,6 +113,31 @@ def test_delay_line_convolution_phases(emu, taps, n, run):
         assert abs(peaks[b] - np.abs(y[b * hop:(b + 1) * hop]).max()) <= 1e-6
 
 
+@pytest.mark.parametrize("taps,n", [(512, 1), (512, 1535), (512, 1536), (1024, 9001), (2048, 30000),
+                                    (4096, 12288), (4096, 5 * 12288 + 4321)])
+def test_wide_block_convolution_phases(emu, taps, n):
+    """F taps on N = 4F blocks (conv_wide_kernel.h: three quarters of a block are fresh output; mid + j side in one
+    transform, pairs of bins un-mixed through the mirror bin): the phase functions of k_conv_wide on the 2048-
+    to 16384-point plans, against the same direct convolution as the other kernels; block peaks too."""
+    rng = np.random.RandomState(taps + n)
+    x = np.ascontiguousarray((0.3 * rng.randn(n, 2)).astype(np.float32))
+    hm, hs = rng.randn(taps) / np.sqrt(taps), rng.randn(taps) / np.sqrt(taps)
+    y = np.zeros((n, 2), dtype=np.float32)
+    ymid = np.zeros(n, dtype=np.float32)
+    hop = 3 * taps
+    nblocks = (n + hop - 1) // hop
+    peaks = np.zeros(nblocks, dtype=np.float32)
+    rc = emu.emu_convolve_wide(_fp(x), ctypes.c_longlong(n), _dp(hm), _dp(hs), ctypes.c_int(taps),
+                               ctypes.c_double(1.3), _fp(y), _fp(ymid), _fp(peaks))
+    assert rc == 0
+    mid, side = mo.mid_side(x.astype(np.float64))
+    want, want_mid = mo.convolve_same(mid * 1.3, hm, side * 1.3, hs)
+    assert rms_error(y, want) <= 1e-6
+    assert rms_error(ymid, want_mid) <= 1e-6
+    for b in range(nblocks):
+        assert abs(peaks[b] - np.abs(y[b * hop:(b + 1) * hop]).max()) <= 1e-6
+
+
 def test_convolution_identity(emu):
     # scipy "same" centring (match_frequencies.py:112): delta at (F-1)//2 is the identity
     rng = np.random.RandomState(5)

@@ -199,6 +199,27 @@ def test_two_partition_filter_as_a_delay_line(n, monkeypatch):
     assert np.abs(y - y2).max() <= 5e-6 and np.abs(ymid - ymid2).max() <= 5e-6 and abs(peak - peak2) <= 5e-6
 
 
+@pytest.mark.parametrize("n", [1, 12287, 12288, 12289, 5 * 12288 + 777, 300 * 12288 + 4321])
+def test_default_filter_on_wide_blocks(n, monkeypatch):
+    """4096 taps (the reference's default fft_size) on 16384-point blocks, three quarters of a block fresh output
+    (k_conv_wide): from one frame to more blocks than workgroups, against fftconvolve and against the N = 2F kernel."""
+    from matchering_amd import kernels
+
+    taps = 4096
+    rng = np.random.RandomState(n % 100000)
+    x = (0.3 * rng.randn(n, 2)).astype(np.float32)
+    hm, hs = rng.randn(taps) / np.sqrt(taps), rng.randn(taps) / np.sqrt(taps)
+    y, ymid, peak = kernels.convolve(x, hm, hs, gain=1.1)
+    mid, side = mo.mid_side(x.astype(np.float64))
+    want, want_mid = mo.convolve_same(mid * 1.1, hm, side * 1.1, hs)
+    assert rms_error(y, want) <= 1e-6
+    assert rms_error(ymid, want_mid) <= 1e-6
+    assert abs(peak - np.abs(y).max()) <= 1e-6
+    monkeypatch.setenv("MGX_NO_CONV_WIDE", "1")
+    y2, ymid2, peak2 = kernels.convolve(x, hm, hs, gain=1.1)
+    assert np.abs(y - y2).max() <= 5e-6 and np.abs(ymid - ymid2).max() <= 5e-6 and abs(peak - peak2) <= 5e-6
+
+
 def test_master_long_fir_96k():
     """BASELINE config #5 in miniature: 96 kHz, fft_size 16384 (16 k-tap matching FIR), full pipeline
     against the oracle."""
