@@ -4,10 +4,13 @@
 // F = 4096, the reference's default fft_size, on N = 16384.  conv2_kernel.h runs that filter on N = 2F = 8192:
 // half of every transform's output is overlap, 4 transforms of 8192 points per 8192 frames, 6.2 k VALU
 // instructions per thread and pair on a kernel that is bound by exactly that (the VALU issue
-// roofline).  On N = 4F a quarter is overlap: 2 transforms of 16384 points per 12288 frames, a fifth fewer
-// instructions per frame.  Round 1 and round 4 both measured that trade and lost it (264 against 148 us) with a
-// 16384-point transform that took 15 us of a CU; the one conv_delay_kernel.h was built around takes a third of
-// that, and this kernel is that one with a single filter partition:
+// roofline).  On N = 4F a quarter is overlap: 2 transforms of 16384 points per 12288 frames -- a third fewer points
+// per frame, 7.5 % fewer instructions (178 against 192.5 per frame: the fourth pass of the larger transform costs a
+// layer of twiddles and the un-mixing below four complex multiplies per pair of bins), and 14.5 KB of code instead of
+// 38 KB, which is what a slow box of the pool pays for.  Round 1 and round 4 both measured the
+// trade and lost it (264 against 148 us) with a 16384-point transform that took 15 us of a CU; the one
+// conv_delay_kernel.h was built around takes a third of that, and this kernel is that one with a single filter
+// partition (145-147 against 149-151 us on fast boxes, 144 against 157 on slow ones: profiles/r04_wide_blocks.txt):
 //
 //  * both channels share one transform, z = mid + j side, un-mixed at the multiply through the mirror bin;
 //  * a thread multiplies PAIRS of bins -- the lower half of its own row and their mirrors in the upper half of the
