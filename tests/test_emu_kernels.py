@@ -138,6 +138,34 @@ def test_wide_block_convolution_phases(emu, taps, n):
         assert abs(peaks[b] - np.abs(y[b * hop:(b + 1) * hop]).max()) <= 1e-6
 
 
+def test_wide_and_delay_line_kernels_over_random_lengths(emu):
+    """Track lengths and run lengths drawn at random (fixed seed) around the block boundaries of the two 16384-point
+    kernels' small-plan twins: every length from 'shorter than a block' to 'a few blocks and a bit' must come out as
+    the direct convolution -- the ends of a track are where the window arithmetic can be off by one."""
+    rng = np.random.RandomState(2024)
+    mid_side = lambda x: mo.mid_side(x.astype(np.float64))
+    for taps, wide in ((512, True), (1024, True), (2048, False), (4096, False)):
+        hop = 3 * taps if wide else taps // 2
+        hm, hs = rng.randn(taps) / np.sqrt(taps), rng.randn(taps) / np.sqrt(taps)
+        for _ in range(6):
+            n = int(rng.choice([rng.randint(1, hop), hop * rng.randint(1, 5) + rng.randint(-2, 3), rng.randint(1, 6 * hop)]))
+            n = max(1, n)
+            x = np.ascontiguousarray((0.3 * rng.randn(n, 2)).astype(np.float32))
+            y = np.zeros((n, 2), dtype=np.float32)
+            ymid = np.zeros(n, dtype=np.float32)
+            if wide:
+                rc = emu.emu_convolve_wide(_fp(x), ctypes.c_longlong(n), _dp(hm), _dp(hs), ctypes.c_int(taps),
+                                           ctypes.c_double(1.0), _fp(y), _fp(ymid), None)
+            else:
+                rc = emu.emu_convolve_delay(_fp(x), ctypes.c_longlong(n), _dp(hm), _dp(hs), ctypes.c_int(taps),
+                                            ctypes.c_double(1.0), _fp(y), _fp(ymid), None, ctypes.c_int(int(rng.randint(1, 6))))
+            assert rc == 0
+            m, sd = mid_side(x)
+            want, want_mid = mo.convolve_same(m, hm, sd, hs)
+            assert np.abs(y - want).max() <= 5e-6, (taps, wide, n)
+            assert np.abs(ymid - want_mid).max() <= 5e-6, (taps, wide, n)
+
+
 def test_convolution_identity(emu):
     # scipy "same" centring (match_frequencies.py:112): delta at (F-1)//2 is the identity
     rng = np.random.RandomState(5)
