@@ -8,7 +8,6 @@ rate change -- same purpose, not sample-identical to resampy, and only reached w
 differs from the internal rate.
 """
 
-from math import gcd
 
 import numpy as np
 
@@ -52,10 +51,9 @@ def _resample(array, sample_rate, required):
 
         return resample(array, sample_rate, required, axis=0)
     except ImportError:
-        from scipy.signal import resample_poly
+        from .resample import resample     # the same algorithm restated (resampy is not a dependency one can count on)
 
-        g = gcd(int(required), int(sample_rate))
-        return resample_poly(array, int(required) // g, int(sample_rate) // g, axis=0)
+        return resample(array, sample_rate, required)
 
 
 LATER = object()      # check(..., peaks=LATER): the caller will hand the peak statistics to peak_warnings itself
