@@ -2,9 +2,9 @@
 stereo, resampling to ``config.internal_sample_rate``, clipping / limiter detection on the target,
 and the "target equals reference" guard.  Host numpy: none of this is on the timed path.
 
-Resampling: the reference calls ``resampy.resample`` (Kaiser-windowed sinc).  ``resampy`` is used
-when it is importable; otherwise ``scipy.signal.resample_poly`` (polyphase Kaiser FIR) does the
-rate change -- same purpose, not sample-identical to resampy, and only reached when a file's rate
+Resampling: the reference calls ``resampy.resample`` (Kaiser-windowed sinc table, ``kaiser_best``).  ``resampy`` is
+used when it is importable; otherwise ``matchering_amd.resample`` does the rate change -- the same algorithm
+restated (parity with the package unpinned: it is not in the build image), only reached when a file's rate
 differs from the internal rate.
 """
 
