@@ -6,7 +6,8 @@ When resampy is installed it is used as it is; where it is not (this image), ``r
 algorithm restated in numpy -- the Kaiser-windowed sinc table of ``resampy.filters.sinc_window(64, 9,
 kaiser(beta=14.769656459379492), rolloff=0.9475937167399596)``, output sample t at input time t / ratio, left and
 right filter wings with stride int(scale * 512) through the table and linear interpolation between its entries
-(``resampy.interpn.resample_f``) -- evaluated a block of output samples at a time instead of one.  It replaces
+(``resampy.interpn.resample_f``) -- evaluated as the polyphase filter it is (all phases of the rational ratio in one
+prototype, scipy's ``upfirdn``: 5 s for an 8-minute stereo file) instead of sample by sample.  It replaces
 the polyphase resampler of scipy used until round 3, which is a different filter and agreed with resampy only
 to the audible, not to the numerical.  Parity with the package itself is unpinned (it is nowhere in the image);
 tests/test_resample.py holds this file against a literal restatement of the package's loops
@@ -79,46 +80,57 @@ def _literal(plan, flat, t, out):
     out[t] = acc
 
 
+def _prototype(plan, phases, hop):
+    """resampy's weights for all `phases` fractional positions p / phases, laid out as the prototype filter of a
+    polyphase resampler: with output t at input time t hop / phases = n + p / phases, the left wing's weight of
+    x[n - i] sits at tap p + i phases and the right wing's weight of x[n + k + 1] at tap p - (k + 1) phases (taps
+    counted from the centre).  Wing lengths, table stride (an INTEGER, int(scale * 512): the stride through the table
+    is not scale * 512) and the interpolation between table entries are resampy's, phase by phase.
+    Returns (taps, index of the centre tap -- a multiple of `hop`)."""
+    frac = np.arange(phases) / phases
+    i = np.arange(plan.taps)
+    wings = []
+    for right in (False, True):
+        offset, eta, count = plan.wing(frac, right)
+        on = i[None, :] < count[:, None]
+        at = np.where(on, offset[:, None] + i[None, :] * plan.index_step, 0)
+        wings.append(np.where(on, plan.win[at] + eta[:, None] * plan.delta[at], 0.0))      # [phase, tap]
+    reach = plan.taps * phases
+    centre = -(-reach // hop) * hop
+    proto = np.zeros(2 * centre + phases)
+    p = np.arange(phases)
+    proto[centre + p[:, None] + i[None, :] * phases] = wings[0]
+    proto[centre + p[:, None] - (i[None, :] + 1) * phases] = wings[1]
+    return proto, centre
+
+
 def resample(array, sample_rate, required, block=8192, max_phases=4096):
     """``array`` (n,) or (n, channels) at ``sample_rate`` -> int(n * required / sample_rate) samples at ``required``.
 
-    required / sample_rate = L / M in lowest terms: output t sits at input time t M / L, so the filter weights of
-    outputs t and t + L are the same and their windows lie M input samples apart.  Away from the ends of the array
-    (where a wing is cut short) every one of the L phases is therefore one matrix product of a strided view of the
-    input with its weight vector; the phase arithmetic is exact (integers), where resampy's own t * (1 / ratio) carries
-    a rounding of ~1e-16 t that moves a weight by ~1e-9 at the end of an hour of audio.  The ends, and ratios with
-    more than `max_phases` phases, go through the literal per-sample form."""
+    required / sample_rate = L / M in lowest terms: output t sits at input time t M / L = n + p / L, and resampy's
+    weights depend on the phase p only.  Its sum over the two filter wings is therefore a polyphase filter -- zero-stuff
+    by L, filter with the prototype of _prototype(), keep every M-th sample -- which scipy's ``upfirdn`` evaluates
+    without the zeros; samples outside the array count as zeros in both forms (resampy cuts its wings short there).  The phase arithmetic is exact (integers), where resampy's own t * (1 / ratio) carries a
+    rounding of ~1e-16 t that moves a weight by ~1e-9 at the end of an hour of audio.  Ratios with more than `max_phases`
+    phases, and rates that are not integers, go through the literal per-sample form."""
+    from scipy.signal import upfirdn
+
     x = np.ascontiguousarray(array, dtype=np.float64)
     flat = x.reshape(x.shape[0], -1)
     plan = _Plan(sample_rate, required)
     n_orig, channels = flat.shape
     n_out = int(n_orig * plan.ratio)
     y = np.zeros((n_out, channels), dtype=np.float64)
-    g = np.gcd(int(required), int(sample_rate))
+    whole = float(required) == int(required) and float(sample_rate) == int(sample_rate)
+    g = np.gcd(int(required), int(sample_rate)) if whole else 1
     phases, hop = int(required) // g, int(sample_rate) // g          # L, M
-    # outputs whose wings are complete: taps <= n(t) and n(t) + taps + 1 <= n_orig - 1, with n(t) = t M // L
-    lo = -(-plan.taps * phases // hop)
-    hi = min(n_out, ((n_orig - plan.taps - 2) * phases) // hop)       # (exclusive, and a little conservative)
-    if phases > max_phases or float(required) != int(required) or float(sample_rate) != int(sample_rate) or hi - lo < 4 * phases:
-        lo = hi = 0
-    for t0 in list(range(0, lo, block)) + list(range(hi, n_out, block)):
-        _literal(plan, flat, np.arange(t0, min(lo if t0 < lo else n_out, t0 + block)), y)
-    step0, step1 = flat.strides
-    for phase in range(phases if hi > lo else 0):
-        t0 = lo + (phase - lo) % phases                               # the first interior output of this phase
-        rows = (hi - 1 - t0) // phases + 1
-        if rows <= 0:
-            continue
-        n0, rem = divmod(t0 * hop, phases)
-        frac = np.array([rem / phases])
-        (off_l, eta_l, cnt_l), (off_r, eta_r, cnt_r) = plan.wing(frac, False), plan.wing(frac, True)
-        il, ir = np.arange(int(cnt_l[0])), np.arange(int(cnt_r[0]))
-        at_l, at_r = off_l[0] + il * plan.index_step, off_r[0] + ir * plan.index_step
-        left = plan.win[at_l] + eta_l[0] * plan.delta[at_l]           # weights of x[n], x[n-1], ...
-        right = plan.win[at_r] + eta_r[0] * plan.delta[at_r]          # weights of x[n+1], x[n+2], ...
-        weights = np.concatenate([left[::-1], right])                 # of x[n - len(left) + 1 ... n + len(right)]
-        first = n0 - len(left) + 1
-        view = np.lib.stride_tricks.as_strided(flat[first:], shape=(rows, len(weights), channels),
-                                               strides=(hop * step0, step0, step1), writeable=False)
-        y[t0:t0 + rows * phases:phases] = np.tensordot(view, weights, axes=([1], [0]))
+    if not whole or phases > max_phases or n_out == 0:
+        for t0 in range(0, n_out, block):
+            _literal(plan, flat, np.arange(t0, min(n_out, t0 + block)), y)
+        return y.reshape((n_out,) + x.shape[1:])
+    proto, centre = _prototype(plan, phases, hop)
+    full = upfirdn(proto, flat, up=phases, down=hop, axis=0)
+    first = centre // hop
+    got = full[first:first + n_out]
+    y[:got.shape[0]] = got
     return y.reshape((n_out,) + x.shape[1:])

@@ -19,10 +19,12 @@ def test_the_filter_is_resampys_kaiser_best():
 
 
 @pytest.mark.parametrize("sr,new,n", [(48000, 44100, 700), (48000, 44100, 3000), (44100, 48000, 3000), (96000, 44100, 6000),
-                                      (22050, 44100, 2000), (44100, 44101, 300), (8000, 44100, 900)])
+                                      (22050, 44100, 2000), (44100, 44101, 300), (8000, 44100, 900), (192000, 44100, 9000),
+                                      (44100, 22050, 1000), (48000, 44100, 5)])
 def test_vectorised_form_equals_the_loops(sr, new, n):
-    """Short arrays go through the literal per-sample form, longer ones through one matrix product per phase of the
-    ratio in the interior and the literal form at the ends; both must be the loops of the restatement."""
+    """The product evaluates resampy's sum as a polyphase filter (one prototype holding the weights of every phase of
+    the rational ratio, scipy's upfirdn), or literally, sample by sample, when the ratio has too many phases; both
+    must be the loops of the restatement, ends of the array included."""
     rng = np.random.RandomState(sr % 1000 + n)
     x = rng.randn(n, 2)
     got = product.resample(x, sr, new, block=257)
