@@ -48,8 +48,18 @@ PIPELINE_BYTES = {"8min_full": 72, "8min_fir_only": 64, "4min_x8_full": 72, "96k
 KERNEL_BYTES = {"convolve": 16,    # S3: read 8 + write 8 (the mid plane's 4 B are booked to S4)
                 "limit": 16}       # read 8 + write 8 per launch of the one-pass limiter (S5's 24 B model
                                    # counts a second read that this kernel takes from the L2 / Infinity Cache)
-KERNEL_NAMES = {"convolve": "k_conv (overlap-save FIR)", "limit": "k_limit (Hyrax limiter, one pass)"}
 WORKLOADS = sorted(PIPELINE_BYTES)
+
+
+def kernel_name(stage, fft):
+    """The kernel a stage's launch runs (csrc/mgx.hip run_conv / launch_limiter pick it from the FIR length)."""
+    if stage == "limit":
+        return "k_limit<256,4> (Hyrax limiter, one pass)"
+    if fft == 4096:
+        return "k_conv_wide<14> (overlap-save FIR, 4096 taps on 16384-point blocks)"
+    if fft == 16384:
+        return "k_conv_delay<14> (overlap-save FIR, two-partition frequency-domain delay line)"
+    return "k_conv (overlap-save FIR, N = 2F)"
 
 
 def parse():
@@ -66,6 +76,9 @@ def parse():
     ap.add_argument("--no-gpu-state", action="store_true", help="skip the clock / power / partition probe")
     ap.add_argument("--stand-in", action="store_true",
                     help="no GPU: a step is 1 ms of sleep (the multi-rank plumbing of this script, for the CPU tests)")
+    ap.add_argument("--lanes", type=int, default=0,
+                    help="device handles per GPU for 4min_x8_full; 0 = rank 0 measures two against three once and every "
+                         "rank adopts its choice (batch.choose_lanes)")
     ap.add_argument("--spinup", type=float, default=0.5,
                     help="seconds of untimed steps before the warm-up (the device climbs out of its idle clocks)")
     return ap.parse_args()
@@ -153,7 +166,7 @@ def timed_steps(ranks, sync, step, steps, warmup, own=None):
 class Workload:
     """Resident inputs/outputs of one named workload on this rank and the function that runs one step."""
 
-    def __init__(self, name, rank, local, mg, Device, device_count, make_pair, world=1):
+    def __init__(self, name, rank, local, mg, Device, device_count, make_pair, world=1, lanes=0):
         self.name = name
         from matchering_amd.batch import choose_lanes, lane_choice_report, lane_device
 
@@ -168,8 +181,14 @@ class Workload:
             # (batch.choose_lanes: a pair's latency-bound stretches -- FIR design, level decisions, the
             # limiter's look-back waits -- are filled by the other pairs' kernels; boxes of the pool disagree
             # on whether the third handle still pays).  Outside the timed region.
-            count = choose_lanes(index, world_size=world)      # (ranks that share a GPU share its lane budget)
-            self.lane_choice = lane_choice_report(index)
+            from matchering_amd.batch import lanes_allowed
+
+            if lanes > 0:                                       # given (or decided by rank 0): nothing is measured here
+                count = min(lanes, lanes_allowed(world))
+                self.lane_choice = {"lanes": count, "given": True}
+            else:
+                count = choose_lanes(index, world_size=world)  # (ranks that share a GPU share its lane budget)
+                self.lane_choice = lane_choice_report(index)
             self.lanes = [lane_device(index, k) for k in range(count)]
         elif name == "96k_16k_full":
             self.sample_rate, self.fft, self.seconds = 96000, 16384, 240.0
@@ -249,7 +268,7 @@ def measure_traffic(workload, timeout=150):
         folder = tempfile.mkdtemp(prefix="mgx_pmc_", dir="/tmp")
         try:
             cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", folder, "-o", "r",
-                   "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1",
+                   "--", sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--spinup", "0",
                    "--no-cpu-baseline", "--no-secondary", "--no-traffic", "--no-gpu-state", "--workload", workload]
             subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=timeout, check=True)
@@ -261,24 +280,35 @@ def measure_traffic(workload, timeout=150):
                             for row in csv.DictReader(fh):
                                 if row.get("Counter_Name") == counter:
                                     acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
-            kib[counter] = {k: sum(v) / len(v) for k, v in acc.items()}
+            kib[counter] = dict(acc)
         except Exception:                                   # noqa: BLE001 -- a measurement aid: never lose the line
             return {}
         finally:
             shutil.rmtree(folder, ignore_errors=True)
     out = {}
-    for stage, pattern in (("convolve", "k_conv<"), ("limit", "k_limit")):
-        fetch = [v for k, v in kib["FETCH_SIZE"].items() if pattern in k]
-        write = [v for k, v in kib["WRITE_SIZE"].items() if pattern in k]
+    # (k_conv<..>, k_conv_wide<..>, k_conv_delay<..>: whichever the FIR length selects; not their *_prep kernels)
+    for stage, wanted in (("convolve", lambda k: "k_conv" in k and "prep" not in k and "direct" not in k),
+                          ("limit", lambda k: "k_limit" in k)):
+        fetch = [max(v) for k, v in kib["FETCH_SIZE"].items() if wanted(k)]
+        write = [max(v) for k, v in kib["WRITE_SIZE"].items() if wanted(k)]
         if fetch and write:
             out[stage] = int(max(fetch) * 1024 * 2 + max(write) * 1024)
+    # the whole step, every kernel: counter bytes of all launches / the number of steps the child ran (one k_analyze each)
+    steps = max((len(v) for k, v in kib["FETCH_SIZE"].items() if "k_analyze" in k), default=0)
+    if steps:
+        fetched = sum(sum(v) for v in kib["FETCH_SIZE"].values()) * 1024 * 2 / steps
+        written = sum(sum(v) for v in kib["WRITE_SIZE"].values()) * 1024 / steps
+        out["step_bytes"] = int(fetched + written)
+        out["step_kernels"] = {k.split("(")[0][:48]: int((sum(v) * 2 + sum(kib["WRITE_SIZE"].get(k, [0.0]))) * 1024 / steps)
+                               for k, v in kib["FETCH_SIZE"].items()
+                               if (sum(v) * 2 + sum(kib["WRITE_SIZE"].get(k, [0.0]))) * 1024 / steps > 1e6}
     return out
 
 
-def roofline_of(kernel, ms, frames, traffic):
+def roofline_of(kernel, ms, frames, traffic, fft=4096):
     alg = KERNEL_BYTES[kernel] * frames
     achieved = alg / (ms * 1e-3) / 1e9
-    return {"kernel": KERNEL_NAMES[kernel], "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+    return {"kernel": kernel_name(kernel, fft), "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "frac_of_measured_copy_ceiling": round(achieved / HBM_COPY_GBS, 4), "traffic": traffic,
             "kernel_ms": round(ms, 4), "algorithmic_bytes_per_launch": alg,
@@ -355,7 +385,21 @@ def run(args, ranks):
         name = args.workload
         if name == "auto":
             name = "8min_full" if ranks.world == 1 else "4min_x8_full"
-        wl = Workload(name, ranks.rank, ranks.local, mg, Device, device_count, make_pair, world=ranks.world)
+        lanes = args.lanes
+        if name == "4min_x8_full" and lanes <= 0 and ranks.world > 1:
+            # ONE calibration per job, not one per rank: rank 0 measures two handles against three on its GPU (the GPUs
+            # of a node are one model) while the others wait at a barrier, and every rank adopts the choice
+            from matchering_amd.batch import choose_lanes, lane_choice_report
+
+            mine = None
+            if ranks.rank == 0:
+                count = choose_lanes(ranks.local % max(1, device_count()), world_size=ranks.world)
+                mine = dict(lane_choice_report(ranks.local % max(1, device_count())) or {"lanes": count}, decided_by="rank 0")
+            decided = ranks.gather(mine)[0]
+            lanes = int(decided["lanes"])
+        wl = Workload(name, ranks.rank, ranks.local, mg, Device, device_count, make_pair, world=ranks.world, lanes=lanes)
+        if name == "4min_x8_full" and args.lanes <= 0 and ranks.world > 1:
+            wl.lane_choice = decided
     spun = spin_up(wl.sync, wl.step, args.spinup)
     own_seconds = []
     elapsed = timed_steps(ranks, wl.sync, wl.step, args.steps, args.warmup, own_seconds)
@@ -364,6 +408,16 @@ def run(args, ranks):
     ms_per_step = elapsed / args.steps * 1e3
     model = PIPELINE_BYTES.get(name, 0)
     pipeline_gbs = model * wl.frames * ranks.world / (elapsed / args.steps) / 1e9
+    # which physical GPU every rank sits on (PCI address from the HIP runtime): "N ranks on N GPUs" is checkable, and
+    # the roofline is taken against the GPUs that really exist -- ranks that share one share its 8 TB/s
+    if args.stand_in:
+        my_gpu = f"stand-in-{ranks.rank}"
+    else:
+        from matchering_amd.device import pci_bus_id
+
+        my_gpu = pci_bus_id(ranks.local % max(1, device_count()))
+    rank_gpus = ranks.gather(my_gpu)
+    physical = len(set(rank_gpus))
 
     line.update({
         "value": round(value, 2), "ms_per_step": round(ms_per_step, 4),
@@ -373,11 +427,15 @@ def run(args, ranks):
         "config": {"workload": wl.describe(), "frames_per_gpu_per_step": wl.frames,
                    "pairs_per_gpu_per_step": wl.pairs, "parallelism": f"pairs x{ranks.world * wl.pairs}",
                    **({"lane_choice": wl.lane_choice} if wl.lane_choice else {})},
+        "rank_gpus": rank_gpus, "physical_gpus": physical, "shared_gpu": physical < ranks.world,
         "pipeline_hbm_model": {"bytes_per_frame": model, "achieved_GBs": round(pipeline_gbs, 1),
-                               "peak_GBs": HBM_PEAK_GBS * ranks.world,
-                               "frac_of_8TBs": round(pipeline_gbs / (HBM_PEAK_GBS * ranks.world), 4),
-                               "frac_of_6p29TBs": round(pipeline_gbs / (HBM_COPY_GBS * ranks.world), 4),
-                               "note": "whole job: bytes of all ranks against N x the one-GPU figures"},
+                               "peak_GBs": HBM_PEAK_GBS * physical,
+                               "frac_of_8TBs": round(pipeline_gbs / (HBM_PEAK_GBS * physical), 4),
+                               "frac_of_6p29TBs": round(pipeline_gbs / (HBM_COPY_GBS * physical), 4),
+                               "note": "whole job: bytes of all ranks against the one-GPU figures x the PHYSICAL GPUs the "
+                                       "ranks sit on (rank_gpus); measured_bytes = HBM bytes per step by the PMC counters, "
+                                       "all kernels (null when the profiler cannot be used)",
+                               "measured_bytes": None, "measured_frac_of_8TBs": None},
     })
     # every rank's own time for the K steps (up to its own stream synchronisation, before the closing barrier)
     line["rank_seconds"] = [round(v, 6) for v in ranks.gather(own_seconds[0])]
@@ -432,6 +490,17 @@ def run(args, ranks):
     elif ranks.world > 1:
         line["rendezvous"] = {"ranks_seen": len(ranks.gather(ranks.rank)), "transport": "matchering_amd.ranks"}
 
+    if ranks.world > 1 and not stuck:
+        # the SAME workload on one rank alone (the other ranks are idle, their GPUs too): the N = 1 point of a scaling
+        # curve that is one workload -- the N = 1 default of this script is the 8-minute pair, another workload
+        alone = Ranks(rank=0, world=1, local=ranks.local)
+        if ranks.rank == 0:
+            e1 = timed_steps(alone, wl.sync, wl.step, args.steps, 1)
+            line["n1_same_workload"] = {"value": round(wl.frames * args.steps / e1 / 1e6, 2), "unit": "Msamples/s",
+                                        "ms_per_step": round(e1 / args.steps * 1e3, 4), "workload": name,
+                                        "note": "rank 0 alone right after the timed region, same resident pairs and lanes; "
+                                                "value / (n_gpus x this) is the weak-scaling efficiency of ONE workload"}
+        ranks.barrier()                              # (the others must not start tearing down under rank 0's run)
     if ranks.rank == 0 and not args.stand_in and not stuck:
         # ---- rooflines of the two streaming kernels, timed where they run: inside the pipeline ----
         # (at N > 1 the other ranks are idle by now: these legs describe one GPU, as at N = 1)
@@ -441,7 +510,12 @@ def run(args, ranks):
         # the same workload); null when the profiler cannot be used
         traffic = {} if args.no_traffic else measure_traffic(name)
         kernels = [k for k in ("convolve", "limit") if k in stage_ms]
-        per = {k: roofline_of(k, stage_ms[k], n0, traffic.get(k)) for k in kernels}
+        per = {k: roofline_of(k, stage_ms[k], n0, traffic.get(k), wl.fft) for k in kernels}
+        if traffic.get("step_bytes"):
+            pm = line["pipeline_hbm_model"]
+            pm["measured_bytes"] = traffic["step_bytes"] * wl.pairs
+            pm["measured_frac_of_8TBs"] = round(traffic["step_bytes"] * wl.pairs / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            pm["measured_bytes_by_kernel"] = traffic.get("step_kernels")
         for k in kernels:
             per[k]["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE (x2, KiB) + --pmc WRITE_SIZE (KiB), one pass each, "
                                         "child runs of this script in this call" if k in traffic else None)
@@ -570,24 +644,95 @@ def host_to_host_batch(mg, make_pair, pairs=8, seconds=240.0, lanes=2):
             "note": f"{pairs} x {seconds:.0f} s pairs, pinned numpy in -> pinned numpy out, {lanes} lanes"}
 
 
-def _oracle_worker(seconds, sample_rate, fft, need, pair):
+def _cpu_worker(seconds, sample_rate, fft, need, pair, use_reference):
+    """One process of the all-host-cores figure: its own synthetic pair through the reference's stages.main (when
+    staged) or the oracle; returns (seconds of the call, frames)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import mastering_oracle as mo
     from matchering_amd.synth import make_pair
 
     target, reference = make_pair(seconds, sample_rate, pair=pair)
+    if use_reference:
+        import warnings
+
+        import build_ref
+
+        mg_ref = build_ref.load()
+        from matchering import stages as ref_stages
+
+        cfg = mg_ref.Config(internal_sample_rate=sample_rate, fft_size=fft)
+        t64, r64 = target.astype(np.float64), reference.astype(np.float64)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t0 = time.perf_counter()
+            ref_stages.main(t64, r64, cfg, need_default=need[0], need_no_limiter=need[1], need_no_limiter_normalized=need[2])
+            return time.perf_counter() - t0, target.shape[0]
+    import mastering_oracle as mo
+
     cfg = mo.params(internal_sample_rate=sample_rate, fft_size=fft)
     t0 = time.perf_counter()
     mo.master(target, reference, cfg, *need)
     return time.perf_counter() - t0, target.shape[0]
 
 
+def reference_main(target, reference, sample_rate, fft, need, runs_budget_s=12.0):
+    """The reference's OWN stages.main (stages.py:210-272), unmodified, timed on this host: the package as
+    oracle/build_ref.py byte-compiled it from /root/reference (oracle/_ref/, shipped with the snapshot -- the tree
+    itself does not exist on the GPU box), soundfile / resampy stubbed (file I/O, never reached from stages.main) and
+    statsmodels' LOWESS served by the pinned restatement (BASELINE.md section 3, option B).  Inputs: the GPU path's
+    float32 values as float64, the reference's native type.  Returns (seconds of the best run, runs, output, info) or
+    None when no staged reference is here."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    try:
+        import build_ref
+
+        mg_ref = build_ref.load()
+    except Exception as exc:                                 # noqa: BLE001 -- not staged / wrong interpreter: the port stands in
+        return None, repr(exc)[:200]
+    import warnings
+
+    from matchering import stages as ref_stages
+
+    cfg = mg_ref.Config(internal_sample_rate=sample_rate, fft_size=fft)
+    t64, r64 = target.astype(np.float64), reference.astype(np.float64)
+    runs, out = [], None
+    t_all = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        while len(runs) < 2 or (time.perf_counter() - t_all < runs_budget_s and len(runs) < 4):
+            t0 = time.perf_counter()
+            out = ref_stages.main(t64.copy(), r64.copy(), cfg, need_default=need[0], need_no_limiter=need[1],
+                                  need_no_limiter_normalized=need[2])
+            runs.append(time.perf_counter() - t0)
+    m = build_ref.manifest()
+    import platform
+
+    import scipy
+
+    info = {"package": f"sergree/matchering {m.get('version')}", "modules": len(m.get("files", {})),
+            "python": platform.python_version(), "numpy": np.__version__, "scipy": scipy.__version__,
+            "lowess": "oracle/mastering_oracle.py lowess_it0 (statsmodels is not installed; pinned to the compiled "
+                      "statsmodels 0.12.2 to 1e-12 by tests/golden)"}
+    return (min(runs), runs, next(o for o in out if o is not None), info), None
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(wl, name, all_cores=True):
-    """The numpy/scipy restatement of stages.main (oracle/, test infrastructure) timed on this box's
-    host cores: (i) one process on the workload's own first pair, what a matchering user gets; (ii)
-    BASELINE.md section 3's all-host-cores figure, P concurrent processes of one pair each, on a bounded
-    sample.  ``port_vs_reference`` is the wall-time ratio oracle / unmodified reference measured on the
-    build container (profiles/cpu_port_vs_reference.json; the reference tree does not exist here)."""
+    """The reference's CPU path on this box's host cores, beside every GPU number:
+    (i) ``kind: "reference"`` -- sergree/matchering's own ``stages.main`` (reference_main above) on the workload's first
+    pair, one process, what a matchering user gets; the oracle (``port``: oracle/mastering_oracle.py, the numpy/scipy
+    restatement the parity tests use) is timed on the same pair and kept beside it; when no staged reference is
+    here the port IS the baseline and says so (``kind: "port"``);  (ii) the all-host-cores figure: P concurrent
+    processes of one 60-second pair each (the port: the processes are the oracle's)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mastering_oracle as mo
 
@@ -597,25 +742,39 @@ def cpu_baseline(wl, name, all_cores=True):
     runs = []
     result = None
     t_all = time.perf_counter()
-    while len(runs) < 2 or (time.perf_counter() - t_all < 12.0 and len(runs) < 6):
+    while len(runs) < 2 or (time.perf_counter() - t_all < 8.0 and len(runs) < 4):
         t0 = time.perf_counter()
         result = mo.master(target, reference, ocfg, *need)
         runs.append(time.perf_counter() - t0)
     result = next(r for r in result if r is not None)
     cpu_s = min(runs)
     n = target.shape[0]
-    out = {"value": round(n / cpu_s / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-           "seconds": round(cpu_s, 2), "runs": len(runs),
-           "sample": f"the workload's first pair ({n} frames), best of {len(runs)} runs of "
-                     f"oracle/mastering_oracle.py (numpy/scipy float64 restatement of stages.main, one thread; "
-                     f"{sum(runs):.0f} s of CPU work); host has {os.cpu_count()} logical cores"}
-    ratio_path = os.path.join(ROOT, "profiles", "cpu_port_vs_reference.json")
-    if os.path.exists(ratio_path):
-        with open(ratio_path) as fh:
-            out["port_vs_reference"] = json.load(fh)
-    out["note"] = ("kind 'port': this is the oracle, not sergree/matchering itself -- the reference tree does not exist "
-                   "on the GPU box.  port_vs_reference is the oracle / reference wall-time ratio measured on ANOTHER "
-                   "machine (the build container, its `host` field), so value / ratio estimates the reference here")
+    port = {"value": round(n / cpu_s / 1e6, 3), "unit": "Msamples/s", "cores": 1, "seconds": round(cpu_s, 2),
+            "runs": len(runs), "what": "oracle/mastering_oracle.py (numpy/scipy float64 restatement of stages.main), one thread"}
+    host = {"cpu": cpu_model(), "logical_cores": os.cpu_count()}
+    ref, why_not = reference_main(target, reference, wl.sample_rate, wl.fft, need)
+    if ref is not None:
+        ref_s, ref_runs, ref_out, info = ref
+        gap = ref_out - result
+        out = {"value": round(n / ref_s / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "reference",
+               "seconds": round(ref_s, 2), "runs": len(ref_runs), "host": host, "reference": info,
+               "sample": f"the workload's first pair ({n} frames, float32 values as float64), best of {len(ref_runs)} runs of "
+                         f"matchering.stages.main (stages.py:210-272, unmodified; {sum(ref_runs):.0f} s of CPU work), one "
+                         f"process: the reference is single-threaded",
+               "port": dict(port, port_over_reference_seconds=round(cpu_s / ref_s, 3),
+                            max_abs_difference_from_reference=float(np.abs(gap).max())),
+               "note": "kind 'reference': sergree/matchering's own stages.main, byte-compiled from /root/reference by "
+                       "oracle/build_ref.py and shipped under oracle/_ref/ (git-ignored); `port` is the oracle on the same pair"}
+    else:
+        out = dict(port, kind="port", host=host,
+                   sample=f"the workload's first pair ({n} frames), best of {len(runs)} runs of oracle/mastering_oracle.py "
+                          f"({sum(runs):.0f} s of CPU work)",
+                   note=f"kind 'port': no staged reference on this box ({why_not}); this is the oracle, not "
+                        f"sergree/matchering itself")
+        ratio_path = os.path.join(ROOT, "profiles", "cpu_port_vs_reference.json")
+        if os.path.exists(ratio_path):
+            with open(ratio_path) as fh:
+                out["port_vs_reference"] = json.load(fh)
     if not all_cores:
         return out, result
     try:
@@ -624,14 +783,14 @@ def cpu_baseline(wl, name, all_cores=True):
         procs = max(1, min(os.cpu_count() or 1, 32))
         sample_seconds = 60.0
         with cf.ProcessPoolExecutor(max_workers=procs) as pool:
-            done = list(pool.map(_oracle_worker, [sample_seconds] * procs, [wl.sample_rate] * procs, [wl.fft] * procs,
-                                 [need] * procs, range(procs)))
+            done = list(pool.map(_cpu_worker, [sample_seconds] * procs, [wl.sample_rate] * procs, [wl.fft] * procs,
+                                 [need] * procs, range(procs), [ref is not None] * procs))
         slowest = max(d[0] for d in done)
         out["all_cores"] = {"value": round(sum(d[1] for d in done) / slowest / 1e6, 3), "unit": "Msamples/s",
-                            "processes": procs,
+                            "processes": procs, "kind": "reference" if ref is not None else "port",
                             "sample": f"{procs} concurrent processes (of {os.cpu_count()} logical cores), one "
                                       f"{sample_seconds:.0f} s pair each, frames of all / time of the slowest "
-                                      f"({slowest:.1f} s; each process times its own call of the oracle)"}
+                                      f"({slowest:.1f} s; each process times its own call of stages.main)"}
     except Exception as exc:           # noqa: BLE001
         out["all_cores"] = {"error": str(exc)[:200]}
     return out, result

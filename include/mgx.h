@@ -82,6 +82,10 @@ typedef struct mgx_report {
 int mgx_version(void);
 const char* mgx_last_error(void);
 int mgx_device_count(int* count);
+/* PCI address of GPU `device` as the driver prints it ("0000:0d:00.0", NUL-terminated, capacity >= 16): which physical
+ * GPU a rank really sits on -- the batch front end and bench.py put it beside every rank's numbers (core.py:32-121 has
+ * no notion of devices; this is part of the new surface, like the handle). */
+int mgx_device_pci_bus_id(int device, char* out, int32_t capacity);
 int mgx_create(int device, mgx_handle** out);
 int mgx_destroy(mgx_handle* h);
 int mgx_config_default(mgx_config* cfg);         /* Config() defaults, defaults.py:61-84 */

@@ -71,6 +71,7 @@ SYMBOLS = {
     "mgx_version": (ctypes.c_int, []),
     "mgx_last_error": (ctypes.c_char_p, []),
     "mgx_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "mgx_device_pci_bus_id": (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int32]),
     "mgx_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_VP)]),
     "mgx_destroy": (ctypes.c_int, [_VP]),
     "mgx_config_default": (ctypes.c_int, [ctypes.POINTER(MgxConfig)]),

@@ -99,8 +99,10 @@ def _compile(out, extra_flags, verbose):
 
 
 if __name__ == "__main__":
-    if "--variant" in sys.argv:        # python -m matchering_amd.build --variant NAME FLAG...
+    if "--variant" in sys.argv:        # python -m matchering_amd.build --variant NAME FLAG...  -> tools/variants/libmgx_NAME.so
         i = sys.argv.index("--variant")
-        print(build(force=True, out=os.path.join(HERE, f"libmgx_{sys.argv[i + 1]}.so"), extra_flags=sys.argv[i + 2:]))
+        folder = os.path.join(os.path.dirname(HERE), "tools", "variants")      # experiments stay out of the product package
+        os.makedirs(folder, exist_ok=True)
+        print(build(force=True, out=os.path.join(folder, f"libmgx_{sys.argv[i + 1]}.so"), extra_flags=sys.argv[i + 2:]))
     else:
         print(build(force=True, verbose="-v" in sys.argv))

@@ -242,7 +242,7 @@ struct LimiterBlock {
             const float g0 = gain_of(scaled(v0, g), a.threshold), g1 = gain_of(scaled(v1, g), a.threshold);
             gp[gidx(i)] = g0;
             gp[gidx(i + 1)] = g1;
-            pm[j] = fmaxf(g0, g1);
+            pm[j] = pmax(g0, g1);
         }
     }
     static MGX_HD int block_of(int tid, int j) { return (tid >> 3) + (T / 8) * j; }
@@ -263,7 +263,7 @@ struct LimiterBlock {
             const float g1 = gain_of(scaled(make_float2(q.z, q.w), g), a.threshold);
             gp[gidx(i)] = g0;
             gp[gidx(i + 1)] = g1;
-            pm[j] = fmaxf(g0, g1);
+            pm[j] = pmax(g0, g1);
         }
     }
 
@@ -286,14 +286,14 @@ struct LimiterBlock {
         MGX_UNROLL
         for (int k = 0; k < 15; ++k) {
             const float v = pl[k < nl ? k : 0];
-            m = fmaxf(m, k < nl ? v : 0.f);
+            m = pmax(m, k < nl ? v : 0.f);
         }
-        for (int k = 0; k < nb; ++k) m = fmaxf(m, bm[(a2 >> 4) + k]);
+        for (int k = 0; k < nb; ++k) m = pmax(m, bm[(a2 >> 4) + k]);
         const float* pr = row + rel(a2 + 16 * nb);                // a block boundary: nr <= 15 frames of one row
         MGX_UNROLL
         for (int k = 0; k < 15; ++k) {
             const float v = pr[k < nr ? k : 0];
-            m = fmaxf(m, k < nr ? v : 0.f);
+            m = pmax(m, k < nr ? v : 0.f);
         }
         // (with nl == 0 and nr == 0 the two rows above are read at offset 0 only: rel(a), rel(a2) lie inside the region)
         return m;
@@ -321,15 +321,15 @@ struct LimiterBlock {
         out[15] = inner;
         MGX_UNROLL
         for (int j = 14; j >= 0; --j) {
-            s = fmaxf(s, r[j]);
-            out[j] = fmaxf(inner, s);
+            s = pmax(s, r[j]);
+            out[j] = pmax(inner, s);
         }
         run15(tid, hw + 1, lds, r);
         s = 0.f;
         MGX_UNROLL
         for (int j = 1; j < E; ++j) {
-            s = fmaxf(s, r[j - 1]);
-            out[j] = fmaxf(out[j], s);
+            s = pmax(s, r[j - 1]);
+            out[j] = pmax(out[j], s);
         }
     }
     // windows shorter than 15 frames (attack times of a few samples): the three parts above would
@@ -340,7 +340,7 @@ struct LimiterBlock {
         MGX_UNROLL
         for (int j = 0; j < E; ++j) {
             float m = 0.f;
-            for (int d = j - lw; d <= j + hw; ++d) m = fmaxf(m, row[rel(d)]);
+            for (int d = j - lw; d <= j + hw; ++d) m = pmax(m, row[rel(d)]);
             out[j] = m;
         }
     }
@@ -438,7 +438,7 @@ struct LimiterBlock {
         const float* bm = block_max(const_cast<float*>(lds)) + tid;
         const int back = (a.hw + a.hb + E - 1) / E, ahead = (a.hw + E - 1) / E;   // = gl, gw: inside the region
         float m = 0.f;
-        for (int d = -back; d <= ahead; ++d) m = fmaxf(m, bm[d]);
+        for (int d = -back; d <= ahead; ++d) m = pmax(m, bm[d]);
         return m;
     }
 
@@ -467,7 +467,7 @@ struct LimiterBlock {
                 const int lw = a.hw + a.hb;
                 if (short_window(lw, a.hw)) window_direct(tid, lw, a.hw, lds, th.sh);
                 else if (short_sl) window16(tid, lw, a.hw, range_max(tid, 15 - lw, a.hw, lds), lds, th.sh);
-                else window16(tid, lw, a.hw, fmaxf(th.inner, range_max(tid, 15 - lw, 14 - a.hw, lds)), lds, th.sh);
+                else window16(tid, lw, a.hw, pmax(th.inner, range_max(tid, 15 - lw, 14 - a.hw, lds)), lds, th.sh);
                 if (!FULL) {
                     MGX_UNROLL
                     for (int j = 0; j < E; ++j)

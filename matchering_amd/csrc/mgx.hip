@@ -211,6 +211,13 @@ struct mgx_handle {
     } last_call;
     bool avoid_tail = false;                // sticky after such a report: rounds 1..K-1 as one launch each
     bool requeued = false;                  // the last check_device_error queued the call again
+    // shadow launches (queue_master): a second stream on which a small instance of the NEXT big kernel runs on scratch
+    // while a latency-bound stretch holds the main stream, so that its code is in the instruction caches when it starts
+    hipStream_t side = nullptr;
+    hipEvent_t side_ev = nullptr;
+    DevBuf shadow_out, shadow_words, shadow_mid;
+    int masters_outstanding = 0;            // mgx_master calls queued since the last check of the error words
+    int downloads_outstanding = 0;          // device-to-host copies queued behind them
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
 };
@@ -219,6 +226,7 @@ static int ensure(mgx_handle* h, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return 0;
     if (b.p) {
         HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->side) HIP_TRY(hipStreamSynchronize(h->side));
         HIP_TRY(hipFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
@@ -881,6 +889,19 @@ static int launch_limiter_general(mgx_handle* h, const LimiterArgs& a, const Lim
 // 256-block chunks (four workgroups per CU) unless the configured attack / hold times need 1024
 // (a persistent grid that fetches a workgroup's next chunk under its current one was built and measured in round 4:
 // 187 against 171 us, profiles/r04_c_persistent_limiter.txt)
+// the 256-block kernel: the instantiation for the configuration's window geometry when there is one (k_limit in
+// mgx_kernels.h; MGX_LIMIT_GENERAL=1: measurement aid, always the general one)
+static void launch_limiter_256(const LimiterArgs& a, dim3 grid, hipStream_t stream) {
+    const size_t lds = LimiterBlock<256>::LDS_BYTES;
+    const char* general = std::getenv("MGX_LIMIT_GENERAL");
+    const bool fixed = !(general && general[0] == '1');
+    if (fixed && a.hw == 44 && a.hb == 43 && a.gr == 26 && a.gl == 6 && a.gw == 3)                 // 44.1 kHz, 1 ms / 1 ms
+        hipLaunchKernelGGL((k_limit<256, 4, 44, 43, 26>), grid, dim3(256), lds, stream, a);
+    else if (fixed && a.hw == 48 && a.hb == 47 && a.gr == 28 && a.gl == 6 && a.gw == 3)            // 48 kHz
+        hipLaunchKernelGGL((k_limit<256, 4, 48, 47, 28>), grid, dim3(256), lds, stream, a);
+    else
+        hipLaunchKernelGGL((k_limit<256, 4>), grid, dim3(256), lds, stream, a);
+}
 static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
     const dim3 grid((unsigned)a.nchunks);
     if (threads == 1024) {
@@ -888,7 +909,7 @@ static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
         MGX_TRY((allow_lds(k_limit<1024, 1>, lds)));
         hipLaunchKernelGGL((k_limit<1024, 1>), grid, dim3(1024), lds, h->stream, a);
     } else {
-        hipLaunchKernelGGL((k_limit<256, 4>), grid, dim3(256), LimiterBlock<256>::LDS_BYTES, h->stream, a);
+        launch_limiter_256(a, grid, h->stream);
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -962,11 +983,27 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
 //     call succeeds; mgx_last_error() carries a note.
 //   * anything else (a limiter look-back word that never came): MGX_ERR_HIP.
 static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c);
-static int check_device_error(mgx_handle* h) {
+// `may_requeue`: the caller has not yet handed anything of the failed run to the host (master_impl before its report
+// is read, mgx_synchronize / mgx_stage_times with no download queued behind the call, the blocking copy that re-issues
+// itself).  Everywhere else -- and whenever MORE than one mgx_master call is outstanding since the last
+// synchronisation, or a download of its outputs is already queued behind it (only the last call could be run again,
+// and a copy would have taken the failed run's frames) -- an expired tail fails like any other expired wait; the handle
+// still switches to one launch per round, so the caller's retry succeeds.
+static int check_device_error(mgx_handle* h, bool may_requeue = false) {
     h->requeued = false;
-    if (!h->error_host || *(volatile int*)h->error_host == 0) return 0;
-    const int what = *(volatile int*)h->error_host;
-    *(volatile int*)h->error_host = 0;
+    // (the caller has waited for the main stream; a shadow launch reads the caller's target and must be over too before
+    // the caller may free it -- it ended long ago, this costs a host call)
+    if (h->side) HIP_TRY(hipStreamSynchronize(h->side));
+    const int outstanding = h->masters_outstanding;
+    const int copies = h->downloads_outstanding;
+    h->masters_outstanding = 0;
+    h->downloads_outstanding = 0;
+    if (!h->error_host) return 0;
+    volatile int* e = (volatile int*)h->error_host;
+    const int what = (e[DEVICE_ERROR_SLOT_LOOKBACK] ? DEVICE_ERROR_LOOKBACK : 0) | (e[DEVICE_ERROR_SLOT_TAIL] ? DEVICE_ERROR_TAIL : 0) |
+                     (e[DEVICE_ERROR_SLOT_INPUT] ? DEVICE_ERROR_INPUT : 0);
+    if (what == 0) return 0;
+    for (int i = 0; i < DEVICE_ERROR_SLOTS; ++i) e[i] = 0;
     if (h->round_ctr.p) HIP_TRY(hipMemsetAsync(h->round_ctr.p, 0, h->round_ctr.bytes, h->stream));
     if (h->lim_ctrl.p) HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 64, h->stream));
     if (h->conv_queue.p) HIP_TRY(hipMemsetAsync(h->conv_queue.p, 0, 64, h->stream));
@@ -974,18 +1011,27 @@ static int check_device_error(mgx_handle* h) {
     if (what & DEVICE_ERROR_INPUT)
         return fail(MGX_ERR_ARGUMENT, "the target or the reference holds samples that are not finite numbers (NaN or infinity): "
                                       "the reference fails on such input too (match_frequencies.py:42)");
-    if (what == DEVICE_ERROR_TAIL && h->last_call.valid && !h->avoid_tail) {
-        h->avoid_tail = true;
-        const mgx_handle::MasterCall again = h->last_call;
-        MGX_TRY(queue_master(h, again));
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (*(volatile int*)h->error_host == 0) {
-            h->requeued = true;
-            g_error = "note: the level-correction tail kernel's workgroups were not resident together (the GPU is shared); "
-                      "the call was run again with one launch per correction round, and this handle keeps doing so";
-            return 0;
+    if (what == DEVICE_ERROR_TAIL && !h->avoid_tail) {
+        h->avoid_tail = true;                                    // whatever happens next, this handle stops using the tail
+        if (may_requeue && h->last_call.valid && outstanding == 1 && copies == 0) {
+            const mgx_handle::MasterCall again = h->last_call;
+            MGX_TRY(queue_master(h, again));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            h->masters_outstanding = 0;
+            bool clean = true;
+            for (int i = 0; i < DEVICE_ERROR_SLOTS; ++i) clean = clean && e[i] == 0;
+            if (clean) {
+                h->requeued = true;
+                g_error = "note: the level-correction tail kernel's workgroups were not resident together (the GPU is shared); "
+                          "the call was run again with one launch per correction round, and this handle keeps doing so";
+                return 0;
+            }
+            for (int i = 0; i < DEVICE_ERROR_SLOTS; ++i) e[i] = 0;
+        } else {
+            return fail(MGX_ERR_HIP, "the level-correction tail kernel's workgroups were not resident together (the GPU is shared) and "
+                                     "the results of the mgx_master calls since the last synchronisation are not valid; this handle now "
+                                     "runs one launch per correction round: call again");
         }
-        *(volatile int*)h->error_host = 0;
     }
     return fail(MGX_ERR_HIP, "a bounded device-side wait expired (limiter look-back or level-correction round): "
                              "the results of the calls since the last synchronisation are not valid");
@@ -1008,6 +1054,18 @@ int mgx_device_count(int* count) {
         return fail(MGX_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorName(e));
     }
     *count = n;
+    return 0;
+}
+
+int mgx_device_pci_bus_id(int device, char* out, int32_t capacity) {
+    if (!out || capacity < 16) return fail(MGX_ERR_ARGUMENT, "need room for 16 characters");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(MGX_ERR_NO_DEVICE, "no HIP device (this library has no CPU fallback)");
+    }
+    if (device < 0 || device >= n) return fail(MGX_ERR_ARGUMENT, "no such device");
+    HIP_TRY(hipDeviceGetPCIBusId(out, capacity, device));
     return 0;
 }
 
@@ -1073,6 +1131,13 @@ int mgx_destroy(mgx_handle* h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    if (h->side) {
+        hipStreamSynchronize(h->side);
+        hipStreamDestroy(h->side);
+        hipEventDestroy(h->side_ev);
+    }
+    for (DevBuf* b : {&h->shadow_out, &h->shadow_words, &h->shadow_mid})
+        if (b->p) hipFree(b->p);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
                       &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->lim_tables, &h->fir_robust, &h->peak_words, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info,
@@ -1107,7 +1172,9 @@ int mgx_free(mgx_handle* h, void* dev) {
     if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
     if (!dev) return 0;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->side) HIP_TRY(hipStreamSynchronize(h->side));
     HIP_TRY(hipFree(dev));
+    h->last_call.valid = false;             // (its pointers may be the block that has just gone: never queued again)
     return 0;
 }
 int mgx_memcpy_h2d(mgx_handle* h, void* dev, const void* host, size_t bytes) {
@@ -1120,7 +1187,12 @@ int mgx_memcpy_d2h(mgx_handle* h, void* host, const void* dev, size_t bytes) {
     if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
     HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return check_device_error(h);
+    MGX_TRY(check_device_error(h, true));
+    if (h->requeued) {                       // the copy above took the failed run's bytes: take them again
+        HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return 0;
 }
 // pinned host memory + copies that do not wait: the pieces of an overlapped host <-> HBM pipeline
 int mgx_host_alloc(size_t bytes, void** host) {
@@ -1141,12 +1213,13 @@ int mgx_memcpy_h2d_async(mgx_handle* h, void* dev, const void* host, size_t byte
 int mgx_memcpy_d2h_async(mgx_handle* h, void* host, const void* dev, size_t bytes) {
     if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
     HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, h->stream));
+    if (h->masters_outstanding > 0) ++h->downloads_outstanding;
     return 0;
 }
 int mgx_synchronize(mgx_handle* h) {
     if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return check_device_error(h);
+    return check_device_error(h, true);
 }
 int mgx_timer_start(mgx_handle* h) {
     if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
@@ -1393,6 +1466,99 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
                        int64_t n_reference, const mgx_config* cfg, const float* fir_given, float* result_dev,
                        float* result_no_limiter_dev, float* result_no_limiter_normalized_dev, mgx_report* report);
 // every launch of one stages.main, queued on the handle's stream (no host round trip)
+// ---- shadow launches ------------------------------------------------------------------------------------------
+// A kernel's first pass over its code is paid once per instruction cache (two compute units share one), in full, by
+// every launch: the hundreds of megabytes the kernel before it streamed have pushed the code out of the L2s, and the
+// other kernels of a step out of the instruction caches.  The caches keep their contents from one dispatch to the
+// next, and kernels of two streams run side by side (tools/micro/icache_persist.hip, profiles/r05_a_icache_persist.txt).
+// So while a latency-bound stretch holds the main stream with a few workgroups -- the FIR design (four small kernels),
+// the level-correction tail (<= 129 workgroups) -- a SMALL INSTANCE OF THE NEXT BIG KERNEL runs on a second stream:
+// the same kernel, on a cut of the real input, writing to scratch, with control words of its own.  It waits for
+// nobody and nobody waits for it; all it leaves behind is its code in the instruction caches.
+//   MGX_SHADOW: bit 0 = the limiter under the level-correction tail, bit 1 = the convolution under the FIR design,
+//   bit 2 = the limiter already under round 0 of the level correction (instead of bit 0); unset = SHADOW_DEFAULT.
+constexpr int SHADOW_LIMIT_UNDER_TAIL = 1, SHADOW_CONV_UNDER_DESIGN = 2, SHADOW_LIMIT_UNDER_ROUND0 = 4;
+constexpr int SHADOW_DEFAULT = 0;
+static int shadow_mode() {
+    const char* e = std::getenv("MGX_SHADOW");
+    return e && e[0] ? std::atoi(e) : SHADOW_DEFAULT;
+}
+static int shadow_blocks() {                       // workgroups of a shadow launch (default: one per compute unit)
+    const char* e = std::getenv("MGX_SHADOW_BLOCKS");
+    return e && e[0] ? std::max(1, std::atoi(e)) : 256;
+}
+static int side_stream(mgx_handle* h) {
+    if (h->side) return 0;
+    HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->side_ev, hipEventDisableTiming));
+    return 0;
+}
+// the side stream starts where the main stream stands now
+static int side_fork(mgx_handle* h) {
+    MGX_TRY(side_stream(h));
+    HIP_TRY(hipEventRecord(h->side_ev, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->side, h->side_ev, 0));
+    return 0;
+}
+// k_conv_wide<14> on the first `blocks` blocks of the target, into scratch; the filter spectra are whatever the last
+// call left (the values do not matter).  Nothing if this handle has not convolved yet.
+static int shadow_conv_wide(mgx_handle* h, const float* x, long long n) {
+    constexpr int WIDE = 14;
+    using F = Fft2<WIDE>;
+    const long long hop = ConvWide<WIDE>::HOP;
+    const int blocks = shadow_blocks();
+    if (!h->filt.p || h->filt.bytes < 2 * ((size_t)1 << WIDE) * sizeof(float2) || n < hop * blocks) return 0;
+    const size_t lds = conv_lds_bytes<WIDE>();
+    MGX_TRY((allow_lds(k_conv_wide<WIDE>, lds)));
+    MGX_TRY(ensure(h, h->shadow_out, (size_t)blocks * hop * sizeof(float2)));
+    MGX_TRY(ensure(h, h->shadow_mid, (size_t)blocks * hop * sizeof(float) + (size_t)blocks * sizeof(float)));
+    Conv2Args a;
+    a.x = reinterpret_cast<const float2*>(x);
+    a.n = hop * blocks;
+    a.y = (float2*)h->shadow_out.p;
+    a.ymid = (float*)h->shadow_mid.p;
+    a.run = 0;
+    MGX_TRY(get_twiddles(h, WIDE, &a.tw));
+    a.parts = 1;
+    a.h_mid = (const float2*)h->filt.p;
+    a.h_side = (const float2*)h->filt.p + F::N;
+    a.npairs = blocks;
+    a.pair_peak = (float*)h->shadow_mid.p + (size_t)blocks * hop;
+    a.queue = nullptr;
+    MGX_TRY(side_fork(h));
+    hipLaunchKernelGGL((k_conv_wide<WIDE>), dim3(blocks), dim3(F::T), lds, h->side, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+// k_limit<256,4> on chunks 1 .. `blocks` of y (all inside the track), into scratch, with look-back words that read
+// "published: 0" from the start (nobody waits), a ticket and an error word of its own
+static int shadow_limiter(mgx_handle* h, LimiterArgs a, int threads, const LimiterParams& lp) {
+    const int blocks = shadow_blocks();
+    if (threads != 256 || lp.general != 0 || a.nchunks < blocks + 3) return 0;
+    const long long chunk = lp.geo.chunk;
+    a.n = (long long)(blocks + 3) * chunk;               // chunks 1 .. blocks lie strictly inside this cut
+    a.nchunks = blocks + 3;
+    const size_t words = (size_t)3 * a.nchunks + 16;
+    const bool fresh = h->shadow_words.bytes < words * sizeof(unsigned long long);
+    MGX_TRY(ensure(h, h->shadow_words, words * sizeof(unsigned long long)));
+    MGX_TRY(ensure(h, h->shadow_out, (size_t)a.n * sizeof(float2)));
+    MGX_TRY(side_fork(h));
+    if (fresh) HIP_TRY(hipMemsetAsync(h->shadow_words.p, 0, h->shadow_words.bytes, h->side));   // +0.0 = published
+    a.out = (float2*)h->shadow_out.p;
+    a.published = (unsigned long long*)h->shadow_words.p;
+    a.ticket = (int*)((unsigned long long*)h->shadow_words.p + (size_t)3 * a.nchunks);
+    a.error = a.ticket + 4;
+    a.active = nullptr;
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.ticket, 1, 1, h->side));      // the first ticket drawn is chunk 1
+    launch_limiter_256(a, dim3(blocks), h->side);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int dev_repeat(const char* name) {
+    const char* e = std::getenv(name);
+    return e ? std::max(1, std::atoi(e)) : 1;
+}
 static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
     const float* target_dev = c.target;
     const float* reference_dev = c.reference;
@@ -1421,6 +1587,8 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
     }
     // stage 2 (stages.py:107-135): FIR design on the device, then the overlap-save convolution with
     // the level gain of stages.py:80-88 (a device scalar) folded into the filter spectra
+    const int shadow = shadow_mode();
+    if ((shadow & SHADOW_CONV_UNDER_DESIGN) && f == 4096) MGX_TRY(shadow_conv_wide(h, target_dev, n_target));
     {
         StageScope scope(h, MGX_STAGE_DESIGN_FIR);
         MGX_TRY(run_fir_design(h, cfg, tw, rw, fir_given));
@@ -1428,8 +1596,11 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
     MGX_TRY(ensure(h, h->y, (size_t)n_target * sizeof(float2)));
     MGX_TRY(ensure(h, h->mid, (size_t)n_target * sizeof(float)));
     long long nblocks = 0;
-    MGX_TRY(run_conv(h, target_dev, n_target, f, (const float*)h->taps.p, 1.0, (float*)h->y.p, (float*)h->mid.p,
-                     &nblocks, (const double*)h->scalars.p));
+    // (MGX_DEV_REPEAT_CONV / MGX_DEV_REPEAT_LIMIT = n: measurement aid, the stage's launches n times in a row -- the
+    // difference between n = 2 and n = 1 is the stage with its code already in the instruction caches)
+    for (int rep = dev_repeat("MGX_DEV_REPEAT_CONV"); rep > 0; --rep)
+        MGX_TRY(run_conv(h, target_dev, n_target, f, (const float*)h->taps.p, 1.0, (float*)h->y.p, (float*)h->mid.p,
+                         &nblocks, (const double*)h->scalars.p));
     // stage 3 (stages.py:138-170): scalar feedback stays on the device; one launch per round, the last
     // round also derives the peak / early-out / normalisation scalars (the state was reset by k_fir_raw)
     CorrectionState* cs = (CorrectionState*)h->cstate.p;
@@ -1488,6 +1659,16 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
             r.final_peaks = (const float*)h->block_peak.p;
             return 0;
         };
+        LimiterArgs shadow_args;
+        LimiterParams shadow_lp;
+        int shadow_threads = 0;
+        const bool shadow_limit = result_dev && (shadow & (SHADOW_LIMIT_UNDER_TAIL | SHADOW_LIMIT_UNDER_ROUND0)) && rounds > 1 && use_tail;
+        if (shadow_limit) {
+            const double* post = &((const TrackStats*)rw.stats.p)->amplitude_c;
+            MGX_TRY(limiter_args(h, (const float*)h->y.p, n_target, cfg, &cs->gain, post, nullptr, result_dev, shadow_args,
+                                 &shadow_threads, shadow_lp));
+            if (shadow & SHADOW_LIMIT_UNDER_ROUND0) MGX_TRY(shadow_limiter(h, shadow_args, shadow_threads, shadow_lp));
+        }
         if (rounds >= 1) {                                    // round 0 streams the mid plane and builds the band lists
             RoundArgs r0 = ra;
             r0.final_peaks = nullptr;
@@ -1500,6 +1681,8 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
             if (rounds == 1) MGX_TRY(with_final(r0));
             hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, r0);
         }
+        if (shadow_limit && !(shadow & SHADOW_LIMIT_UNDER_ROUND0))
+            MGX_TRY(shadow_limiter(h, shadow_args, shadow_threads, shadow_lp));
         if (rounds > 1 && !use_tail) {
             // one launch per round, the last arriver of each decides (k_correction_round without a tail): what a handle
             // falls back to after its tail kernel found the GPU shared (check_device_error), and MGX_NO_TAIL=1
@@ -1545,6 +1728,8 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
         const double* post = &((const TrackStats*)rw.stats.p)->amplitude_c;
         MGX_TRY(run_limiter(h, (const float*)h->y.p, n_target, cfg, &cs->gain, post, &cs->limiter_active, result_dev,
                             limiter_preset));
+        for (int rep = dev_repeat("MGX_DEV_REPEAT_LIMIT"); rep > 1; --rep)
+            MGX_TRY(run_limiter(h, (const float*)h->y.p, n_target, cfg, &cs->gain, post, &cs->limiter_active, result_dev, false));
     }
     return 0;
 }
@@ -1573,6 +1758,7 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
     call.out[2] = result_no_limiter_normalized_dev;
     MGX_TRY(queue_master(h, call));
     call.valid = true;
+    ++h->masters_outstanding;
     TrackWork& tw = h->track[0];
     TrackWork& rw = h->track[1];
     CorrectionState* cs = (CorrectionState*)h->cstate.p;
@@ -1589,7 +1775,7 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
             HIP_TRY(hipMemcpyAsync(hc, cs, sizeof(CorrectionState), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipMemcpyAsync(c0, h->scalars.p, sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));
-            MGX_TRY(check_device_error(h));
+            MGX_TRY(check_device_error(h, true));                 // (nothing of the run has been handed out yet)
             if (!h->requeued) break;
         }
         std::memset(report, 0, sizeof(*report));

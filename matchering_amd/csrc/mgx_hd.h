@@ -253,6 +253,18 @@ MGX_HD float fast_rcp(float x) {
 #endif
 }
 
+// maximum of two NON-NEGATIVE floats (no NaN, no -0): their order is the order of their bit patterns, so one integer
+// maximum does it.  fmaxf on a value that comes from memory costs a second instruction on this target (the compiler
+// quiets a possible signalling NaN first: v_max_f32 v, v, v), and the limiter's window maxima are nothing but that.
+MGX_HD float pmax(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MGX_HOST_EMU)
+    const int x = __float_as_int(a), y = __float_as_int(b);
+    return __int_as_float(x > y ? x : y);
+#else
+    return a > b ? a : b;
+#endif
+}
+
 constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 constexpr int bitrev(int v, int bits) {
     int r = 0;

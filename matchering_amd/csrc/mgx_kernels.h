@@ -105,12 +105,16 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 #include "small_fft_kernels.h"     // fft_size 8 .. 32 (needs the block reductions above)
 namespace mgx {
 
-// Values of the handle's error word.  A limiter look-back that expires (limiter_kernel.h) means a lost word: the
+// The handle's error words: ONE int per kind of failure (error[0] look-back, error[1] tail, error[2] input), each set by
+// a plain store of 1 -- kernels of different kinds never write the same word, so a later tail expiry cannot erase an
+// earlier lost look-back word; the host folds them into the DEVICE_ERROR_* bits below.
+// A limiter look-back that expires (limiter_kernel.h) means a lost word: the
 // audio is wrong and the call fails.  An expired wait of k_correction_tail means its workgroups were not resident
 // together (another process's kernels held the compute units): the host then runs the rounds again as one launch
 // each, which wait for nobody (mgx.hip, check_device_error).  DEVICE_ERROR_INPUT is not a wait at all: the level
 // analysis met a NaN or an infinity (k_match_curve), where the reference raises.
 constexpr int DEVICE_ERROR_LOOKBACK = 1, DEVICE_ERROR_TAIL = 2, DEVICE_ERROR_INPUT = 4;
+constexpr int DEVICE_ERROR_SLOT_LOOKBACK = 0, DEVICE_ERROR_SLOT_TAIL = 1, DEVICE_ERROR_SLOT_INPUT = 2, DEVICE_ERROR_SLOTS = 3;
 #ifdef MGX_TEST_TAIL_EXPIRE
 __device__ int g_test_tail_launches;
 #endif
@@ -1091,14 +1095,53 @@ __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack 
     float* pk = reinterpret_cast<float*>(loud + 2 * max_div);   // [rows]
     const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int w = threadIdx.x; w < rows; w += 1024) {
+    // The spectra of the first 512 workgroup rows of EACH track are asked for before anything else: what is summed
+    // depends on the level decisions below, what is loaded does not, so the decisions (two LDS round trips and a
+    // wave's worth of arithmetic) run while the loads are in flight.  Buffer views: ONE lane offset per track, the row
+    // step is a scalar displacement, and rows past the end of a track read as zero through the range check.
+    const int b = threadIdx.x & 31, row_lane = threadIdx.x >> 5, plane = blockIdx.y;
+    const int bin = blockIdx.x * 32 + b;
+    const MemView vt = mem_view(tt.wg_spec, (long long)tt.nwg * 2 * bins * 4);
+    const MemView vr = mem_view(tr.wg_spec, (long long)tr.nwg * 2 * bins * 4);
+    // (a bin past the end reads from past the end of the view: zeros)
+    const unsigned lane_off = bin < bins ? (unsigned)((((size_t)row_lane * 2 + plane) * bins + bin) * 4) : 0xfffffff0u;
+    const unsigned row_step = (unsigned)((size_t)32 * 2 * bins * 4);
+    double ssv[2] = {0.0, 0.0};
+    float pkv[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                                // (rows <= 2048: host_params / run_fir_design)
+        const int w = threadIdx.x + 1024 * u;
+        if (w < rows) {
+            const bool second = w >= tt.nwg;
+            const LevelsArgs& t = second ? tr.lv : tt.lv;
+            const int i = second ? w - tt.nwg : w;
+            ssv[u] = t.wg_sumsq[i];
+            pkv[u] = t.wg_peak[i];
+        }
+    }
+    float v0[2][16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const unsigned disp = (unsigned)u * row_step;
+        v0[0][u] = ld_f1(vt, lane_off, disp);
+        v0[1][u] = ld_f1(vr, lane_off, disp);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int w = threadIdx.x + 1024 * u;
+        if (w < rows) {
+            ss[w] = ssv[u];
+            pk[w] = pkv[u];
+        }
+    }
+    for (int w = threadIdx.x + 2048; w < rows; w += 1024) {       // (more rows than that: the plain way)
         const bool second = w >= tt.nwg;
         const LevelsArgs& t = second ? tr.lv : tt.lv;
         const int i = second ? w - tt.nwg : w;
         ss[w] = t.wg_sumsq[i];
         pk[w] = t.wg_peak[i];
     }
-    __syncthreads();
+    lds_barrier();
     for (int p = threadIdx.x; p < tt.lv.divisions + tr.lv.divisions; p += 1024) {
         const bool second = p >= tt.lv.divisions;
         const LevelsArgs& t = second ? tr.lv : tt.lv;
@@ -1108,7 +1151,7 @@ __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack 
         for (int ch = 0; ch < t.chunks_per_piece; ++ch) sum += src[ch];
         sums[(second ? max_div : 0) + d] = sum;
     }
-    __syncthreads();
+    lds_barrier();
     if (wave < 2) {                                             // wave 0: target, wave 1: reference
         const int k = wave;
         const LevelsArgs& t = k == 0 ? tt.lv : tr.lv;
@@ -1142,35 +1185,32 @@ __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack 
                 // A NaN or an infinity among the samples: no piece is "loud" (every comparison with NaN fails) or
                 // the loud pieces' RMS is not a number.  The reference stops there (match_frequencies.py:42 is
                 // handed an empty selection); here the handle's error word makes the next blocking call fail.
-                if (error && (count == 0 || !(fabs(match) < 1.0e300))) *error = DEVICE_ERROR_INPUT;
+                if (error && (count == 0 || !(fabs(match) < 1.0e300))) error[DEVICE_ERROR_SLOT_INPUT] = 1;
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     const double c0 = scal[4 + 1] / fmax(eps, scal[1]);         // match_levels.py:106-111
     if (writer && threadIdx.x == 0) {
         *c0_out = c0;
         if (cs_init) correction_reset(cs_init, 1.0);            // stages.py:138-170 starts from gain 1
     }
-    const int b = threadIdx.x & 31, row_lane = threadIdx.x >> 5, plane = blockIdx.y;
-    const int bin = blockIdx.x * 32 + b;
-    // sixteen rows of EACH track in flight per thread: one round trip for a pair of 8-minute tracks
+    // sixteen rows of EACH track per thread and batch: one round trip for a pair of 8-minute tracks
     double sacc[2] = {0.0, 0.0};
-    if (bin < bins) {
-        // buffer views: ONE lane offset per track, the row step is a scalar displacement, and rows past
-        // the end of a track read as zero through the range check
-        const MemView vt = mem_view(tt.wg_spec, (long long)tt.nwg * 2 * bins * 4);
-        const MemView vr = mem_view(tr.wg_spec, (long long)tr.nwg * 2 * bins * 4);
-        const unsigned lane_off = (unsigned)((((size_t)row_lane * 2 + plane) * bins + bin) * 4);
-        const unsigned row_step = (unsigned)((size_t)32 * 2 * bins * 4);
+    {
         const int longest = max(tt.nwg, tr.nwg);
+        // workgroup row -> piece without a division per row: floor(w * ceil(2^32 / d) / 2^32) = w / d for w, d < 2^16
+        const unsigned magic[2] = {(unsigned)((0x100000000ull + tt.lv.chunks_per_piece - 1) / tt.lv.chunks_per_piece),
+                                   (unsigned)((0x100000000ull + tr.lv.chunks_per_piece - 1) / tr.lv.chunks_per_piece)};
+#pragma unroll 1
         for (int w0 = 0; w0 < longest; w0 += 32 * 16) {
-            float v[2][16];
+            if (opaque(w0) > 0) {                               // (the first batch is in flight since the top; opaque: one copy of the sums)
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const unsigned disp = (unsigned)(w0 / 32 + u) * row_step;
-                v[0][u] = ld_f1(vt, lane_off, disp);
-                v[1][u] = ld_f1(vr, lane_off, disp);
+                for (int u = 0; u < 16; ++u) {
+                    const unsigned disp = (unsigned)(w0 / 32 + u) * row_step;
+                    v0[0][u] = ld_f1(vt, lane_off, disp);
+                    v0[1][u] = ld_f1(vr, lane_off, disp);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -1178,8 +1218,9 @@ __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack 
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
                     const int w = w0 + row_lane + 32 * u;
-                    const bool on = w < t.nwg && loud[k * max_div + (w < t.nwg ? w : 0) / t.lv.chunks_per_piece] != 0;
-                    sacc[k] += on ? (double)v[k][u] : 0.0;
+                    const int piece = t.lv.chunks_per_piece == 1 ? w : (int)__umulhi((unsigned)w, magic[k]);
+                    const bool on = w < t.nwg && loud[k * max_div + (w < t.nwg ? piece : 0)] != 0;
+                    sacc[k] += on ? (double)v0[k][u] : 0.0;
                 }
             }
         }
@@ -1901,7 +1942,7 @@ __device__ __forceinline__ unsigned long long poll_word(const unsigned long long
         ++spins;
     }
     if (v == ~0ull) {
-        *error = DEVICE_ERROR_TAIL;
+        error[DEVICE_ERROR_SLOT_TAIL] = 1;
         v = on_expiry;
     }
     return v;
@@ -2317,10 +2358,11 @@ __device__ __forceinline__ Affine compose_waves(const Affine* totals, Affine exc
 
 // maximum over the eight lanes that share lane >> 3 (non-negative values): three DPP steps
 __device__ __forceinline__ float dpp_max8(float v) {
+    // (integer maxima of the bit patterns: the values are non-negative, pmax in mgx_hd.h)
     int x = __float_as_int(v);
-    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true))));   // quad_perm [1,0,3,2]
-    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true))));   // quad_perm [2,3,0,1]
-    x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true))));  // row_half_mirror
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));   // row_half_mirror
     return __int_as_float(x);
 }
 
@@ -2732,10 +2774,23 @@ __global__ __launch_bounds__(256, 2) void k_limit_general(LimiterArgs a, General
 
 // T = threads = 16-frame blocks per chunk (256, or 1024 for long attack / hold times); WGS = workgroups
 // per CU the kernel is compiled for (register budget 512 / (WGS * T / 256) per lane)
-template <int T, int WGS>
-__global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a) {
+// HW / HB / GR >= 0: an instantiation for ONE window geometry (attack half window, hold look-back, right halo blocks;
+// gl and gw follow from them): the bounds of every window loop are literals, the masked ragged-edge reads of the
+// general form fold away and the code is a third shorter.  The host launches it when the configuration's numbers are
+// exactly these (44.1 and 48 kHz with the reference's default 1 ms attack and hold, defaults.py:25-58), the general
+// instantiation (-1) otherwise; the results are the same to the bit.
+template <int T, int WGS, int HW = -1, int HB = -1, int GR = -1>
+__global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a0) {
     warm_code(CODE_LIMIT, T == 256 ? 0 : 1);
     using LB = LimiterBlock<T>;
+    LimiterArgs a = a0;
+    if (HW >= 0) {
+        a.hw = HW;
+        a.hb = HB;
+        a.gl = (HW + HB + LB::E - 1) / LB::E;
+        a.gw = (HW + LB::E - 1) / LB::E;
+        a.gr = GR;
+    }
     MGX_LDS;
     float* lds = reinterpret_cast<float*>(mgx_smem);
     int& ticket = *reinterpret_cast<int*>(LB::scalars(lds) + 4);      // dynamic LDS only (16-byte aligned base)

@@ -415,3 +415,10 @@ def device_count():
     n = ctypes.c_int()
     rc = library().mgx_device_count(ctypes.byref(n))
     return n.value if rc == 0 else 0
+
+
+def pci_bus_id(index=0):
+    """PCI address of GPU ``index`` ("0000:0d:00.0"): which physical device a rank or lane sits on."""
+    buf = ctypes.create_string_buffer(32)
+    check(library().mgx_device_pci_bus_id(int(index), buf, 32))
+    return buf.value.decode("ascii", "replace")

@@ -10,13 +10,24 @@ The socket is an abstract-namespace Unix socket named after MASTER_ADDR:MASTER_P
 store (``torch.distributed.run`` keeps a TCP store on that very port) is left alone, nothing is left behind in
 the file system, and two jobs with different ports do not meet.  ``MGX_RENDEZVOUS=tcp://host:port`` selects a
 TCP socket instead (ranks on several nodes).  Every wait is bounded (``timeout`` seconds).
+
+Messages are JSON (None, numbers, strings, lists, dicts; ``bytes`` as base64 under a reserved key), length-prefixed
+and bounded -- never pickle: the abstract socket has no file permissions and the TCP form listens on the network, so
+whatever connects must not be able to make a rank execute anything.  A rank introduces itself with its number and
+``MGX_RENDEZVOUS_TOKEN`` (when the job sets one, rank 0 turns away connections that do not know it); numbers outside
+1 .. world-1 and duplicates are refused.
 """
 
+import base64
+import hmac
+import json
 import os
-import pickle
 import socket
 import struct
 import time
+
+MAX_MESSAGE = 64 << 20          # bytes; the largest real payload is a gathered list of small dicts
+_BYTES_KEY = "__mgx_bytes__"
 
 
 def rank_environment():
@@ -38,8 +49,34 @@ def _address():
     return socket.AF_UNIX, "\0mgx-ranks-" + key
 
 
+def _encode(obj):
+    if isinstance(obj, (bytes, bytearray, memoryview)):
+        return {_BYTES_KEY: base64.b64encode(bytes(obj)).decode("ascii")}
+    if isinstance(obj, (list, tuple)):
+        return [_encode(v) for v in obj]
+    if isinstance(obj, dict):
+        return {str(k): _encode(v) for k, v in obj.items()}
+    if obj is None or isinstance(obj, (bool, int, float, str)):
+        return obj
+    if hasattr(obj, "item"):                  # numpy scalars
+        return obj.item()
+    raise TypeError(f"ranks exchange None, numbers, strings, bytes, lists and dicts, not {type(obj).__name__}")
+
+
+def _decode(obj):
+    if isinstance(obj, dict):
+        if set(obj) == {_BYTES_KEY}:
+            return base64.b64decode(obj[_BYTES_KEY])
+        return {k: _decode(v) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [_decode(v) for v in obj]
+    return obj
+
+
 def _send(sock, obj):
-    blob = pickle.dumps(obj, protocol=4)
+    blob = json.dumps(_encode(obj), allow_nan=True).encode("utf-8")
+    if len(blob) > MAX_MESSAGE:
+        raise ValueError(f"message of {len(blob)} bytes exceeds the {MAX_MESSAGE}-byte bound of the rendezvous")
     sock.sendall(struct.pack("<Q", len(blob)) + blob)
 
 
@@ -55,7 +92,13 @@ def _recv(sock):
         return b"".join(parts)
 
     (size,) = struct.unpack("<Q", exactly(8))
-    return pickle.loads(exactly(size))
+    if size > MAX_MESSAGE:
+        raise ConnectionError(f"a peer announced a message of {size} bytes (bound: {MAX_MESSAGE})")
+    return _decode(json.loads(exactly(size).decode("utf-8")))
+
+
+def _token():
+    return os.environ.get("MGX_RENDEZVOUS_TOKEN", "")
 
 
 class Ranks:
@@ -91,8 +134,17 @@ class Ranks:
                     missing = sorted(set(range(1, self.world)) - set(self.peers))
                     raise TimeoutError(f"ranks {missing} did not arrive within {self.timeout:.0f} s") from None
                 conn.settimeout(self.timeout)
-                who = _recv(conn)
-                self.peers[int(who)] = conn
+                try:                                   # whoever connects says who it is; anything else is turned away
+                    hello = _recv(conn)
+                    who = hello.get("rank") if isinstance(hello, dict) else None
+                    known = isinstance(hello, dict) and hmac.compare_digest(str(hello.get("token", "")), _token())
+                    if not (known and isinstance(who, int) and not isinstance(who, bool)
+                            and 1 <= who < self.world and who not in self.peers):
+                        raise ValueError(f"unexpected introduction {hello!r}"[:120])
+                except (ValueError, ConnectionError, UnicodeDecodeError, socket.timeout):
+                    conn.close()
+                    continue
+                self.peers[who] = conn
             for conn in self.peers.values():
                 _send(conn, "met")
         else:
@@ -107,7 +159,7 @@ class Ranks:
                         raise TimeoutError(f"rank 0 did not open the rendezvous within {self.timeout:.0f} s") from None
                     time.sleep(0.02)
             sock.settimeout(self.timeout)
-            _send(sock, self.rank)
+            _send(sock, {"rank": self.rank, "token": _token()})
             self.root = sock
             _recv(sock)
 

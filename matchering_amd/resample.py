@@ -112,9 +112,13 @@ def resample(array, sample_rate, required, block=8192, max_phases=4096):
     by L, filter with the prototype of _prototype(), keep every M-th sample -- which scipy's ``upfirdn`` evaluates
     without the zeros; samples outside the array count as zeros in both forms (resampy cuts its wings short there).  The phase arithmetic is exact (integers), where resampy's own t * (1 / ratio) carries a
     rounding of ~1e-16 t that moves a weight by ~1e-9 at the end of an hour of audio.  Ratios with more than `max_phases`
-    phases, and rates that are not integers, go through the literal per-sample form."""
+    phases, and rates that are not integers, go through the literal per-sample form.  The sums run in float64; the
+    result comes back in the input's floating type, as resampy's does (float32 in, float32 out: the same array on a
+    machine with resampy and on one without; integers come back as float64)."""
     from scipy.signal import upfirdn
 
+    given = np.asarray(array).dtype
+    out_dtype = given if given.kind == "f" else np.dtype(np.float64)
     x = np.ascontiguousarray(array, dtype=np.float64)
     flat = x.reshape(x.shape[0], -1)
     plan = _Plan(sample_rate, required)
@@ -127,10 +131,10 @@ def resample(array, sample_rate, required, block=8192, max_phases=4096):
     if not whole or phases > max_phases or n_out == 0:
         for t0 in range(0, n_out, block):
             _literal(plan, flat, np.arange(t0, min(n_out, t0 + block)), y)
-        return y.reshape((n_out,) + x.shape[1:])
+        return y.reshape((n_out,) + x.shape[1:]).astype(out_dtype, copy=False)
     proto, centre = _prototype(plan, phases, hop)
     full = upfirdn(proto, flat, up=phases, down=hop, axis=0)
     first = centre // hop
     got = full[first:first + n_out]
     y[:got.shape[0]] = got
-    return y.reshape((n_out,) + x.shape[1:])
+    return y.reshape((n_out,) + x.shape[1:]).astype(out_dtype, copy=False)

@@ -24,7 +24,7 @@ def _bench(*flags, env=None, timeout=120):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_self_launched_ranks_print_one_line(world):
     line = _bench("--gpus", str(world))
     assert line["n_gpus"] == world and line["launch"] == "self" and line["scaling"] == "weak"
@@ -35,11 +35,21 @@ def test_self_launched_ranks_print_one_line(world):
     per_rank = line["config"]["frames_per_gpu_per_step"]
     assert line["value"] == pytest.approx(world * per_rank * 5 / (line["ms_per_step"] * 5e-3) / 1e6, rel=1e-3)
     assert line["ms_per_step"] * 5e-3 >= max(line["rank_seconds"]) - 1e-3
+    # which device every rank sat on (PCI address on a GPU box; a stand-in name here), and what the roofline is taken against
+    assert len(line["rank_gpus"]) == world and len(set(line["rank_gpus"])) == line["physical_gpus"] == world
+    assert line["shared_gpu"] is False
+    assert line["pipeline_hbm_model"]["measured_bytes"] is None          # (no profiler without a GPU)
+    # the N = 1 point of the SAME workload, taken by rank 0 alone after the timed region
+    n1 = line["n1_same_workload"]
+    assert n1["workload"] == "stand_in" and n1["unit"] == "Msamples/s"
+    assert n1["value"] == pytest.approx(per_rank / (n1["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    assert 0.5 < line["value"] / (world * n1["value"]) < 1.5              # a curve of one workload: efficiency near 1
 
 
 def test_single_rank_needs_no_rendezvous():
     line = _bench("--gpus", "1")
     assert line["n_gpus"] == 1 and line["launch"] == "single" and "rendezvous" not in line
+    assert line["rank_gpus"] == ["stand-in-0"] and line["physical_gpus"] == 1 and "n1_same_workload" not in line
 
 
 def test_a_launcher_started_rank_does_not_launch_again():

@@ -15,7 +15,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VARIANT = os.path.join(ROOT, "matchering_amd", "libmgx_loseword.so")
+BUILD_DIR = os.path.join(ROOT, "tests", "_build")          # test builds of the library live under tests/, not in the product package
+VARIANT = os.path.join(BUILD_DIR, "libmgx_loseword.so")
 FLAGS = ("-DMGX_TEST_LOSE_WORD", "-DMGX_TEST_LIMITER_MAX_SPINS=64")
 
 CHILD = r"""
@@ -52,6 +53,7 @@ def build_variant():
     sys.path.insert(0, ROOT)
     from matchering_amd import build as native_build
 
+    os.makedirs(BUILD_DIR, exist_ok=True)
     return native_build.build(out=VARIANT, extra_flags=FLAGS)
 
 
@@ -84,7 +86,7 @@ def test_an_expired_lookback_fails_the_next_synchronize_without_a_report():
 # queued again with one launch per round (no workgroup waits for another) and SUCCEEDS, and the handle stays in
 # that mode.  Forced with a second test build: -DMGX_TEST_TAIL_EXPIRE (the first tail of the process never hears
 # of round 0's gain) -DMGX_TEST_TAIL_MAX_SPINS=64 (its workgroups give up after 64 polls).
-TAIL_VARIANT = os.path.join(ROOT, "matchering_amd", "libmgx_tailexpire.so")
+TAIL_VARIANT = os.path.join(BUILD_DIR, "libmgx_tailexpire.so")
 TAIL_FLAGS = ("-DMGX_TEST_TAIL_EXPIRE", "-DMGX_TEST_TAIL_MAX_SPINS=64")
 
 TAIL_CHILD = r"""
@@ -115,6 +117,79 @@ for attempt, with_report in enumerate((False, True, False)):
 """
 
 
+def build_tail_variant():
+    sys.path.insert(0, ROOT)
+    from matchering_amd import build as native_build
+
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    return native_build.build(out=TAIL_VARIANT, extra_flags=TAIL_FLAGS)
+
+
+# What the host may already hold when the expiry is noticed.  MODE download: no synchronize between
+# the call and the blocking copy -- the copy took the failed run's frames, so it is taken AGAIN after the re-run.
+# MODE two_calls: two mgx_master calls queued before one synchronize -- only the last could be run again, so the
+# synchronize FAILS (and the handle, now without the tail, succeeds on the retry).  MODE async_copy: a non-blocking
+# download queued behind the call -- it has copied the failed run, so the synchronize fails as well.
+TAIL_CHILD_MODES = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {root!r} + "/oracle")
+import ctypes
+import numpy as np
+import mastering_oracle as mo
+import matchering_amd as mg
+from matchering_amd._native import MgxError, check, library
+from matchering_amd.device import Device
+from matchering_amd.synth import make_pair
+
+mode = os.environ["MGX_TEST_MODE"]
+target, reference = make_pair(20.0, 44100, pair=3)
+want = mo.master(target, reference, mo.params(), True, False, False)[0]
+dev = Device(0)
+native = mg.Config().to_native()
+n = target.shape[0]
+t, r = dev.upload(target), dev.upload(reference)
+out = dev.alloc(n * 8)
+def rms(got):
+    return float(np.sqrt(np.mean((got.astype(np.float64) - want) ** 2)))
+if mode == "download":
+    dev.master(t, n, r, reference.shape[0], native, result=out, want_report=False)
+    got = np.empty((n, 2), np.float32)
+    check(library().mgx_memcpy_d2h(dev.handle, got.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(out.ptr), got.nbytes))
+    print("download rms_ok", rms(got) <= 1e-5, "note", "not resident together" in library().mgx_last_error().decode())
+else:
+    host = ctypes.c_void_p()
+    check(library().mgx_host_alloc(n * 8, ctypes.byref(host)))
+    dev.master(t, n, r, reference.shape[0], native, result=out, want_report=False)
+    if mode == "two_calls":
+        dev.master(t, n, r, reference.shape[0], native, result=out, want_report=False)
+    else:
+        check(library().mgx_memcpy_d2h_async(dev.handle, host, ctypes.c_void_p(out.ptr), n * 8))
+    try:
+        dev.synchronize()
+        print(mode, "silent")
+    except MgxError as exc:
+        print(mode, "raised", exc.code, "call again" in str(exc))
+    dev.master(t, n, r, reference.shape[0], native, result=out, want_report=False)          # the retry
+    dev.synchronize()
+    print(mode, "retry rms_ok", rms(dev.download(out, target.shape)) <= 1e-5)
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["download", "two_calls", "async_copy"])
+def test_an_expired_tail_never_hands_out_the_failed_run(mode):
+    lib = build_tail_variant()
+    done = subprocess.run([sys.executable, "-c", TAIL_CHILD_MODES.format(root=ROOT)],
+                          env=dict(os.environ, MGX_LIB=lib, MGX_TEST_MODE=mode), capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    if mode == "download":
+        assert "download rms_ok True note True" in done.stdout, done.stdout + done.stderr[-2000:]
+    else:
+        assert f"{mode} raised -2 True" in done.stdout, done.stdout + done.stderr[-2000:]
+        assert f"{mode} retry rms_ok True" in done.stdout, done.stdout
+
+
 def test_the_tail_test_build_is_not_the_product():
     sys.path.insert(0, ROOT)
     from matchering_amd import build as native_build
@@ -130,7 +205,7 @@ def test_an_expired_tail_is_run_again_round_by_round_and_succeeds():
     sys.path.insert(0, ROOT)
     from matchering_amd import build as native_build
 
-    lib = native_build.build(out=TAIL_VARIANT, extra_flags=TAIL_FLAGS)
+    lib = build_tail_variant()
     done = subprocess.run([sys.executable, "-c", TAIL_CHILD.format(root=ROOT)], env=dict(os.environ, MGX_LIB=lib),
                           capture_output=True, text=True, timeout=600)
     assert done.returncode == 0, done.stderr[-2000:]

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library BUILDS on one box: tools/ab_libs.sh TAG "bench_stages args" libA.so libB.so ...
-# (python -m matchering_amd.build --variant NAME -DFLAG makes matchering_amd/libmgx_NAME.so).
+# (python -m matchering_amd.build --variant NAME -DFLAG makes tools/variants/libmgx_NAME.so).
 # Alternates processes, three passes, so the box's clock state is shared by the variants.
 OUT=gpurun_out/${1:-ab}; mkdir -p $OUT; ARGS=$2; shift 2
 for pass in 1 2 3; do

@@ -4,7 +4,7 @@ k_conv_delay, over the blocks of one run of config #5's workload (--wide: of k_c
 Needs the development build
 
     python -m matchering_amd.build --variant convphases -DMGX_DEV_CONV_PHASES
-    MGX_LIB=$PWD/matchering_amd/libmgx_convphases.so python tools/conv_delay_phases.py
+    MGX_LIB=$PWD/tools/variants/libmgx_convphases.so python tools/conv_delay_phases.py
 """
 import ctypes
 import os

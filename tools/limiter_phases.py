@@ -3,7 +3,7 @@
 averaged over the chunks of one run.  Needs the development build
 
     python -m matchering_amd.build --variant phases -DMGX_DEV_LIMITER_PHASES
-    MGX_LIB=$PWD/matchering_amd/libmgx_phases.so python tools/limiter_phases.py
+    MGX_LIB=$PWD/tools/variants/libmgx_phases.so python tools/limiter_phases.py
 """
 import ctypes
 import os
