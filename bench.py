@@ -263,7 +263,7 @@ def measure_traffic(workload, timeout=150):
         return {}
     if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER_")) for k in os.environ):
         return {}                                          # already running under a profiler: no nesting
-    kib = {}
+    kib, last_step = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         folder = tempfile.mkdtemp(prefix="mgx_pmc_", dir="/tmp")
         try:
@@ -273,6 +273,7 @@ def measure_traffic(workload, timeout=150):
             subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=timeout, check=True)
             acc = defaultdict(list)
+            rows = []
             for root, _, files in os.walk(folder):
                 for name in files:
                     if name.endswith("counter_collection.csv"):
@@ -280,7 +281,17 @@ def measure_traffic(workload, timeout=150):
                             for row in csv.DictReader(fh):
                                 if row.get("Counter_Name") == counter:
                                     acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+                                    rows.append((int(row.get("Dispatch_Id") or len(rows)), row["Kernel_Name"],
+                                                 float(row["Counter_Value"])))
             kib[counter] = dict(acc)
+            # one whole step: every dispatch from the last k_analyze on (the plan's one-off kernels ran long before)
+            rows.sort()
+            starts = [i for i, r in enumerate(rows) if "k_analyze" in r[1]]
+            if starts:
+                per = defaultdict(float)
+                for _, kernel, value in rows[starts[-1]:]:
+                    per[kernel] += value
+                last_step[counter] = dict(per)
         except Exception:                                   # noqa: BLE001 -- a measurement aid: never lose the line
             return {}
         finally:
@@ -293,15 +304,11 @@ def measure_traffic(workload, timeout=150):
         write = [max(v) for k, v in kib["WRITE_SIZE"].items() if wanted(k)]
         if fetch and write:
             out[stage] = int(max(fetch) * 1024 * 2 + max(write) * 1024)
-    # the whole step, every kernel: counter bytes of all launches / the number of steps the child ran (one k_analyze each)
-    steps = max((len(v) for k, v in kib["FETCH_SIZE"].items() if "k_analyze" in k), default=0)
-    if steps:
-        fetched = sum(sum(v) for v in kib["FETCH_SIZE"].values()) * 1024 * 2 / steps
-        written = sum(sum(v) for v in kib["WRITE_SIZE"].values()) * 1024 / steps
-        out["step_bytes"] = int(fetched + written)
-        out["step_kernels"] = {k.split("(")[0][:48]: int((sum(v) * 2 + sum(kib["WRITE_SIZE"].get(k, [0.0]))) * 1024 / steps)
-                               for k, v in kib["FETCH_SIZE"].items()
-                               if (sum(v) * 2 + sum(kib["WRITE_SIZE"].get(k, [0.0]))) * 1024 / steps > 1e6}
+    if len(last_step) == 2:
+        by_kernel = {k: int((last_step["FETCH_SIZE"].get(k, 0.0) * 2 + last_step["WRITE_SIZE"].get(k, 0.0)) * 1024)
+                     for k in set(last_step["FETCH_SIZE"]) | set(last_step["WRITE_SIZE"])}
+        out["step_bytes"] = sum(by_kernel.values())
+        out["step_kernels"] = {k.split("(")[0][:48]: v for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]) if v > 1e6}
     return out
 
 
@@ -650,6 +657,12 @@ def _cpu_worker(seconds, sample_rate, fft, need, pair, use_reference):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from matchering_amd.synth import make_pair
 
+    try:                        # P processes x a BLAS pool of every core each would only fight: one thread per process
+        from threadpoolctl import threadpool_limits
+
+        threadpool_limits(1)
+    except Exception:           # noqa: BLE001
+        pass
     target, reference = make_pair(seconds, sample_rate, pair=pair)
     if use_reference:
         import warnings

@@ -211,11 +211,9 @@ struct mgx_handle {
     } last_call;
     bool avoid_tail = false;                // sticky after such a report: rounds 1..K-1 as one launch each
     bool requeued = false;                  // the last check_device_error queued the call again
-    // shadow launches (queue_master): a second stream on which a small instance of the NEXT big kernel runs on scratch
-    // while a latency-bound stretch holds the main stream, so that its code is in the instruction caches when it starts
-    hipStream_t side = nullptr;
-    hipEvent_t side_ev = nullptr;
-    DevBuf shadow_out, shadow_words, shadow_mid;
+    // the limiter's chunks are its workgroups' numbers; after a look-back wait has expired once on this handle they are
+    // drawn from an atomic ticket instead, which does not lean on the dispatch order (k_limit, mgx_kernels.h)
+    bool limiter_tickets = false;
     int masters_outstanding = 0;            // mgx_master calls queued since the last check of the error words
     int downloads_outstanding = 0;          // device-to-host copies queued behind them
     ncclComm_t comm = nullptr;
@@ -226,7 +224,6 @@ static int ensure(mgx_handle* h, DevBuf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return 0;
     if (b.p) {
         HIP_TRY(hipStreamSynchronize(h->stream));
-        if (h->side) HIP_TRY(hipStreamSynchronize(h->side));
         HIP_TRY(hipFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
@@ -960,7 +957,8 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     MGX_TRY(ensure(h, h->lim_published, pub_bytes));
     MGX_TRY(ensure_ctrl(h));
     a.published = (unsigned long long*)h->lim_published.p;
-    a.ticket = (int*)h->lim_ctrl.p;
+    const char* force_tickets = std::getenv("MGX_LIMIT_TICKETS");             // measurement aid / tests: "1" = always tickets
+    a.ticket = (h->limiter_tickets || (force_tickets && force_tickets[0] == '1')) ? (int*)h->lim_ctrl.p : nullptr;
     a.error = h->error_dev;
     if (!preset_done) {
         HIP_TRY(hipMemsetAsync(h->lim_published.p, 0xff, pub_bytes, h->stream));
@@ -991,9 +989,6 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c);
 // still switches to one launch per round, so the caller's retry succeeds.
 static int check_device_error(mgx_handle* h, bool may_requeue = false) {
     h->requeued = false;
-    // (the caller has waited for the main stream; a shadow launch reads the caller's target and must be over too before
-    // the caller may free it -- it ended long ago, this costs a host call)
-    if (h->side) HIP_TRY(hipStreamSynchronize(h->side));
     const int outstanding = h->masters_outstanding;
     const int copies = h->downloads_outstanding;
     h->masters_outstanding = 0;
@@ -1011,8 +1006,15 @@ static int check_device_error(mgx_handle* h, bool may_requeue = false) {
     if (what & DEVICE_ERROR_INPUT)
         return fail(MGX_ERR_ARGUMENT, "the target or the reference holds samples that are not finite numbers (NaN or infinity): "
                                       "the reference fails on such input too (match_frequencies.py:42)");
-    if (what == DEVICE_ERROR_TAIL && !h->avoid_tail) {
-        h->avoid_tail = true;                                    // whatever happens next, this handle stops using the tail
+    // What a handle can recover from, once each: an expired tail (its workgroups were not resident together -> one launch
+    // per round from now on) and an expired limiter look-back while chunks were dealt by workgroup number (-> tickets from
+    // now on).  Anything else, or the same again in the safer mode, is a lost word.
+    const bool tail_new = (what & DEVICE_ERROR_TAIL) && !h->avoid_tail;
+    const bool lookback_new = (what & DEVICE_ERROR_LOOKBACK) && !h->limiter_tickets;
+    const bool recoverable = (!(what & DEVICE_ERROR_TAIL) || tail_new) && (!(what & DEVICE_ERROR_LOOKBACK) || lookback_new);
+    if (recoverable) {
+        if (tail_new) h->avoid_tail = true;                      // whatever happens next, this handle stops using the tail
+        if (lookback_new) h->limiter_tickets = true;
         if (may_requeue && h->last_call.valid && outstanding == 1 && copies == 0) {
             const mgx_handle::MasterCall again = h->last_call;
             MGX_TRY(queue_master(h, again));
@@ -1022,15 +1024,20 @@ static int check_device_error(mgx_handle* h, bool may_requeue = false) {
             for (int i = 0; i < DEVICE_ERROR_SLOTS; ++i) clean = clean && e[i] == 0;
             if (clean) {
                 h->requeued = true;
-                g_error = "note: the level-correction tail kernel's workgroups were not resident together (the GPU is shared); "
-                          "the call was run again with one launch per correction round, and this handle keeps doing so";
+                g_error = tail_new ? "note: the level-correction tail kernel's workgroups were not resident together (the GPU is shared); "
+                                     "the call was run again with one launch per correction round, and this handle keeps doing so"
+                                   : "note: a limiter look-back wait expired with chunks dealt by workgroup number; the call was run again "
+                                     "with chunks drawn from an atomic ticket, and this handle keeps doing so";
                 return 0;
             }
             for (int i = 0; i < DEVICE_ERROR_SLOTS; ++i) e[i] = 0;
         } else {
-            return fail(MGX_ERR_HIP, "the level-correction tail kernel's workgroups were not resident together (the GPU is shared) and "
-                                     "the results of the mgx_master calls since the last synchronisation are not valid; this handle now "
-                                     "runs one launch per correction round: call again");
+            return fail(MGX_ERR_HIP, tail_new
+                ? "the level-correction tail kernel's workgroups were not resident together (the GPU is shared) and "
+                  "the results of the mgx_master calls since the last synchronisation are not valid; this handle now "
+                  "runs one launch per correction round: call again"
+                : "a limiter look-back wait expired with chunks dealt by workgroup number and the results of the calls since the "
+                  "last synchronisation are not valid; this handle now draws chunks from an atomic ticket: call again");
         }
     }
     return fail(MGX_ERR_HIP, "a bounded device-side wait expired (limiter look-back or level-correction round): "
@@ -1131,13 +1138,6 @@ int mgx_destroy(mgx_handle* h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    if (h->side) {
-        hipStreamSynchronize(h->side);
-        hipStreamDestroy(h->side);
-        hipEventDestroy(h->side_ev);
-    }
-    for (DevBuf* b : {&h->shadow_out, &h->shadow_words, &h->shadow_mid})
-        if (b->p) hipFree(b->p);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
                       &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->lim_tables, &h->fir_robust, &h->peak_words, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info,
@@ -1172,7 +1172,6 @@ int mgx_free(mgx_handle* h, void* dev) {
     if (!h) return fail(MGX_ERR_ARGUMENT, "null handle");
     if (!dev) return 0;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->side) HIP_TRY(hipStreamSynchronize(h->side));
     HIP_TRY(hipFree(dev));
     h->last_call.valid = false;             // (its pointers may be the block that has just gone: never queued again)
     return 0;
@@ -1352,11 +1351,16 @@ int mgx_limit(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cf
     double* post = (double*)h->pinned;
     *post = post_gain;
     HIP_TRY(hipMemcpyAsync(h->scalars.p, post, sizeof(double), hipMemcpyHostToDevice, h->stream));
-    MGX_TRY(run_limiter(h, x_dev, n, cfg, &cs->gain, (const double*)h->scalars.p, &cs->limiter_active, out_dev));
     CorrectionState host_cs;
-    HIP_TRY(hipMemcpyAsync(&host_cs, cs, sizeof(host_cs), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    MGX_TRY(check_device_error(h));
+    for (int attempt = 0;; ++attempt) {
+        const bool tickets_before = h->limiter_tickets;
+        MGX_TRY(run_limiter(h, x_dev, n, cfg, &cs->gain, (const double*)h->scalars.p, &cs->limiter_active, out_dev));
+        HIP_TRY(hipMemcpyAsync(&host_cs, cs, sizeof(host_cs), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const int rc = check_device_error(h);
+        if (rc == 0) break;
+        if (attempt > 0 || tickets_before || !h->limiter_tickets) return rc;       // (once more when the handle has just switched to tickets)
+    }
     if (active) *active = host_cs.limiter_active;
     return 0;
 }
@@ -1466,95 +1470,6 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
                        int64_t n_reference, const mgx_config* cfg, const float* fir_given, float* result_dev,
                        float* result_no_limiter_dev, float* result_no_limiter_normalized_dev, mgx_report* report);
 // every launch of one stages.main, queued on the handle's stream (no host round trip)
-// ---- shadow launches ------------------------------------------------------------------------------------------
-// A kernel's first pass over its code is paid once per instruction cache (two compute units share one), in full, by
-// every launch: the hundreds of megabytes the kernel before it streamed have pushed the code out of the L2s, and the
-// other kernels of a step out of the instruction caches.  The caches keep their contents from one dispatch to the
-// next, and kernels of two streams run side by side (tools/micro/icache_persist.hip, profiles/r05_a_icache_persist.txt).
-// So while a latency-bound stretch holds the main stream with a few workgroups -- the FIR design (four small kernels),
-// the level-correction tail (<= 129 workgroups) -- a SMALL INSTANCE OF THE NEXT BIG KERNEL runs on a second stream:
-// the same kernel, on a cut of the real input, writing to scratch, with control words of its own.  It waits for
-// nobody and nobody waits for it; all it leaves behind is its code in the instruction caches.
-//   MGX_SHADOW: bit 0 = the limiter under the level-correction tail, bit 1 = the convolution under the FIR design,
-//   bit 2 = the limiter already under round 0 of the level correction (instead of bit 0); unset = SHADOW_DEFAULT.
-constexpr int SHADOW_LIMIT_UNDER_TAIL = 1, SHADOW_CONV_UNDER_DESIGN = 2, SHADOW_LIMIT_UNDER_ROUND0 = 4;
-constexpr int SHADOW_DEFAULT = 0;
-static int shadow_mode() {
-    const char* e = std::getenv("MGX_SHADOW");
-    return e && e[0] ? std::atoi(e) : SHADOW_DEFAULT;
-}
-static int shadow_blocks() {                       // workgroups of a shadow launch (default: one per compute unit)
-    const char* e = std::getenv("MGX_SHADOW_BLOCKS");
-    return e && e[0] ? std::max(1, std::atoi(e)) : 256;
-}
-static int side_stream(mgx_handle* h) {
-    if (h->side) return 0;
-    HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&h->side_ev, hipEventDisableTiming));
-    return 0;
-}
-// the side stream starts where the main stream stands now
-static int side_fork(mgx_handle* h) {
-    MGX_TRY(side_stream(h));
-    HIP_TRY(hipEventRecord(h->side_ev, h->stream));
-    HIP_TRY(hipStreamWaitEvent(h->side, h->side_ev, 0));
-    return 0;
-}
-// k_conv_wide<14> on the first `blocks` blocks of the target, into scratch; the filter spectra are whatever the last
-// call left (the values do not matter).  Nothing if this handle has not convolved yet.
-static int shadow_conv_wide(mgx_handle* h, const float* x, long long n) {
-    constexpr int WIDE = 14;
-    using F = Fft2<WIDE>;
-    const long long hop = ConvWide<WIDE>::HOP;
-    const int blocks = shadow_blocks();
-    if (!h->filt.p || h->filt.bytes < 2 * ((size_t)1 << WIDE) * sizeof(float2) || n < hop * blocks) return 0;
-    const size_t lds = conv_lds_bytes<WIDE>();
-    MGX_TRY((allow_lds(k_conv_wide<WIDE>, lds)));
-    MGX_TRY(ensure(h, h->shadow_out, (size_t)blocks * hop * sizeof(float2)));
-    MGX_TRY(ensure(h, h->shadow_mid, (size_t)blocks * hop * sizeof(float) + (size_t)blocks * sizeof(float)));
-    Conv2Args a;
-    a.x = reinterpret_cast<const float2*>(x);
-    a.n = hop * blocks;
-    a.y = (float2*)h->shadow_out.p;
-    a.ymid = (float*)h->shadow_mid.p;
-    a.run = 0;
-    MGX_TRY(get_twiddles(h, WIDE, &a.tw));
-    a.parts = 1;
-    a.h_mid = (const float2*)h->filt.p;
-    a.h_side = (const float2*)h->filt.p + F::N;
-    a.npairs = blocks;
-    a.pair_peak = (float*)h->shadow_mid.p + (size_t)blocks * hop;
-    a.queue = nullptr;
-    MGX_TRY(side_fork(h));
-    hipLaunchKernelGGL((k_conv_wide<WIDE>), dim3(blocks), dim3(F::T), lds, h->side, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-// k_limit<256,4> on chunks 1 .. `blocks` of y (all inside the track), into scratch, with look-back words that read
-// "published: 0" from the start (nobody waits), a ticket and an error word of its own
-static int shadow_limiter(mgx_handle* h, LimiterArgs a, int threads, const LimiterParams& lp) {
-    const int blocks = shadow_blocks();
-    if (threads != 256 || lp.general != 0 || a.nchunks < blocks + 3) return 0;
-    const long long chunk = lp.geo.chunk;
-    a.n = (long long)(blocks + 3) * chunk;               // chunks 1 .. blocks lie strictly inside this cut
-    a.nchunks = blocks + 3;
-    const size_t words = (size_t)3 * a.nchunks + 16;
-    const bool fresh = h->shadow_words.bytes < words * sizeof(unsigned long long);
-    MGX_TRY(ensure(h, h->shadow_words, words * sizeof(unsigned long long)));
-    MGX_TRY(ensure(h, h->shadow_out, (size_t)a.n * sizeof(float2)));
-    MGX_TRY(side_fork(h));
-    if (fresh) HIP_TRY(hipMemsetAsync(h->shadow_words.p, 0, h->shadow_words.bytes, h->side));   // +0.0 = published
-    a.out = (float2*)h->shadow_out.p;
-    a.published = (unsigned long long*)h->shadow_words.p;
-    a.ticket = (int*)((unsigned long long*)h->shadow_words.p + (size_t)3 * a.nchunks);
-    a.error = a.ticket + 4;
-    a.active = nullptr;
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)a.ticket, 1, 1, h->side));      // the first ticket drawn is chunk 1
-    launch_limiter_256(a, dim3(blocks), h->side);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 static int dev_repeat(const char* name) {
     const char* e = std::getenv(name);
     return e ? std::max(1, std::atoi(e)) : 1;
@@ -1587,8 +1502,6 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
     }
     // stage 2 (stages.py:107-135): FIR design on the device, then the overlap-save convolution with
     // the level gain of stages.py:80-88 (a device scalar) folded into the filter spectra
-    const int shadow = shadow_mode();
-    if ((shadow & SHADOW_CONV_UNDER_DESIGN) && f == 4096) MGX_TRY(shadow_conv_wide(h, target_dev, n_target));
     {
         StageScope scope(h, MGX_STAGE_DESIGN_FIR);
         MGX_TRY(run_fir_design(h, cfg, tw, rw, fir_given));
@@ -1659,16 +1572,6 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
             r.final_peaks = (const float*)h->block_peak.p;
             return 0;
         };
-        LimiterArgs shadow_args;
-        LimiterParams shadow_lp;
-        int shadow_threads = 0;
-        const bool shadow_limit = result_dev && (shadow & (SHADOW_LIMIT_UNDER_TAIL | SHADOW_LIMIT_UNDER_ROUND0)) && rounds > 1 && use_tail;
-        if (shadow_limit) {
-            const double* post = &((const TrackStats*)rw.stats.p)->amplitude_c;
-            MGX_TRY(limiter_args(h, (const float*)h->y.p, n_target, cfg, &cs->gain, post, nullptr, result_dev, shadow_args,
-                                 &shadow_threads, shadow_lp));
-            if (shadow & SHADOW_LIMIT_UNDER_ROUND0) MGX_TRY(shadow_limiter(h, shadow_args, shadow_threads, shadow_lp));
-        }
         if (rounds >= 1) {                                    // round 0 streams the mid plane and builds the band lists
             RoundArgs r0 = ra;
             r0.final_peaks = nullptr;
@@ -1681,8 +1584,6 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
             if (rounds == 1) MGX_TRY(with_final(r0));
             hipLaunchKernelGGL(k_correction_round, dim3(ra.divisions * ra.chunks), dim3(256), lds_step, h->stream, r0);
         }
-        if (shadow_limit && !(shadow & SHADOW_LIMIT_UNDER_ROUND0))
-            MGX_TRY(shadow_limiter(h, shadow_args, shadow_threads, shadow_lp));
         if (rounds > 1 && !use_tail) {
             // one launch per round, the last arriver of each decides (k_correction_round without a tail): what a handle
             // falls back to after its tail kernel found the GPU shared (check_device_error), and MGX_NO_TAIL=1
@@ -1824,6 +1725,9 @@ int mgx_dev_conv_ticks_read(unsigned* out, int blocks) {        // out: [blocks]
 }
 #endif
 #ifdef MGX_DEV_LIMITER_PHASES        // development builds only (tools/limiter_phases.py)
+int mgx_dev_chunk_life_read(long long* out, int chunks) {       // out: [chunks][8]
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx::mgx_dev_chunk_life), (size_t)chunks * 8 * sizeof(long long)) != hipSuccess;
+}
 int mgx_dev_phase_ticks_read(unsigned* out, int chunks) {       // out: [chunks][16]
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(mgx::mgx_dev_phase_ticks), (size_t)chunks * 16 * sizeof(unsigned)) != hipSuccess;
 }

@@ -2369,6 +2369,12 @@ __device__ __forceinline__ float dpp_max8(float v) {
 #ifdef MGX_DEV_LIMITER_PHASES      // development builds only: where a chunk's time goes (tools/limiter_phases.py)
 constexpr int DEV_PHASE_CHUNKS = 16384;
 __device__ unsigned mgx_dev_phase_ticks[DEV_PHASE_CHUNKS][16];       // [chunk][mark]: ticks since the previous mark; [15] = start time
+// every chunk's life, quiet ones included: {kernel entry, frames loaded, end, kind (0 edge, 1 busy, 2 quiet) | cu << 8 | xcc << 20}
+__device__ long long mgx_dev_chunk_life[DEV_PHASE_CHUNKS][8];    // [4] hold word out, [5] hold carry in, [6] release word out, [7] release carry in
+#define DEV_LIFE(slot, value)                                                                        \
+    do {                                                                                             \
+        if (threadIdx.x == 0 && chunk < DEV_PHASE_CHUNKS) mgx_dev_chunk_life[chunk][slot] = (value); \
+    } while (0)
 #define DEV_MARK(k)                                                                                  \
     do {                                                                                             \
         if (threadIdx.x == 0 && chunk < DEV_PHASE_CHUNKS) {                                          \
@@ -2379,6 +2385,7 @@ __device__ unsigned mgx_dev_phase_ticks[DEV_PHASE_CHUNKS][16];       // [chunk][
     } while (0)
 #else
 #define DEV_MARK(k)
+#define DEV_LIFE(slot, value)
 #endif
 // one chunk, from the load phase to the store; FULL = the chunk lies strictly inside the track
 // one chunk, from the load phase to the store; FULL = the chunk lies strictly inside the track
@@ -2417,6 +2424,7 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     }
     DEV_MARK(1);      // hold window + scan
     if (tid == 0) LB::lookback_publish(chunk, 0, a, whole.b);
+    DEV_LIFE(4, wall_clock64());
     // ask for the predecessors' words now, take them after the attack path (wave 0: hold, wave 1: attack)
     typename LB::Polls polls;
     if (wave == 0) LB::lookback_ask(lane, chunk, 0, a, polls);
@@ -2462,6 +2470,7 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
         if (lane == 0) LB::scalars(lds)[2] = s;
     }
     DEV_MARK(4);      // take hold (wave 0)
+    DEV_LIFE(5, wall_clock64());
     __syncthreads();
     DEV_MARK(5);      // barrier after the takes (waits for wave 1's attack take)
 
@@ -2474,6 +2483,7 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
     const Affine pr = compose_waves<false, LB::WAVES>(LB::wave_totals(lds, 3), er, &whole);
     DEV_MARK(6);      // hold output + release scan
     if (tid == 0) LB::lookback_publish(chunk, 1, a, whole.b);
+    DEV_LIFE(6, wall_clock64());
     if (wave == 0) LB::lookback_ask(lane, chunk, 1, a, polls);
     typename LB::Reload again;
     if (FULL) LB::phase_reload(opaque(tid), chunk, a, again);
@@ -2483,6 +2493,7 @@ __device__ __forceinline__ void limit_chunk(const LimiterArgs& a, long long chun
         if (lane == 0) LB::scalars(lds)[1] = s;
     }
     DEV_MARK(8);      // take release
+    DEV_LIFE(7, wall_clock64());
     __syncthreads();
     LB::template phase_gain<FULL>(opaque(tid), a, th, pr, LB::scalars(lds)[1], lds);
     __syncthreads();
@@ -2499,11 +2510,12 @@ template <int T>
 __device__ __forceinline__ void limit_chunk_quiet(const LimiterArgs& a, long long chunk, float* lds,
                                                   const typename LimiterBlock<T>::Reload& kept) {
     using LB = LimiterBlock<T>;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = opaque((int)threadIdx.x), lane = tid & 63, wave = tid >> 6;
     if (tid == 0) {
         LB::lookback_publish(chunk, 0, a, 0.0);
         LB::lookback_publish(chunk, 2, a, 0.0);
     }
+    DEV_LIFE(4, wall_clock64());
     typename LB::Polls polls;
     if (wave == 0) {
         LB::lookback_ask(lane, chunk, 0, a, polls);
@@ -2517,13 +2529,16 @@ __device__ __forceinline__ void limit_chunk_quiet(const LimiterArgs& a, long lon
     }
     __syncthreads();
     const double hc = LB::scalars(lds)[0], ac = LB::scalars(lds)[2];
+    DEV_LIFE(5, wall_clock64());
     if (tid == 0) LB::lookback_publish(chunk, 1, a, hc * a.quiet_rel_gain);
+    DEV_LIFE(6, wall_clock64());
     if (wave == 0) {
         LB::lookback_ask(lane, chunk, 1, a, polls);
         const double s = wave_sum(LB::lookback_take(lane, chunk, 1, a, polls));
         if (lane == 0) LB::scalars(lds)[1] = s;
     }
     __syncthreads();
+    DEV_LIFE(7, wall_clock64());
     LB::phase_quiet_store(tid, chunk, a, kept, hc, ac, LB::scalars(lds)[1]);
 }
 
@@ -2767,9 +2782,13 @@ __global__ __launch_bounds__(256, 2) void k_limit_general(LimiterArgs a, General
         LB::phase_store(threadIdx.x, blockIdx.x, a, false, lds);
         return;
     }
-    if (threadIdx.x == 0) ticket = atomicAdd(a.ticket, 1);
-    __syncthreads();
-    limit_chunk_general<K>(a, g, ticket, lds);
+    long long chunk = blockIdx.x;            // (the workgroup's number, or a ticket: see k_limit)
+    if (a.ticket) {
+        if (threadIdx.x == 0) ticket = atomicAdd(a.ticket, 1);
+        __syncthreads();
+        chunk = ticket;
+    }
+    limit_chunk_general<K>(a, g, chunk, lds);
 }
 
 // T = threads = 16-frame blocks per chunk (256, or 1024 for long attack / hold times); WGS = workgroups
@@ -2800,11 +2819,27 @@ __global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a0) {
         LB::phase_store(tid, blockIdx.x, a, false, lds);
         return;
     }
-    if (tid == 0) ticket = atomicAdd(a.ticket, 1);
-    __syncthreads();
-    const long long chunk = ticket;
+#ifdef MGX_DEV_LIMITER_PHASES
+    const long long dev_entry = wall_clock64();
+#endif
+    // Which chunk?  The workgroup's own number.  A chunk waits for words of LOWER-numbered chunks only, and the
+    // dispatcher walks a grid in the order of the workgroup numbers (the walk may stall on an XCD whose slots are all
+    // taken, but whatever it has handed out is lower-numbered than what it has not): the lowest unfinished chunk has
+    // always been handed out, all it waits for is finished, so it finishes -- no chunk can wait for ever.  An atomic
+    // ticket (a.ticket != null) gives the same guarantee without leaning on the dispatch order, at the price of a
+    // returning atomic and a barrier in front of every chunk's loads (entry to loaded 6.2 -> 3.3 us, the kernel
+    // 152 -> 134 us: profiles/r05_g_*); a handle falls back to it if a bounded look-back wait ever expires.
+    long long chunk = blockIdx.x;
+    if (a.ticket) {
+        if (tid == 0) ticket = atomicAdd(a.ticket, 1);
+        __syncthreads();
+        chunk = ticket;
+    }
+    DEV_LIFE(0, dev_entry);
     if (!LB::full_chunk(chunk, a)) {
         limit_chunk<T, false>(a, chunk, lds);
+        DEV_LIFE(2, wall_clock64());
+        DEV_LIFE(3, 0ll | ((long long)__builtin_amdgcn_s_getreg((4 << 11) | 4) << 8));
         return;
     }
     // a chunk inside the track: load (the frames stay in registers until it is known whether the chunk is
@@ -2827,8 +2862,13 @@ __global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a0) {
     bool chunk_busy = false;
 #pragma unroll
     for (int w = 0; w < LB::WAVES; ++w) chunk_busy = chunk_busy || LB::edge_sl(lds)[w] != 0.f;
+    DEV_LIFE(1, wall_clock64());
     if (!chunk_busy && a.quiet_ok) limit_chunk_quiet<T>(a, chunk, lds, kept);
     else limit_chunk<T, true>(a, chunk, lds);
+    DEV_LIFE(2, wall_clock64());
+    // HW_ID (hwreg 4): cu_id bits 11:8, sh 12, se 15:13; XCC_ID (hwreg 20)
+    DEV_LIFE(3, (long long)((!chunk_busy && a.quiet_ok) ? 2 : 1) | ((long long)__builtin_amdgcn_s_getreg((15 << 11) | 4) << 8) |
+                    ((long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32));
 }
 
 }  // namespace mgx

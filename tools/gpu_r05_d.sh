@@ -7,3 +7,4 @@ timeout 400 python tools/bench_stages.py --rounds 7 base gen:MGX_LIMIT_GENERAL=1
 timeout 60 python -c "
 import sys; sys.path.insert(0,'tools')
 from gpu_state import compact_state; s=compact_state(); print(s['pci_bus'], s['memory_probe']['ns_per_instruction_112KiB_code'])" 2>&1 | tail -1
+timeout 200 python -X faulthandler -m pytest tests/test_batch.py -m gpu -x -q -p no:cacheprovider --timeout 150 -k "album" > $OUT/pytest_album.log 2>&1; echo "album rc=$?"; tail -30 $OUT/pytest_album.log
