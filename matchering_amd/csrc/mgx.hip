@@ -896,6 +896,8 @@ static void launch_limiter_256(const LimiterArgs& a, dim3 grid, hipStream_t stre
         hipLaunchKernelGGL((k_limit<256, 4, 44, 43, 26>), grid, dim3(256), lds, stream, a);
     else if (fixed && a.hw == 48 && a.hb == 47 && a.gr == 28 && a.gl == 6 && a.gw == 3)            // 48 kHz
         hipLaunchKernelGGL((k_limit<256, 4, 48, 47, 28>), grid, dim3(256), lds, stream, a);
+    else if (fixed && a.hw == 96 && a.hb == 95 && a.gr == 55 && a.gl == 12 && a.gw == 6)           // 96 kHz (BASELINE config #5)
+        hipLaunchKernelGGL((k_limit<256, 4, 96, 95, 55>), grid, dim3(256), lds, stream, a);
     else
         hipLaunchKernelGGL((k_limit<256, 4>), grid, dim3(256), lds, stream, a);
 }

@@ -118,10 +118,10 @@ def test_code_sizes_are_read_from_the_librarys_own_code_object():
         if m:
             seen[m.group(2)] = int(m.group(1))
     assert seen["_ZN3mgx6k_convILi13ELb0EEEvNS_9Conv2ArgsE"] == conv[13]
-    # the 256-block limiter has three instantiations (the general one and two for fixed window geometries): the table
+    # the 256-block limiter has four instantiations (the general one and three for fixed window geometries): the table
     # holds the smallest, so that no instantiation's window reaches past its own code
     limiters = [size for name, size in seen.items() if name.startswith("_ZN3mgx7k_limitILi256ELi4E")]
-    assert len(limiters) == 3 and min(limiters) == limit[0]
+    assert len(limiters) == 4 and min(limiters) == limit[0]
     assert seen["_ZN3mgx9k_analyzeILi12EEEvNS_12AnalysisArgsES1_i"] == analyze[12]
     assert min(seen["_ZN3mgx6k_convILi14ELb0EEEvNS_9Conv2ArgsE"], seen["_ZN3mgx6k_convILi14ELb1EEEvNS_9Conv2ArgsE"]) == conv[14]
     assert seen["_ZN3mgx12k_conv_delayILi14EEEvNS_9Conv2ArgsE"] == conv[15]        # the delay-line kernel's own slot
@@ -153,4 +153,5 @@ def test_the_hot_kernels_do_not_spill():
     assert scratch("k_limitILi256ELi4ELin1E") <= 16             # the general instantiation (two spilled scalars of the look-back)
     assert scratch("k_limitILi256ELi4ELi44ELi43E") == 0         # the headline workload's: 44.1 kHz, 1 ms attack and hold
     assert scratch("k_limitILi256ELi4ELi48ELi47E") == 0         # 48 kHz
+    assert scratch("k_limitILi256ELi4ELi96ELi95E") <= 16        # 96 kHz (config #5)
     assert scratch("k_correction_tail") == 0
