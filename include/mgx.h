@@ -118,7 +118,7 @@ int mgx_timer_stop(mgx_handle* h, float* milliseconds);
  * before the GPU has finished (mgx_synchronize to wait); with a report it waits
  * itself and fills it.
  * Limits (MGX_ERR_UNSUPPORTED, never a silent approximation): fft_size in
- * [64, 32768]; limiter filter orders 1 or 2; lowess_it in [0, 64]; tracks up to 536 million
+ * [8, 65536]; limiter filter orders 1 or 2; lowess_it in [0, 64]; tracks up to 536 million
  * frames (32-bit byte offsets; 3.3 hours at 44.1 kHz). */
 int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target,
                const float* reference_dev, int64_t n_reference, const mgx_config* cfg,

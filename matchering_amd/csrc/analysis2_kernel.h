@@ -43,6 +43,7 @@ struct AnalysisArgs {
     float* wg_peak;         // max(|L|,|R|) over the frames this workgroup owns
     float* wg_spec;         // [wg][2][F/2+1] sum over segments of |M_k|, |S_k| (unscaled)
     const float2* tw;
+    float2* wg_pack;        // fft_size 65536 only (AnalysisQuad): [wg][F/4+1] spectrum of a segment's even samples
 };
 
 template <int LOG2N>
@@ -340,6 +341,175 @@ struct AnalysisDouble {
             side[N - k] = t.hi[1][q];
         }
         if (tid == 0) { mid[N / 2] = t.lo[0][RL / 2]; side[N / 2] = t.lo[1][RL / 2]; }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// fft_size = 4 N': a segment's spectra from FOUR transforms of N' points per channel pair -- the split above applied
+// twice.  The 4 N' real samples r of a channel fall into the even ones e[n] = r[2n] and the odd ones o[n] = r[2n+1],
+// two real sequences of 2 N' points whose spectra E_k, O_k (k = 0 .. N') are what AnalysisDouble forms, as complex
+// values now, not magnitudes, and
+//     R_k = E_k + w^k O_k,   R_{2N'-k} = conj(E_k - w^k O_k),   w = exp(-j pi / (2 N')),   k = 0 .. N'
+// (bin N' comes out of k = N' twice: counted once).  Passes of a segment: mid even, mid odd, side even, side odd.
+// The even pass leaves E_k in the workgroup's slice of global scratch (a.wg_pack, N' + 1 values: a thread reads back
+// what it wrote itself, no barrier involved); the odd pass adds |E_k +- w^k O_k| to the workgroup's spectrum rows
+// in wg_spec directly -- 4 bins per pair {k, N'-k} and channel are 64 accumulators a thread of the 1024 has no
+// registers for, and every bin has exactly one owner.  Frames are read four times (three of them from the L2).
+template <int LOG2H>
+struct AnalysisQuad {
+    using AB = Analysis2Block<LOG2H>;
+    using AD = AnalysisDouble<LOG2H>;
+    using F = Fft2<LOG2H>;
+    static constexpr int N = F::N;                 // N'; the segment has 4 N frames, the spectrum 2 N + 1 bins
+    static constexpr int T = F::T;
+    static constexpr int R0 = F::R0;
+    static constexpr int RL = F::RL;
+    static constexpr int S0 = F::S(0);
+    static constexpr int CNT0 = F::CNT(0);
+    using Persist = typename AB::Persist;
+
+    struct Thread {
+        double sumsq;
+        float peak;
+    };
+    static MGX_HD void init(Thread& t) {
+        t.sumsq = 0.0;
+        t.peak = 0.f;
+    }
+    static MGX_HD float* spectrum_row(const AnalysisArgs& a, int wg, bool side) {
+        return a.wg_spec + ((size_t)wg * 2 + (side ? 1 : 0)) * (2 * N + 1);
+    }
+    // the bins a thread owns start from zero
+    static MGX_HD void phase_clear(int tid, int wg, const AnalysisArgs& a) {
+        if (!F::has_row(tid)) return;
+        const int k0 = F::frequency_at(tid * RL);
+        for (int c = 0; c < 2; ++c) {
+            float* row = spectrum_row(a, wg, c != 0);
+            MGX_UNROLL
+            for (int q = 0; q < RL / 2; ++q) {
+                const int k = k0 + q * F::L;
+                row[k] = 0.f;
+                row[N - k] = 0.f;
+                row[N + k] = 0.f;
+                row[2 * N - k] = 0.f;
+            }
+            if (tid == 0) { row[N / 2] = 0.f; row[3 * N / 2] = 0.f; }
+        }
+    }
+    // frames 4m + PARITY and 4m + 2 + PARITY of the segment -> packed mid (or side) samples, pass 0 -> LDS; the mid
+    // passes also gather the level statistics (both parities together see every frame once)
+    template <bool SIDE, int PARITY>
+    static MGX_HD void phase_load(int tid, long long start, const AnalysisArgs& a, const Persist& ps, Thread& t,
+                                  float2* lds) {
+        if (!AB::active0(tid)) return;
+        typename F::Tw0Full tw;
+        F::expand_tw0(ps.tw0, tw);
+        const MemView src = mem_view(a.x, a.n * 8);
+        MGX_UNROLL
+        for (int c = 0; c < CNT0; ++c) {
+            const unsigned lane = ((unsigned)start + 4u * (unsigned)(tid + c * T) + (unsigned)PARITY) * 8u;
+            float2 f0[R0], f1[R0];
+            MGX_UNROLL
+            for (int j = 0; j < R0; ++j) {
+                f0[j] = ld_f2(src, lane, (unsigned)(j * S0 * 32));
+                f1[j] = ld_f2(src, lane, (unsigned)(j * S0 * 32 + 16));
+            }
+            float2 v[R0];
+            float ss = 0.f;
+            MGX_UNROLL
+            for (int j = 0; j < R0; ++j) {
+                float m0, s0, m1, s1;
+                AB::to_ms(f0[j], m0, s0);
+                AB::to_ms(f1[j], m1, s1);
+                v[j] = SIDE ? make_float2(s0, s1) : make_float2(m0, m1);
+                if (!SIDE) {
+                    ss = fmaf(m0, m0, fmaf(m1, m1, ss));
+                    t.peak = fmaxf(t.peak, fmaxf(fmaxf(fabsf(f0[j].x), fabsf(f0[j].y)), fmaxf(fabsf(f1[j].x), fabsf(f1[j].y))));
+                }
+            }
+            if (!SIDE) t.sumsq += (double)ss;
+            F::fwd0_store(v, tid, c, tw, lds);
+        }
+    }
+    static MGX_HD void phase_row(int tid, float2* lds) { AD::phase_row(tid, lds); }
+
+    // the spectrum U (of the 2 N' even or odd samples) at the thread's pairs: lo[q] = U_k, hi[q] = U_{N'-k} for the bin
+    // k of (row, q < RL/2); on thread 0 lo[0] = U_0, hi[0] = U_{N'} (both real) and half = U_{N'/2}
+    struct Pairs {
+        float2 lo[RL / 2], hi[RL / 2];
+        float2 half;
+    };
+    static MGX_HD void phase_unmix(int tid, Pairs& u, const float2* lds) {
+        if (!F::has_row(tid)) return;
+        float2 z[RL / 2 + 2], m[RL / 2];
+        F::template load_row_part<0, RL / 2 + 2>(z, tid, lds);
+        F::template load_row_part<RL / 2, RL / 2>(m, F::mirror_row(tid), lds);
+        const bool r0 = tid == 0;
+        const int k0 = F::frequency_at(tid * RL);
+        MGX_UNROLL
+        for (int q = 0; q < RL / 2; ++q) {
+            const float2 a = m[RL / 2 - 1 - q];
+            const float2 b = q == 0 ? z[0] : m[RL / 2 - q];
+            const float2 zm = make_float2(r0 ? b.x : a.x, r0 ? b.y : a.y);
+            // 2A = Z + conj Zm, 2B = (Z - conj Zm) / j;  U_k = A + v^k B, U_{N'-k} = conj(A - v^k B), v = exp(-j pi / N')
+            const float ax = z[q].x + zm.x, ay = z[q].y - zm.y;
+            const float bx = z[q].y + zm.y, by = -(z[q].x - zm.x);
+            const int k = k0 + q * F::L;
+            float sn, cs;
+            sincos_pi((float)k * (1.0f / (float)N), sn, cs);
+            const float wx = fmaf(cs, bx, sn * by), wy = fmaf(cs, by, -sn * bx);
+            u.lo[q] = make_float2(0.5f * (ax + wx), 0.5f * (ay + wy));
+            u.hi[q] = make_float2(0.5f * (ax - wx), -0.5f * (ay - wy));
+        }
+        // k = N'/2 mirrors into itself: A = Re Y, B = Im Y, v^k = -j: U = A - j B = conj(Y)
+        u.half = make_float2(z[RL / 2].x, -z[RL / 2].y);
+    }
+    // even pass: E to the workgroup's scratch
+    static MGX_HD void phase_keep(int tid, int wg, const AnalysisArgs& a, const Pairs& e) {
+        if (!F::has_row(tid)) return;
+        float2* pack = a.wg_pack + (size_t)wg * (N + 1);
+        const int k0 = F::frequency_at(tid * RL);
+        MGX_UNROLL
+        for (int q = 0; q < RL / 2; ++q) {
+            const int k = k0 + q * F::L;
+            pack[k] = e.lo[q];
+            pack[N - k] = e.hi[q];
+        }
+        if (tid == 0) pack[N / 2] = e.half;
+    }
+    // |E + w^k O| -> bin k, |E - w^k O| -> bin 2N' - k (skipped for k = N': the same bin)
+    static MGX_HD void add_bins(float* row, int k, float2 e, float2 o) {
+        float sn, cs;
+        sincos_pi((float)k * (0.5f / (float)N), sn, cs);                  // w^k = cs - j sn
+        const float tx = fmaf(cs, o.x, sn * o.y), ty = fmaf(cs, o.y, -sn * o.x);
+        const float px = e.x + tx, py = e.y + ty, mx = e.x - tx, my = e.y - ty;
+        row[k] += fast_sqrt(fmaf(px, px, py * py));
+        if (k != N) row[2 * N - k] += fast_sqrt(fmaf(mx, mx, my * my));
+    }
+    // odd pass: O in registers, E back from the scratch, magnitudes into the spectrum rows
+    template <bool SIDE>
+    static MGX_HD void phase_magnitudes(int tid, int wg, const AnalysisArgs& a, const Pairs& o) {
+        if (!F::has_row(tid)) return;
+        const float2* pack = a.wg_pack + (size_t)wg * (N + 1);
+        float* row = spectrum_row(a, wg, SIDE);
+        const int k0 = F::frequency_at(tid * RL);
+        MGX_UNROLL
+        for (int q = 0; q < RL / 2; ++q) {
+            const int k = k0 + q * F::L;
+            add_bins(row, k, pack[k], o.lo[q]);
+            add_bins(row, N - k, pack[N - k], o.hi[q]);
+        }
+        if (tid == 0) add_bins(row, N / 2, pack[N / 2], o.half);
+    }
+    static MGX_HD void phase_loose_frames(int tid, long long begin, long long end, bool count_rms, const AnalysisArgs& a,
+                                          Thread& t) {
+        for (long long f = begin + tid; f < end; f += T) {
+            const float2 lr = a.x[f];
+            float m, s;
+            AB::to_ms(lr, m, s);
+            if (count_rms) t.sumsq += (double)(m * m);
+            t.peak = fmaxf(t.peak, fmaxf(fabsf(lr.x), fabsf(lr.y)));
+        }
     }
 };
 

@@ -155,6 +155,7 @@ struct DevBuf {
 
 struct TrackWork {              // per-track analysis workspace + results (device)
     DevBuf wg_sumsq, wg_peak, wg_spec, stats, rms, loud, avg;   // avg: [2][F/2+1] double
+    DevBuf wg_pack;                                              // fft_size 65536: [nwg][F/4+1] float2 (AnalysisQuad)
     DevBuf part;                                                 // [SPEC_SLICES][2][F/2+1] partial spectrum sums
     int divisions = 0, segs_per_piece = 0, segs_per_wg = 0, chunks = 0, nwg = 0, is_reference = 0;
     long long piece = 0;
@@ -164,6 +165,13 @@ struct PlanDev {
     void* blob = nullptr;       // FirPlanHost tables
     double* M = nullptr;        // [bins][bins] raw -> smooth operator
     int2* band = nullptr;       // [bins] columns [x, y) of each row that matter (k_fir_band)
+    // the same operator in two packed, banded factors (fft_size >= 16384; mgx_kernels.h, k_fir_apply_a / _b)
+    struct Factor {
+        double* packed = nullptr;       // the rows' windows, one after the other
+        int2* band = nullptr;           // [rows] window of each row
+        long long* off = nullptr;       // [rows] where a row's window starts in `packed`
+        size_t bytes = 0;
+    } A, B;
     std::shared_ptr<FirPlanHost> plan;      // keeps the host tables alive as long as the device copy
 };
 // One copy per (device, Config's design parameters) for the whole process, not per handle: the operator
@@ -320,9 +328,9 @@ static int check_config(const mgx_config* c) {
     if (c->fft_size < 8)          /* (defaults.py:110-112 lets 2 and 4 through; match_frequencies.py:45-58 then fails) */
         return fail(MGX_ERR_ARGUMENT, "fft_size below 8: the reference's own cubic interpolation of the matching curve "
                                       "needs at least four points per side and fails there");
-    if (c->fft_size > 32768)
-        return fail(MGX_ERR_UNSUPPORTED, "fft_size above 32768 is not implemented "
-                                         "(an analysis segment is one or two transforms that fit one CU's LDS)");
+    if (c->fft_size > 65536)
+        return fail(MGX_ERR_UNSUPPORTED, "fft_size above 65536 is not implemented "
+                                         "(an analysis segment is one, two or four transforms that fit one CU's LDS)");
     if (c->rms_correction_steps < 0) return fail(MGX_ERR_ARGUMENT, "rms_correction_steps must not be negative");
     if (c->rms_correction_steps > 4096)      /* (a flag word per round and summing workgroup: 4 MB at 4096) */
         return fail(MGX_ERR_UNSUPPORTED, "more than 4096 rms_correction_steps are not implemented");
@@ -354,7 +362,8 @@ static int analysis_workgroups_per_cu(int log2f) {
 #define CASE(L) case L: lds = analysis_lds_bytes<L>(); threads = Fft2<L>::T; break;
         CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
-        case 15: lds = analysis_lds_bytes<14>(); threads = Fft2<14>::T; break;       // two 16384-point transforms per segment
+        case 15:                                                                     // two 16384-point transforms per segment
+        case 16: lds = analysis_lds_bytes<14>(); threads = Fft2<14>::T; break;       // four
         default: return 1;
     }
     const int by_lds = (int)((size_t)160 * 1024 / lds), by_waves = 2048 / threads;
@@ -416,6 +425,7 @@ static int choose_chunks(mgx_handle* h, const mgx_config* cfg, TrackWork* const*
         MGX_TRY(ensure(h, w.wg_sumsq, (size_t)w.nwg * sizeof(double)));
         MGX_TRY(ensure(h, w.wg_peak, (size_t)w.nwg * sizeof(float)));
         MGX_TRY(ensure(h, w.wg_spec, (size_t)w.nwg * 2 * (half + 1) * sizeof(float)));
+        if (cfg->fft_size == 65536) MGX_TRY(ensure(h, w.wg_pack, (size_t)w.nwg * (cfg->fft_size / 4 + 1) * sizeof(float2)));
         MGX_TRY(ensure(h, w.stats, sizeof(TrackStats)));
         MGX_TRY(ensure(h, w.rms, (size_t)w.divisions * sizeof(double)));
         MGX_TRY(ensure(h, w.loud, (size_t)w.divisions * sizeof(int)));
@@ -436,9 +446,10 @@ static int analysis_args(mgx_handle* h, const float* x, long long n, const mgx_c
     a.wg_sumsq = (double*)w.wg_sumsq.p;
     a.wg_peak = (float*)w.wg_peak.p;
     a.wg_spec = (float*)w.wg_spec.p;
+    a.wg_pack = (float2*)w.wg_pack.p;
     a.tw = nullptr;
     if (cfg->fft_size < 64) return 0;                            // k_analyze_small transforms in registers: no table
-    // (fft_size 32768 runs on 16384-point transforms: AnalysisDouble)
+    // (fft_size 32768 and 65536 run on 16384-point transforms: AnalysisDouble, AnalysisQuad)
     return get_twiddles(h, std::min(14, ilog2_exact(cfg->fft_size)), &a.tw);
 }
 
@@ -465,6 +476,13 @@ static int run_analysis(mgx_handle* h, const mgx_config* cfg, const float* x0, l
             const size_t lds = analysis_lds_bytes<14>();
             MGX_TRY(allow_lds(k_analyze_double<14>, lds));
             hipLaunchKernelGGL(k_analyze_double<14>, dim3(nwg), dim3(Fft2<14>::T), lds, h->stream, a0, a1, w0.nwg);
+            HIP_TRY(hipGetLastError());
+            break;
+        }
+        case 16: {
+            const size_t lds = analysis_lds_bytes<14>();
+            MGX_TRY(allow_lds(k_analyze_quad<14>, lds));
+            hipLaunchKernelGGL(k_analyze_quad<14>, dim3(nwg), dim3(Fft2<14>::T), lds, h->stream, a0, a1, w0.nwg);
             HIP_TRY(hipGetLastError());
             break;
         }
@@ -543,15 +561,82 @@ static int build_fir_operator(mgx_handle* h, const FirPlanView& pl, double** out
     return 0;
 }
 
+// A dense [rows][cols] matrix -> its rows' windows (k_fir_band), packed.  The dense matrix is freed.
+static int pack_fir_factor(mgx_handle* h, double* dense, int rows, int cols, PlanDev::Factor& f) {
+    HIP_TRY(hipMalloc((void**)&f.band, (size_t)rows * sizeof(int2)));
+    hipLaunchKernelGGL(k_fir_band, dim3(rows), dim3(256), 0, h->stream, (const double*)dense, cols, f.band);
+    HIP_TRY(hipGetLastError());
+    std::vector<int2> band(rows);
+    HIP_TRY(hipMemcpyAsync(band.data(), f.band, (size_t)rows * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<long long> off(rows);
+    long long total = 0;
+    for (int r = 0; r < rows; ++r) {
+        off[r] = total;
+        total += (band[r].y - band[r].x + 1) & ~1;               // (rows start on 16-byte boundaries)
+    }
+    f.bytes = (size_t)std::max<long long>(total, 2) * sizeof(double);
+    HIP_TRY(hipMalloc((void**)&f.off, (size_t)rows * sizeof(long long)));
+    HIP_TRY(hipMalloc((void**)&f.packed, f.bytes));
+    HIP_TRY(hipMemcpyAsync(f.off, off.data(), (size_t)rows * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemsetAsync(f.packed, 0, f.bytes, h->stream));
+    hipLaunchKernelGGL(k_fir_pack, dim3(rows), dim3(256), 0, h->stream, (const double*)dense, cols, (const int2*)f.band,
+                       (const long long*)f.off, f.packed);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(dense));
+    return 0;
+}
+
+// raw -> smooth as B * (A * raw) through the anchors' LOWESS fits (mgx_kernels.h): unit vectors pushed through the two
+// halves of the chain, 256 at a time, gathered into dense matrices that live only until their windows are packed
+static int build_fir_factors(mgx_handle* h, const FirPlanView& pl, PlanDev& pd) {
+    const size_t per = (size_t)3 * pl.bins + (size_t)3 * pl.nlog + pl.lw.anchors;
+    const int anchors = pl.lw.anchors, batch = 256;
+    double* scratch = nullptr;
+    double* dense = nullptr;
+    HIP_TRY(hipMalloc((void**)&scratch, (size_t)batch * per * sizeof(double)));
+    const size_t lds_scan = (size_t)FirDesign::Scan::SCRATCH * sizeof(Affine);
+    // A: unit raw curves -> the anchors' fits
+    HIP_TRY(hipMalloc((void**)&dense, (size_t)anchors * pl.bins * sizeof(double)));
+    for (int col0 = 0; col0 < pl.bins; col0 += batch) {
+        const int nb = std::min(batch, pl.bins - col0);
+        hipLaunchKernelGGL(k_fir_unit_a, dim3(nb), dim3(1024), lds_scan, h->stream, pl, scratch, col0);
+        hipLaunchKernelGGL(k_fir_lowess, dim3((anchors + 15) / 16, nb), dim3(1024), 0, h->stream, pl, scratch);
+        hipLaunchKernelGGL(k_fir_gather_plane, dim3((nb + 255) / 256, anchors), dim3(256), 0, h->stream, pl, scratch, col0,
+                           nb, pl.bins, 1, dense);
+    }
+    HIP_TRY(hipGetLastError());
+    MGX_TRY(pack_fir_factor(h, dense, anchors, pl.bins, pd.A));
+    // B: unit fits -> the smooth curve on the linear grid
+    HIP_TRY(hipMalloc((void**)&dense, (size_t)pl.bins * anchors * sizeof(double)));
+    for (int col0 = 0; col0 < anchors; col0 += batch) {
+        const int nb = std::min(batch, anchors - col0);
+        hipLaunchKernelGGL(k_fir_unit_fit, dim3(nb), dim3(256), 0, h->stream, pl, scratch, col0);
+        hipLaunchKernelGGL(k_fir_b, dim3(nb), dim3(1024), lds_scan, h->stream, pl, scratch);
+        hipLaunchKernelGGL(k_fir_gather_plane, dim3((nb + 255) / 256, pl.bins), dim3(256), 0, h->stream, pl, scratch, col0,
+                           nb, anchors, 0, dense);
+    }
+    HIP_TRY(hipGetLastError());
+    MGX_TRY(pack_fir_factor(h, dense, pl.bins, anchors, pd.B));
+    HIP_TRY(hipFree(scratch));
+    return 0;
+}
+
 // fir_given: a FIR pair to use instead of the designed one (album mode), or null
 static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork& tw, const TrackWork& rw,
                           const float* fir_given) {
     FirDesignParams p{cfg->fft_size, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac,
                       cfg->lowess_it, cfg->lowess_delta, cfg->min_value};
     std::shared_ptr<FirPlanHost> plan = FirPlanHost::get(p);
-    // no operator when LOWESS is not linear (robustness passes), nor when it would not be worth its size:
-    // bins^2 doubles are 2.1 GB at fft_size 32768
-    const bool robust = cfg->lowess_it > 0, direct = robust || plan->bins() > 8193;
+    // no operator when LOWESS is not linear (robustness passes): the chain runs on the curve itself.  Otherwise the
+    // dense operator up to fft_size 8192 (134 MB there, of which a product reads a sixth), its two packed factors
+    // from 16384 on (MGX_FIR_ROUND4=1: the choices of round 4, for A/B measurements)
+    const bool robust = cfg->lowess_it > 0;
+    const char* env_old = std::getenv("MGX_FIR_ROUND4");
+    const bool round4 = env_old && env_old[0] == '1';            // dense at 16384, the chain itself beyond
+    const bool factored = !robust && plan->bins() > 4097 && !round4;
+    const bool direct = robust || (!factored && plan->bins() > 8193);
     PlanDev pd;
     {
         // (the first handle to need an operator builds it on its own stream and waits for it; its siblings
@@ -563,7 +648,11 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
             HIP_TRY(hipMemcpy(shared.blob, plan->blob(), plan->blob_bytes(), hipMemcpyHostToDevice));
             shared.plan = plan;
         }
-        if (!direct && !shared.M) MGX_TRY(build_fir_operator(h, plan->view(shared.blob), &shared.M, &shared.band));
+        if (factored) {
+            if (!shared.B.packed) MGX_TRY(build_fir_factors(h, plan->view(shared.blob), shared));
+        } else if (!direct && !shared.M) {
+            MGX_TRY(build_fir_operator(h, plan->view(shared.blob), &shared.M, &shared.band));
+        }
         pd = shared;
     }
     const FirPlanView pl = plan->view(pd.blob);
@@ -590,10 +679,22 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     if (lds_curve <= (size_t)150 * 1024) {
         CurveTrack ct{levels_args(tw), (const float*)tw.wg_spec.p, tw.nwg, tw.segs_per_piece};
         CurveTrack cr{levels_args(rw), (const float*)rw.wg_spec.p, rw.nwg, rw.segs_per_piece};
-        MGX_TRY(allow_lds(k_match_curve, lds_curve));
-        hipLaunchKernelGGL(k_match_curve, dim3((pl.bins + 31) / 32, 2), dim3(1024), lds_curve, h->stream, ct, cr, pl.bins,
-                           pl.fft, max_div, cfg->threshold, cfg->min_value, pl.min_value, raw, (double*)h->scalars.p,
-                           (CorrectionState*)h->cstate.p, h->error_dev);
+        // tiles of 33 bins where they save a round of workgroups (one workgroup of 1024 threads per CU)
+        int dev_cus = 256;
+        HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        auto rounds = [&](int tile) { return (2 * ((pl.bins + tile - 1) / tile) + dev_cus - 1) / dev_cus; };
+        const char* tile32 = std::getenv("MGX_CURVE_TILE32");                    // (A/B: always 32)
+        if (rounds(33) < rounds(32) && !(tile32 && tile32[0] == '1')) {
+            MGX_TRY(allow_lds(k_match_curve<33>, lds_curve));
+            hipLaunchKernelGGL(k_match_curve<33>, dim3((pl.bins + 32) / 33, 2), dim3(1024), lds_curve, h->stream, ct, cr,
+                               pl.bins, pl.fft, max_div, cfg->threshold, cfg->min_value, pl.min_value, raw,
+                               (double*)h->scalars.p, (CorrectionState*)h->cstate.p, h->error_dev);
+        } else {
+            MGX_TRY(allow_lds(k_match_curve<32>, lds_curve));
+            hipLaunchKernelGGL(k_match_curve<32>, dim3((pl.bins + 31) / 32, 2), dim3(1024), lds_curve, h->stream, ct, cr,
+                               pl.bins, pl.fft, max_div, cfg->threshold, cfg->min_value, pl.min_value, raw,
+                               (double*)h->scalars.p, (CorrectionState*)h->cstate.p, h->error_dev);
+        }
     } else {
         TrackWork& t = const_cast<TrackWork&>(tw);
         TrackWork& r = const_cast<TrackWork&>(rw);
@@ -621,6 +722,11 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
             hipLaunchKernelGGL(k_fir_lowess, dim3((pl.lw.anchors + 15) / 16, 2), dim3(1024), 0, h->stream, pl, scratch);
         }
         hipLaunchKernelGGL(k_fir_b, dim3(2), dim3(1024), lds_scan, h->stream, pl, scratch);
+    } else if (factored) {
+        hipLaunchKernelGGL(k_fir_apply_a, dim3(pl.lw.anchors), dim3(256), 0, h->stream, pl, (const double*)pd.A.packed,
+                           (const int2*)pd.A.band, (const long long*)pd.A.off, (const double*)raw, scratch);
+        hipLaunchKernelGGL(k_fir_apply_b, dim3((pl.bins + 255) / 256), dim3(256), 0, h->stream, pl, (const double*)pd.B.packed,
+                           (const int2*)pd.B.band, (const long long*)pd.B.off, (const double*)raw, scratch);
     } else {
         hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
                            (const int2*)pd.band, (const double*)raw, scratch);
@@ -635,14 +741,16 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     // transform cost 10), the split transform from 8192 taps on (13 us against 47 at 16384;
     // profiles/r03_x_tap_synthesis.txt).  MGX_TAPS_BY_COSINE_SUM=1 forces the sum: the A/B switch of that profile.
     if (pl.fft >= TAP_TRANSFORM_FROM && !std::getenv("MGX_TAPS_BY_COSINE_SUM")) {
-        const int m = pl.fft / 2 / TAP_SPLIT;
+        // (65536 taps: sixteen sub-transforms of 2048 points -- the longest one instantiated)
+        const int split = pl.fft > 32768 ? 2 * TAP_SPLIT : TAP_SPLIT;
+        const int m = pl.fft / 2 / split;
         const size_t sub_at = (2 * per + 2 * (size_t)pl.bins + 1) & ~(size_t)1;      // 16-byte aligned
         double2* sub = reinterpret_cast<double2*>(scratch + sub_at);
         const size_t lds_sub = fir_taps_sub_lds_bytes(m);
         switch (m) {
 #define MGX_TAPS_SUB(L)                                                                                                \
     case 1 << L:                                                                                                       \
-        hipLaunchKernelGGL(k_fir_taps_sub<L>, dim3(TAP_SPLIT, 2), dim3(TapFft<L>::T), lds_sub, h->stream, pl,          \
+        hipLaunchKernelGGL(k_fir_taps_sub<L>, dim3(split, 2), dim3(TapFft<L>::T), lds_sub, h->stream, pl,              \
                            (const double*)scratch, sub);                                                               \
         break;
             MGX_TAPS_SUB(9) MGX_TAPS_SUB(10) MGX_TAPS_SUB(11)
@@ -650,7 +758,7 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
             default: return fail(MGX_ERR_UNSUPPORTED, "tap synthesis: transform length not instantiated");
         }
         hipLaunchKernelGGL(k_fir_taps_combine, dim3((pl.fft / 2 + 255) / 256, 2), dim3(256), 0, h->stream, pl,
-                           (const double2*)sub, TAP_SPLIT, (float*)h->taps.p);
+                           (const double2*)sub, split, (float*)h->taps.p);
     } else {
         const size_t lds_taps = ((size_t)pl.bins + 2048 + 2 * TAP_ROWS) * sizeof(double);
         MGX_TRY(allow_lds(k_fir_taps, lds_taps));

@@ -623,7 +623,9 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
         // variant spills (116 - 172 B: the kernel sits at 124 registers without it) and the spilling kernel ran 152 us;
         // at three workgroups per CU and 168 VGPRs it fits without scratch and changes nothing: 100 us with and
         // without it, against 92 us for four workgroups without.  Hiding the loads is worth exactly the fourth
-        // workgroup it costs.  profiles/r04_b_ab_variants.txt)
+        // workgroup it costs.  profiles/r04_b_ab_variants.txt.  Round 5: one word of each 128-byte line of the next
+        // segment asked for behind this segment's loads (one register, no scratch at 16384 points) so that the L2
+        // holds it -- 149 -> 173 us at 16384 points, 88 -> 126 us at 4096: profiles/r05_p_analysis_touch_next_segment.txt)
         typename AB::Raw raw;
         AB::fetch(tid, (long long)d * a.piece + (long long)s * F::N, a, raw);
         AB::phase_load(tid, raw, ps, th, lds);
@@ -719,6 +721,82 @@ __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) v
             AD::phase_loose_frames(tid, (long long)a.divisions * a.piece, a.n, false, a, th);
     }
     AD::phase_write_spectrum(tid, wg, a, th);
+    const double ss = block_sum<F::T>(th.sumsq, dscratch);
+    const float pk = block_max<F::T>(th.peak, fscratch);
+    if (tid == 0) {
+        a.wg_sumsq[wg] = ss;
+        a.wg_peak[wg] = pk;
+    }
+}
+
+// fft_size = 4 * Fft2<LOG2H>::N (analysis2_kernel.h, AnalysisQuad): the same grid layout and outputs, four transforms
+// per segment; the spectrum sums live in wg_spec from the start (every bin has one owning thread)
+template <int LOG2H>
+__global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) void k_analyze_quad(AnalysisArgs a0,
+                                                                                                  AnalysisArgs a1,
+                                                                                                  int nwg0) {
+    using AQ = AnalysisQuad<LOG2H>;
+    using F = Fft2<LOG2H>;
+    MGX_LDS;
+    float2* lds = reinterpret_cast<float2*>(mgx_smem);
+    float2* mid_table = lds + F::LDS_ELEMS;
+    double* dscratch = reinterpret_cast<double*>(mid_table + F::MID_TABLE);
+    float* fscratch = reinterpret_cast<float*>(dscratch + F::T / 64);   // (one slot per wave each)
+    const bool second = (int)blockIdx.x >= nwg0;                 // uniform
+    const AnalysisArgs& a = second ? a1 : a0;
+    const int tid = threadIdx.x, wg = second ? blockIdx.x - nwg0 : blockIdx.x;
+    const int d = wg / a.chunks_per_piece, ch = wg % a.chunks_per_piece;
+    typename AQ::Thread th;
+    AQ::init(th);
+    typename AQ::Persist ps;
+    AQ::AB::load_persist(tid, a.tw, mid_table, ps);
+    AQ::phase_clear(tid, wg, a);
+    __syncthreads();
+    int s0, s1;
+    AQ::AB::chunk_segments(a, ch, s0, s1);
+    auto transform = [&]() {
+        lds_barrier();
+        if (F::P >= 3) {
+            AQ::AB::phase_fwd_mid(opaque(tid), lds, mid_table);
+            pass_sync<F>();
+        }
+        if (F::P == 4) {
+            AQ::AB::phase_fwd_mid2(opaque(tid), lds, mid_table);
+            pass_sync<F>();
+        }
+        AQ::phase_row(opaque(tid), lds);
+        lds_barrier();
+    };
+    for (int s = s0; s < s1; ++s) {
+        const long long start = (long long)d * a.piece + (long long)s * 4 * F::N;
+        typename AQ::Pairs u;
+        AQ::template phase_load<false, 0>(opaque(tid), start, a, ps, th, lds);
+        transform();
+        AQ::phase_unmix(opaque(tid), u, lds);
+        AQ::phase_keep(opaque(tid), wg, a, u);
+        lds_barrier();
+        AQ::template phase_load<false, 1>(opaque(tid), start, a, ps, th, lds);
+        transform();
+        AQ::phase_unmix(opaque(tid), u, lds);
+        AQ::template phase_magnitudes<false>(opaque(tid), wg, a, u);
+        lds_barrier();
+        AQ::template phase_load<true, 0>(opaque(tid), start, a, ps, th, lds);
+        transform();
+        AQ::phase_unmix(opaque(tid), u, lds);
+        AQ::phase_keep(opaque(tid), wg, a, u);
+        lds_barrier();
+        AQ::template phase_load<true, 1>(opaque(tid), start, a, ps, th, lds);
+        transform();
+        AQ::phase_unmix(opaque(tid), u, lds);
+        AQ::template phase_magnitudes<true>(opaque(tid), wg, a, u);
+        lds_barrier();
+    }
+    if (ch == a.chunks_per_piece - 1) {
+        AQ::phase_loose_frames(tid, (long long)d * a.piece + (long long)a.segs_per_piece * 4 * F::N,
+                               (long long)(d + 1) * a.piece, true, a, th);
+        if (d == a.divisions - 1)
+            AQ::phase_loose_frames(tid, (long long)a.divisions * a.piece, a.n, false, a, th);
+    }
     const double ss = block_sum<F::T>(th.sumsq, dscratch);
     const float pk = block_max<F::T>(th.peak, fscratch);
     if (tid == 0) {
@@ -1080,6 +1158,10 @@ struct CurveTrack {
 __host__ __device__ inline size_t match_curve_lds_bytes(int max_div, int rows) {
     return ((size_t)1024 + 16 + 2 * (size_t)max_div + rows) * 8 + (2 * (size_t)max_div + rows + 4) * 4;
 }
+// TILE bins x ROWL = 1024 / TILE row lanes per workgroup.  32 x 32 unless 33 x 31 (one idle thread) saves a round of
+// workgroups: the spectrum has 2^k + 1 bins, so tiles of 32 leave ONE bin for a last tile per channel, and at
+// fft_size 16384 those two workgroups are numbers 513 and 514 on a chip that holds 256 at a time (29 -> 20 us).
+template <int TILE>
 __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack tr, int bins, int fft, int max_div,
                                                       double threshold, double eps, double curve_floor,
                                                       double* raw /* [2][bins] */, double* c0_out,
@@ -1095,17 +1177,18 @@ __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack 
     float* pk = reinterpret_cast<float*>(loud + 2 * max_div);   // [rows]
     const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // The spectra of the first 512 workgroup rows of EACH track are asked for before anything else: what is summed
+    // The spectra of the first 16 ROWL workgroup rows of EACH track are asked for before anything else: what is summed
     // depends on the level decisions below, what is loaded does not, so the decisions (two LDS round trips and a
     // wave's worth of arithmetic) run while the loads are in flight.  Buffer views: ONE lane offset per track, the row
     // step is a scalar displacement, and rows past the end of a track read as zero through the range check.
-    const int b = threadIdx.x & 31, row_lane = threadIdx.x >> 5, plane = blockIdx.y;
-    const int bin = blockIdx.x * 32 + b;
+    constexpr int ROWL = 1024 / TILE;
+    const int b = threadIdx.x % TILE, row_lane = threadIdx.x / TILE, plane = blockIdx.y;      // (row_lane == ROWL: the idle thread)
+    const int bin = row_lane < ROWL ? blockIdx.x * TILE + b : bins;
     const MemView vt = mem_view(tt.wg_spec, (long long)tt.nwg * 2 * bins * 4);
     const MemView vr = mem_view(tr.wg_spec, (long long)tr.nwg * 2 * bins * 4);
     // (a bin past the end reads from past the end of the view: zeros)
     const unsigned lane_off = bin < bins ? (unsigned)((((size_t)row_lane * 2 + plane) * bins + bin) * 4) : 0xfffffff0u;
-    const unsigned row_step = (unsigned)((size_t)32 * 2 * bins * 4);
+    const unsigned row_step = (unsigned)((size_t)ROWL * 2 * bins * 4);
     double ssv[2] = {0.0, 0.0};
     float pkv[2] = {0.f, 0.f};
 #pragma unroll
@@ -1203,11 +1286,11 @@ __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack 
         const unsigned magic[2] = {(unsigned)((0x100000000ull + tt.lv.chunks_per_piece - 1) / tt.lv.chunks_per_piece),
                                    (unsigned)((0x100000000ull + tr.lv.chunks_per_piece - 1) / tr.lv.chunks_per_piece)};
 #pragma unroll 1
-        for (int w0 = 0; w0 < longest; w0 += 32 * 16) {
+        for (int w0 = 0; w0 < longest; w0 += ROWL * 16) {
             if (opaque(w0) > 0) {                               // (the first batch is in flight since the top; opaque: one copy of the sums)
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    const unsigned disp = (unsigned)(w0 / 32 + u) * row_step;
+                    const unsigned disp = (unsigned)(w0 / ROWL + u) * row_step;
                     v0[0][u] = ld_f1(vt, lane_off, disp);
                     v0[1][u] = ld_f1(vr, lane_off, disp);
                 }
@@ -1217,7 +1300,7 @@ __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack 
                 const CurveTrack& t = k == 0 ? tt : tr;
 #pragma unroll
                 for (int u = 0; u < 16; ++u) {
-                    const int w = w0 + row_lane + 32 * u;
+                    const int w = w0 + row_lane + ROWL * u;
                     const int piece = t.lv.chunks_per_piece == 1 ? w : (int)__umulhi((unsigned)w, magic[k]);
                     const bool on = w < t.nwg && loud[k * max_div + (w < t.nwg ? piece : 0)] != 0;
                     sacc[k] += on ? (double)v0[k][u] : 0.0;
@@ -1234,7 +1317,7 @@ __global__ __launch_bounds__(1024) void k_match_curve(CurveTrack tt, CurveTrack 
         double total = 0.0;
         if (row_lane == 0) {
 #pragma unroll 8
-            for (int l = 0; l < 32; ++l) total += acc[l * 32 + b];
+            for (int l = 0; l < ROWL; ++l) total += acc[l * TILE + b];
         }
         // mean over loud pieces and segments of |rfft|/F of the normalised track (match_frequencies.py:42)
         level[k] = total / (scal[k * 4 + 2] * (double)t.segs_per_piece * (double)fft * scal[k * 4 + 0]);
@@ -1307,6 +1390,108 @@ __global__ __launch_bounds__(256) void k_fir_matvec(FirPlanView pl, const double
         fir_scratch(scratch, pl, 0).smooth[row] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
         fir_scratch(scratch, pl, 1).smooth[row] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     }
+}
+
+// ---- the same chain in TWO factors, for fft_size >= 16384 ----------------------------------------------
+// raw -> smooth passes through the LOWESS fits at the anchors (match_frequencies.py:62-64 with lowess_delta: only
+// ~1/delta = 1000 points of the log grid get a regression, the rest is interpolated between them), so
+//     smooth = B * (A * raw),   A = [anchors x bins]: spline onto the log grid + the anchors' regressions,
+//                               B = [bins x anchors]: fill between anchors + spline back + pinned bins.
+// Both are banded like M (A's row of anchor a covers the linear bins under its 3.75 % neighbourhood, B's row of bin
+// i the handful of anchors around it) and stored PACKED, row after row, only the window k_fir_band found:
+// 3.4 MB at fft_size 16384 where M is 537 MB (of which the product read 83 MB per pair, 28 us), a few MB more at
+// 65536 where M would be 8.6 GB.  Built like M, by pushing unit vectors through the chain's own kernels.
+// unit anchor `col0 + plane` as the fits, nothing on the raw side (phase_pin reads raw[1])
+__global__ __launch_bounds__(256) void k_fir_unit_fit(FirPlanView pl, double* scratch, int col0) {
+    const int plane = blockIdx.x;
+    FirScratch s = fir_scratch(scratch, pl, plane);
+    for (int a = threadIdx.x; a < pl.lw.anchors; a += 256) s.fit[a] = a == col0 + plane ? 1.0 : 0.0;
+    if (threadIdx.x == 0) s.raw[1] = 0.0;
+}
+// dense[i][col0 + c] = (fits | smooth curve) of plane c at i; grid = (ceil(ncols / 256), rows)
+__global__ __launch_bounds__(256) void k_fir_gather_plane(FirPlanView pl, double* scratch, int col0, int ncols, int stride,
+                                                          int from_fit, double* dense) {
+    const int c = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (c >= ncols) return;
+    const FirScratch s = fir_scratch(scratch, pl, c);
+    dense[(size_t)i * stride + col0 + c] = from_fit ? s.fit[i] : s.smooth[i];
+}
+// packed[off[row] + j - band[row].x] = dense[row][j] over the row's window; grid = rows
+__global__ __launch_bounds__(256) void k_fir_pack(const double* dense, int stride, const int2* band, const long long* off,
+                                                  double* packed) {
+    const int row = blockIdx.x;
+    const int first = band[row].x, last = band[row].y;
+    const double* src = dense + (size_t)row * stride;
+    double* dst = packed + off[row] - first;
+    for (int j = first + threadIdx.x; j < last; j += 256) dst[j] = src[j];
+}
+// fit[plane][a] = sum_j A[a][j] raw[plane][j]: one 256-thread workgroup per anchor, both channels per pass, the whole
+// window in flight at once (the widest is 0.31 * bins + 62 columns: eleven loads per thread at fft_size 16384);
+// grid = anchors.  (One WAVE per anchor, the first version, walked the wide windows in five dependent batches:
+// 20 us for the two factors against the dense product's 28, profiles/r05_p_fir_factored_first_version.txt.)
+__global__ __launch_bounds__(256) void k_fir_apply_a(FirPlanView pl, const double* A, const int2* band, const long long* off,
+                                                     const double* raw, double* scratch) {
+    __shared__ double red[2][4];
+    const int a = blockIdx.x, tid = threadIdx.x;
+    const int first = band[a].x, last = band[a].y;
+    const double* m = A + off[a] - first;
+    const double* r0 = raw;
+    const double* r1 = raw + pl.bins;
+    double a0 = 0.0, a1 = 0.0;
+    for (int j0 = first + tid; j0 < last; j0 += 256 * 12) {
+        double v[12], x0[12], x1[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int j = j0 + 256 * u;
+            const bool in = j < last;
+            v[u] = in ? m[j] : 0.0;
+            x0[u] = in ? r0[j] : 0.0;
+            x1[u] = in ? r1[j] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            a0 = fma(v[u], x0[u], a0);
+            a1 = fma(v[u], x1[u], a1);
+        }
+    }
+    a0 = wave_sum(a0);
+    a1 = wave_sum(a1);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = a0; red[1][tid >> 6] = a1; }
+    __syncthreads();
+    if (tid == 0) {
+        fir_scratch(scratch, pl, 0).fit[a] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        fir_scratch(scratch, pl, 1).fit[a] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
+// smooth[plane][i] = sum_a B[i][a] fit[plane][a] (a handful of terms: one thread per bin), bins 0 and 1 pinned
+// (match_frequencies.py:72-73); grid = ceil(bins / 256)
+__global__ __launch_bounds__(256) void k_fir_apply_b(FirPlanView pl, const double* B, const int2* band, const long long* off,
+                                                     const double* raw, double* scratch) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= pl.bins) return;
+    const FirScratch s0 = fir_scratch(scratch, pl, 0), s1 = fir_scratch(scratch, pl, 1);
+    const int first = band[i].x, last = band[i].y;
+    const double* m = B + off[i] - first;
+    double a0 = 0.0, a1 = 0.0;
+    for (int a = first; a < last; a += 8) {                      // (windows are 4 - 10 anchors wide: one batch, two at most)
+        double v[8], f0[8], f1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool in = a + u < last;
+            v[u] = in ? m[a + u] : 0.0;
+            f0[u] = in ? s0.fit[a + u] : 0.0;
+            f1[u] = in ? s1.fit[a + u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a0 = fma(v[u], f0[u], a0);
+            a1 = fma(v[u], f1[u], a1);
+        }
+    }
+    if (i == 0) a0 = a1 = 0.0;
+    if (i == 1) { a0 = raw[1]; a1 = raw[pl.bins + 1]; }
+    s0.smooth[i] = a0;
+    s1.smooth[i] = a1;
 }
 
 // fft_size 8 .. 32 (small_fft_kernels.h): taps[i] = hann[i] * irfft(smooth)[(i + F/2) mod F] by the plain cosine sum (fir_plan.h, phase_taps); grid = 2

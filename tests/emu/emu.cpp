@@ -481,6 +481,120 @@ static int analyze_double_impl(const float* x, long long n, const mgx_config* cf
     return 0;
 }
 
+// fft_size = 4 * Fft2<LOG2H>::N: k_analyze_quad of mgx_kernels.h, phase by phase
+template <int LOG2H>
+static int analyze_quad_impl(const float* x, long long n, const mgx_config* cfg, int is_reference, double* peak,
+                             double* amplitude_c, double* match_rms, int* divisions_out, long long* piece_out,
+                             double* piece_rms, int* loud, double* avg_mid, double* avg_side) {
+    using AQ = AnalysisQuad<LOG2H>;
+    using F = typename AQ::F;
+    const int fft = 4 * F::N, half = 2 * F::N;
+    const std::vector<float2> tw = twiddles(F::N);
+    int divisions;
+    long long piece;
+    piece_geometry(n, cfg->max_piece_size, divisions, piece);
+    AnalysisArgs a;
+    a.x = reinterpret_cast<const float2*>(x);
+    a.n = n;
+    a.fft = fft;
+    a.piece = piece;
+    a.divisions = divisions;
+    a.segs_per_piece = (int)(piece / fft);
+    if (a.segs_per_piece < 1) return -5;
+    a.chunks_per_piece = std::max(1, (a.segs_per_piece + 4) / 5);
+    const int nwg = divisions * a.chunks_per_piece;
+    std::vector<double> wg_sumsq(nwg);
+    std::vector<float> wg_peak(nwg), wg_spec((size_t)nwg * 2 * (half + 1), -1.f);      // (the kernel clears its rows)
+    std::vector<float2> wg_pack((size_t)nwg * (F::N + 1));
+    a.wg_sumsq = wg_sumsq.data();
+    a.wg_peak = wg_peak.data();
+    a.wg_spec = wg_spec.data();
+    a.wg_pack = wg_pack.data();
+    a.tw = tw.data();
+    std::vector<float2> lds(F::LDS_ELEMS);
+    std::vector<typename AQ::Thread> th(F::T);
+    std::vector<typename AQ::Pairs> pairs(F::T);
+    std::vector<typename AQ::Persist> ps(F::T);
+    std::vector<float2> mid_table(F::MID_TABLE + 1);
+    FOR_THREADS(F::T) AQ::AB::load_persist(tid, a.tw, mid_table.data(), ps[tid]);
+    auto transform = [&]() {
+        local_phases<F>(mid_phases<F>(false, lds.data(), mid_table.data()) +
+                        std::vector<Phase>{[&](int tid) { AQ::phase_row(tid, lds.data()); }});
+        FOR_THREADS(F::T) AQ::phase_unmix(tid, pairs[tid], lds.data());
+    };
+    for (int wg = 0; wg < nwg; ++wg) {
+        const int d = wg / a.chunks_per_piece, ch = wg % a.chunks_per_piece;
+        FOR_THREADS(F::T) AQ::init(th[tid]);
+        FOR_THREADS(F::T) AQ::phase_clear(tid, wg, a);
+        int s0, s1;
+        AQ::AB::chunk_segments(a, ch, s0, s1);
+        for (int s = s0; s < s1; ++s) {
+            const long long start = d * piece + (long long)s * fft;
+            FOR_THREADS(F::T) AQ::template phase_load<false, 0>(tid, start, a, ps[tid], th[tid], lds.data());
+            transform();
+            FOR_THREADS(F::T) AQ::phase_keep(tid, wg, a, pairs[tid]);
+            FOR_THREADS(F::T) AQ::template phase_load<false, 1>(tid, start, a, ps[tid], th[tid], lds.data());
+            transform();
+            FOR_THREADS(F::T) AQ::template phase_magnitudes<false>(tid, wg, a, pairs[tid]);
+            FOR_THREADS(F::T) AQ::template phase_load<true, 0>(tid, start, a, ps[tid], th[tid], lds.data());
+            transform();
+            FOR_THREADS(F::T) AQ::phase_keep(tid, wg, a, pairs[tid]);
+            FOR_THREADS(F::T) AQ::template phase_load<true, 1>(tid, start, a, ps[tid], th[tid], lds.data());
+            transform();
+            FOR_THREADS(F::T) AQ::template phase_magnitudes<true>(tid, wg, a, pairs[tid]);
+        }
+        if (ch == a.chunks_per_piece - 1) {
+            FOR_THREADS(F::T)
+            AQ::phase_loose_frames(tid, d * piece + (long long)a.segs_per_piece * fft, (d + 1) * piece, true, a, th[tid]);
+            if (d == divisions - 1) {
+                FOR_THREADS(F::T) AQ::phase_loose_frames(tid, (long long)divisions * piece, n, false, a, th[tid]);
+            }
+        }
+        double ss = 0.0;
+        float pk = 0.f;
+        FOR_THREADS(F::T) { ss += th[tid].sumsq; pk = std::fmax(pk, th[tid].peak); }
+        wg_sumsq[wg] = ss;
+        wg_peak[wg] = pk;
+    }
+    std::vector<double> rms(divisions);
+    std::vector<int> ld(divisions);
+    TrackStats st;
+    finish_levels(wg_sumsq.data(), wg_peak.data(), a.chunks_per_piece, divisions, piece, is_reference != 0,
+                  cfg->threshold, cfg->min_value, rms.data(), ld.data(), st);
+    if (peak) *peak = st.peak;
+    if (amplitude_c) *amplitude_c = st.amplitude_c;
+    if (match_rms) *match_rms = st.match_rms;
+    if (divisions_out) *divisions_out = divisions;
+    if (piece_out) *piece_out = piece;
+    for (int d = 0; d < divisions; ++d) {
+        if (piece_rms) piece_rms[d] = rms[d];
+        if (loud) loud[d] = ld[d];
+    }
+    const double scale = 1.0 / ((double)st.loud_count * a.segs_per_piece * (double)fft * st.amplitude_c);
+    for (int k = 0; k <= half; ++k) {
+        double sm = 0.0, ssd = 0.0;
+        for (int wg = 0; wg < nwg; ++wg) {
+            if (!ld[wg / a.chunks_per_piece]) continue;
+            sm += wg_spec[(size_t)wg * 2 * (half + 1) + k];
+            ssd += wg_spec[(size_t)wg * 2 * (half + 1) + (half + 1) + k];
+        }
+        if (avg_mid) avg_mid[k] = sm * scale;
+        if (avg_side) avg_side[k] = ssd * scale;
+    }
+    return 0;
+}
+// the four-transform form on a transform of 2^log2h points (fft_size = 4 * 2^log2h): small sizes test it quickly
+extern "C" int emu_analyze_quad(const float* x, long long n, const mgx_config* cfg, int is_reference, double* peak,
+                                double* amplitude_c, double* match_rms, int* divisions, long long* piece,
+                                double* piece_rms, int* loud, double* avg_mid, double* avg_side, int log2h) {
+    switch (log2h) {
+#define CASE(L) case L: return analyze_quad_impl<L>(x, n, cfg, is_reference, peak, amplitude_c, match_rms, divisions, piece, piece_rms, loud, avg_mid, avg_side);
+        CASE(8) CASE(10) CASE(12) CASE(14)
+#undef CASE
+        default: return -4;
+    }
+}
+
 extern "C" int emu_analyze(const float* x, long long n, const mgx_config* cfg, int is_reference, double* peak,
                            double* amplitude_c, double* match_rms, int* divisions, long long* piece,
                            double* piece_rms, int* loud, double* avg_mid, double* avg_side) {
@@ -490,6 +604,7 @@ extern "C" int emu_analyze(const float* x, long long n, const mgx_config* cfg, i
         CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13) CASE(14)
 #undef CASE
         case 15: return analyze_double_impl<14>(x, n, cfg, is_reference, peak, amplitude_c, match_rms, divisions, piece, piece_rms, loud, avg_mid, avg_side);
+        case 16: return analyze_quad_impl<14>(x, n, cfg, is_reference, peak, amplitude_c, match_rms, divisions, piece, piece_rms, loud, avg_mid, avg_side);
         // (the emulation also runs the double form on small transforms, to test it quickly: fft_size = -2^l)
         default: return -4;
     }

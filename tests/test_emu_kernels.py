@@ -265,6 +265,50 @@ def test_analysis_with_a_segment_of_two_transforms(emu):
             assert np.abs(mine - want).max() <= 2e-6 * want.max()
 
 
+@pytest.mark.parametrize("log2h,seconds,piece", [(8, 0.5, 0.06), (10, 1.5, 0.25), (14, 9.0, 2.6)])
+def test_analysis_with_a_segment_of_four_transforms(emu, log2h, seconds, piece):
+    """fft_size = 4 N' (65536 with the 16384-point transform; AnalysisQuad): the real-FFT split applied twice, the even
+    samples' spectrum through a scratch row, magnitudes added to the spectrum rows in place.  Levels and the averaged
+    |rfft| of mid and side (match_frequencies.py:30-42) against the oracle, target and normalised reference; the small
+    transforms run the same code in a fraction of the time."""
+    import matchering_amd as mg
+    from matchering_amd.synth import make_pair
+
+    fft = 4 << log2h
+    t, r = make_pair(seconds, 44100, pair=21, reference_seconds=seconds * 0.8, reference_gain=0.6)
+    cfg = mg.Config(fft_size=fft, max_piece_size=piece)
+    ocfg = mo.params(fft_size=fft, max_piece_size=piece)
+    native = cfg.to_native()
+    for x32, is_ref in ((t, 0), (r, 1)):
+        n = x32.shape[0]
+        max_div = int(n / cfg.max_piece_size) + 1
+        half = fft // 2
+        peak, amp, match = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        div, piece_frames = ctypes.c_int(), ctypes.c_longlong()
+        rms = np.zeros(max_div)
+        loud = np.zeros(max_div, dtype=np.int32)
+        avg_mid, avg_side = np.zeros(half + 1), np.zeros(half + 1)
+        rc = emu.emu_analyze_quad(_fp(x32), ctypes.c_longlong(n), ctypes.byref(native), is_ref, ctypes.byref(peak),
+                                  ctypes.byref(amp), ctypes.byref(match), ctypes.byref(div), ctypes.byref(piece_frames),
+                                  _dp(rms), loud.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _dp(avg_mid),
+                                  _dp(avg_side), ctypes.c_int(log2h))
+        assert rc == 0
+        x64 = x32.astype(np.float64)
+        c = 1.0
+        if is_ref:
+            x64, c = mo.peak_normalize(x64, ocfg.threshold, ocfg.min_value, False)
+        a = mo.analyze(x64, ocfg)
+        assert div.value == a.divisions and piece_frames.value == a.piece
+        assert abs(amp.value - c) <= 1e-7
+        assert abs(peak.value - np.abs(x32).max()) <= 1e-7
+        assert np.array_equal(np.flatnonzero(loud[: a.divisions]), a.loud_idx)
+        assert np.abs(rms[: a.divisions] / a.rmses - 1).max() <= 1e-6
+        assert abs(match.value / a.match_rms - 1) <= 1e-6
+        for mine, rows in ((avg_mid, a.mid_loud), (avg_side, a.side_loud)):
+            want = mo.average_spectrum(rows, ocfg.fft_size)
+            assert np.abs(mine - want).max() <= 2e-6 * want.max()
+
+
 @pytest.mark.parametrize("name", ["hot_lowrate", "custom_limiter"])
 def test_limiter_phases(emu, name):
     t, r = build_inputs(CASES[name])

@@ -159,7 +159,7 @@ def test_convolution_stage(taps):
     assert abs(peak - np.abs(y).max()) <= 1e-6
 
 
-@pytest.mark.parametrize("taps", [16384, 32768])
+@pytest.mark.parametrize("taps", [16384, 32768, 65536])
 def test_partitioned_convolution_stage(taps):
     """Uniformly partitioned overlap-save: FIRs longer than half an LDS block (a 16 k-tap filter on
     8192-frame blocks = 4 partitions; BASELINE config #5)."""
@@ -238,11 +238,37 @@ def test_master_long_fir_96k():
         assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
 
 
-def test_master_fft_size_32768():
-    """fft_size 32768, the largest supported: analysis segments of two 16384-point transforms
-    (k_analyze_double), the FIR designed on the curve itself (the raw -> smooth operator would be 2 GB), 32 k
-    taps convolved in eight partitions.  192 kHz, where such a size is at home, full pipeline against the
-    oracle; then fft_size 65536 must be refused."""
+def _master_with_taps(t, r, cfg):
+    """stages.main's three outputs through the device API, plus the FIR pair the call designed (mgx_last_fir)."""
+    import ctypes
+
+    from matchering_amd._native import check, library
+    from matchering_amd.device import default_device
+
+    dev = default_device()
+    with dev.lock:
+        td, rd = dev.upload(t), dev.upload(r)
+        outs = [dev.alloc(t.shape[0] * 8) for _ in range(3)]
+        try:
+            dev.master(td, t.shape[0], rd, r.shape[0], cfg.to_native(), *outs)
+            taps_dev, taps = ctypes.c_void_p(), ctypes.c_int32()
+            check(library().mgx_last_fir(dev.handle, ctypes.byref(taps_dev), ctypes.byref(taps)))
+            assert taps.value == cfg.fft_size
+            fir = dev.download(int(taps_dev.value), (2, taps.value))
+            res = [np.array(dev.download(o, (t.shape[0], 2))) for o in outs]
+            fir = np.array(fir)
+        finally:
+            for b in (td, rd, *outs):
+                b.release()
+    return res, fir
+
+
+@pytest.mark.parametrize("fft", [32768, 65536])
+def test_master_fft_size_32768_and_65536(fft):
+    """The two sizes above what one transform in a CU's LDS holds: analysis segments of two / four 16384-point
+    transforms (k_analyze_double, k_analyze_quad), the raw -> smooth operator in its two packed factors, the taps by
+    8 / 16 sub-transforms, 32 k / 64 k taps convolved in four / eight partitions.  192 kHz, where such sizes are at
+    home: the FIR pair and the full pipeline against the oracle; fft_size 131072 must be refused."""
     import matchering_amd as mg
     from matchering_amd import stages
     from matchering_amd._native import MgxError
@@ -250,15 +276,38 @@ def test_master_fft_size_32768():
 
     sr = 192000
     t, r = make_pair(2.0, sr, pair=14, reference_seconds=1.7)
-    kw = dict(internal_sample_rate=sr, fft_size=32768, max_piece_size=0.6)
+    kw = dict(internal_sample_rate=sr, fft_size=fft, max_piece_size=0.6)
     res, res_nl, res_nln = stages.main(t, r, mg.Config(**kw), need_default=True, need_no_limiter=True,
                                        need_no_limiter_normalized=True)
-    want = mo.master(t, r, mo.params(**kw), True, True, True)
+    tr = {}
+    want = mo.master(t, r, mo.params(**kw), True, True, True, trace=tr)
     for mine, ref in zip((res, res_nl, res_nln), want):
         assert rms_error(mine, ref) <= RMS_TOL
         assert np.abs(mine - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    _, fir = _master_with_taps(t, r, mg.Config(**kw))
+    for mine, ref in ((fir[0], tr["fir_mid"]), (fir[1], tr["fir_side"])):
+        assert np.abs(mine - ref).max() <= 2e-6 * np.abs(ref).max()
     with pytest.raises(MgxError, match="fft_size"):
-        stages.main(t, r, mg.Config(internal_sample_rate=sr, fft_size=65536, max_piece_size=0.6))
+        stages.main(t, r, mg.Config(internal_sample_rate=sr, fft_size=131072, max_piece_size=0.9))
+
+
+@pytest.mark.parametrize("fft", [16384, 32768])
+def test_factored_fir_operator_equals_the_round_4_paths(fft, monkeypatch):
+    """fft_size >= 16384: raw -> smooth as B (A raw) through the anchors' LOWESS fits (two packed banded factors, a
+    few MB) against what it replaces -- the dense 537 MB operator at 16384, the chain run on the curve itself at
+    32768 (MGX_FIR_ROUND4=1).  The same linear map summed in another order: taps equal to float32 rounding."""
+    import matchering_amd as mg
+    from matchering_amd.synth import make_pair
+
+    sr = 96000
+    t, r = make_pair(3.0, sr, pair=9, reference_seconds=2.6)
+    cfg = mg.Config(internal_sample_rate=sr, fft_size=fft, max_piece_size=1.1)
+    res, fir = _master_with_taps(t, r, cfg)
+    monkeypatch.setenv("MGX_FIR_ROUND4", "1")
+    res4, fir4 = _master_with_taps(t, r, cfg)
+    assert np.abs(fir - fir4).max() <= 2e-7 * np.abs(fir4).max()
+    for a, b in zip(res, res4):
+        assert np.abs(a - b).max() <= 2e-6
 
 
 def test_convolution_identity_and_linearity():
@@ -408,7 +457,7 @@ def test_fails_loudly_on_unsupported():
 
     t, r = build_inputs(CASES["hot_lowrate"])
     with pytest.raises(MgxError):
-        stages.main(t, r, mg.Config(internal_sample_rate=8000, fft_size=65536, max_piece_size=9.0,
+        stages.main(t, r, mg.Config(internal_sample_rate=8000, fft_size=131072, max_piece_size=17.0,
                                     max_length=600))
     # fft_size 2 and 4 pass defaults.py:110-112 and then fail inside the reference (tests/test_host_vs_reference.py)
     with pytest.raises(MgxError, match="fft_size below 8"):
