@@ -43,7 +43,7 @@ struct AnalysisArgs {
     float* wg_peak;         // max(|L|,|R|) over the frames this workgroup owns
     float* wg_spec;         // [wg][2][F/2+1] sum over segments of |M_k|, |S_k| (unscaled)
     const float2* tw;
-    float2* wg_pack;        // fft_size 65536 only (AnalysisQuad): [wg][F/4+1] spectrum of a segment's even samples
+    float2* wg_pack;        // fft_size 65536 only (AnalysisQuad): [wg][AnalysisQuad::SCRATCH_FLOAT2] scratch
 };
 
 template <int LOG2N>
@@ -351,10 +351,12 @@ struct AnalysisDouble {
 // values now, not magnitudes, and
 //     R_k = E_k + w^k O_k,   R_{2N'-k} = conj(E_k - w^k O_k),   w = exp(-j pi / (2 N')),   k = 0 .. N'
 // (bin N' comes out of k = N' twice: counted once).  Passes of a segment: mid even, mid odd, side even, side odd.
-// The even pass leaves E_k in the workgroup's slice of global scratch (a.wg_pack, N' + 1 values: a thread reads back
-// what it wrote itself, no barrier involved); the odd pass adds |E_k +- w^k O_k| to the workgroup's spectrum rows
-// in wg_spec directly -- 4 bins per pair {k, N'-k} and channel are 64 accumulators a thread of the 1024 has no
-// registers for, and every bin has exactly one owner.  Frames are read four times (three of them from the L2).
+// 4 bins per pair {k, N'-k} and channel are 68 accumulators, and the even pass's 17 complex values have to outlive
+// the odd pass's transform: a thread of the 1024 has registers for neither, so both live in the workgroup's slice of
+// global scratch (a.wg_pack), laid out [slot][thread] -- every access is a wave's 64 consecutive words, a thread
+// only ever reads back what it wrote itself (no barrier involved), and the slice of the one workgroup a CU runs
+// stays in the L2.  The spectrum rows in wg_spec are written once, at the end, like the other analysis kernels'.
+// Frames are read four times (three of them from the L2).
 template <int LOG2H>
 struct AnalysisQuad {
     using AB = Analysis2Block<LOG2H>;
@@ -366,7 +368,13 @@ struct AnalysisQuad {
     static constexpr int RL = F::RL;
     static constexpr int S0 = F::S(0);
     static constexpr int CNT0 = F::CNT(0);
+    static constexpr int HALF = RL / 2;
     using Persist = typename AB::Persist;
+    // a workgroup's scratch, in float2 units: E of the even pass [2 HALF + 1][T], then the accumulators as floats
+    // [2 channels][4 HALF + 2][T]
+    static constexpr int PACK_SLOTS = 2 * HALF + 1;
+    static constexpr int ACC_SLOTS = 4 * HALF + 2;                      // per channel
+    static constexpr size_t SCRATCH_FLOAT2 = (size_t)(PACK_SLOTS + ACC_SLOTS) * T;
 
     struct Thread {
         double sumsq;
@@ -376,25 +384,15 @@ struct AnalysisQuad {
         t.sumsq = 0.0;
         t.peak = 0.f;
     }
-    static MGX_HD float* spectrum_row(const AnalysisArgs& a, int wg, bool side) {
-        return a.wg_spec + ((size_t)wg * 2 + (side ? 1 : 0)) * (2 * N + 1);
+    static MGX_HD float2* pack_of(const AnalysisArgs& a, int wg) { return a.wg_pack + (size_t)wg * SCRATCH_FLOAT2; }
+    static MGX_HD float* acc_of(const AnalysisArgs& a, int wg, bool side) {
+        return reinterpret_cast<float*>(pack_of(a, wg) + (size_t)PACK_SLOTS * T) + (side ? (size_t)ACC_SLOTS * T : 0);
     }
-    // the bins a thread owns start from zero
+    // the accumulators start from zero
     static MGX_HD void phase_clear(int tid, int wg, const AnalysisArgs& a) {
-        if (!F::has_row(tid)) return;
-        const int k0 = F::frequency_at(tid * RL);
-        for (int c = 0; c < 2; ++c) {
-            float* row = spectrum_row(a, wg, c != 0);
-            MGX_UNROLL
-            for (int q = 0; q < RL / 2; ++q) {
-                const int k = k0 + q * F::L;
-                row[k] = 0.f;
-                row[N - k] = 0.f;
-                row[N + k] = 0.f;
-                row[2 * N - k] = 0.f;
-            }
-            if (tid == 0) { row[N / 2] = 0.f; row[3 * N / 2] = 0.f; }
-        }
+        float* acc = acc_of(a, wg, false);
+        MGX_UNROLL
+        for (int s = 0; s < 2 * ACC_SLOTS; ++s) acc[(size_t)s * T + tid] = 0.f;
     }
     // frames 4m + PARITY and 4m + 2 + PARITY of the segment -> packed mid (or side) samples, pass 0 -> LDS; the mid
     // passes also gather the level statistics (both parities together see every frame once)
@@ -436,20 +434,20 @@ struct AnalysisQuad {
     // the spectrum U (of the 2 N' even or odd samples) at the thread's pairs: lo[q] = U_k, hi[q] = U_{N'-k} for the bin
     // k of (row, q < RL/2); on thread 0 lo[0] = U_0, hi[0] = U_{N'} (both real) and half = U_{N'/2}
     struct Pairs {
-        float2 lo[RL / 2], hi[RL / 2];
+        float2 lo[HALF], hi[HALF];
         float2 half;
     };
     static MGX_HD void phase_unmix(int tid, Pairs& u, const float2* lds) {
         if (!F::has_row(tid)) return;
-        float2 z[RL / 2 + 2], m[RL / 2];
-        F::template load_row_part<0, RL / 2 + 2>(z, tid, lds);
-        F::template load_row_part<RL / 2, RL / 2>(m, F::mirror_row(tid), lds);
+        float2 z[HALF + 2], m[HALF];
+        F::template load_row_part<0, HALF + 2>(z, tid, lds);
+        F::template load_row_part<HALF, HALF>(m, F::mirror_row(tid), lds);
         const bool r0 = tid == 0;
         const int k0 = F::frequency_at(tid * RL);
         MGX_UNROLL
-        for (int q = 0; q < RL / 2; ++q) {
-            const float2 a = m[RL / 2 - 1 - q];
-            const float2 b = q == 0 ? z[0] : m[RL / 2 - q];
+        for (int q = 0; q < HALF; ++q) {
+            const float2 a = m[HALF - 1 - q];
+            const float2 b = q == 0 ? z[0] : m[HALF - q];
             const float2 zm = make_float2(r0 ? b.x : a.x, r0 ? b.y : a.y);
             // 2A = Z + conj Zm, 2B = (Z - conj Zm) / j;  U_k = A + v^k B, U_{N'-k} = conj(A - v^k B), v = exp(-j pi / N')
             const float ax = z[q].x + zm.x, ay = z[q].y - zm.y;
@@ -462,44 +460,43 @@ struct AnalysisQuad {
             u.hi[q] = make_float2(0.5f * (ax - wx), -0.5f * (ay - wy));
         }
         // k = N'/2 mirrors into itself: A = Re Y, B = Im Y, v^k = -j: U = A - j B = conj(Y)
-        u.half = make_float2(z[RL / 2].x, -z[RL / 2].y);
+        u.half = make_float2(z[HALF].x, -z[HALF].y);
     }
     // even pass: E to the workgroup's scratch
     static MGX_HD void phase_keep(int tid, int wg, const AnalysisArgs& a, const Pairs& e) {
         if (!F::has_row(tid)) return;
-        float2* pack = a.wg_pack + (size_t)wg * (N + 1);
-        const int k0 = F::frequency_at(tid * RL);
+        float2* pack = pack_of(a, wg) + tid;
         MGX_UNROLL
-        for (int q = 0; q < RL / 2; ++q) {
-            const int k = k0 + q * F::L;
-            pack[k] = e.lo[q];
-            pack[N - k] = e.hi[q];
+        for (int q = 0; q < HALF; ++q) {
+            pack[(size_t)q * T] = e.lo[q];
+            pack[(size_t)(HALF + q) * T] = e.hi[q];
         }
-        if (tid == 0) pack[N / 2] = e.half;
+        pack[(size_t)(2 * HALF) * T] = e.half;
     }
-    // |E + w^k O| -> bin k, |E - w^k O| -> bin 2N' - k (skipped for k = N': the same bin)
-    static MGX_HD void add_bins(float* row, int k, float2 e, float2 o) {
+    // |E + w^k O| and |E - w^k O| (bins k and 2N' - k) onto two accumulators
+    static MGX_HD void add_bins(float* lo, float* hi, int k, float2 e, float2 o) {
         float sn, cs;
         sincos_pi((float)k * (0.5f / (float)N), sn, cs);                  // w^k = cs - j sn
         const float tx = fmaf(cs, o.x, sn * o.y), ty = fmaf(cs, o.y, -sn * o.x);
         const float px = e.x + tx, py = e.y + ty, mx = e.x - tx, my = e.y - ty;
-        row[k] += fast_sqrt(fmaf(px, px, py * py));
-        if (k != N) row[2 * N - k] += fast_sqrt(fmaf(mx, mx, my * my));
+        *lo += fast_sqrt(fmaf(px, px, py * py));
+        *hi += fast_sqrt(fmaf(mx, mx, my * my));
     }
-    // odd pass: O in registers, E back from the scratch, magnitudes into the spectrum rows
+    // odd pass: O in registers, E back from the scratch, magnitudes onto the accumulators.  Slots of a channel:
+    // 4q .. 4q+3 = bins k, 2N'-k, N'-k, N'+k of pair q; 4 HALF, 4 HALF + 1 = bins N'/2, 3N'/2 (thread 0)
     template <bool SIDE>
     static MGX_HD void phase_magnitudes(int tid, int wg, const AnalysisArgs& a, const Pairs& o) {
         if (!F::has_row(tid)) return;
-        const float2* pack = a.wg_pack + (size_t)wg * (N + 1);
-        float* row = spectrum_row(a, wg, SIDE);
+        const float2* pack = pack_of(a, wg) + tid;
+        float* acc = acc_of(a, wg, SIDE) + tid;
         const int k0 = F::frequency_at(tid * RL);
         MGX_UNROLL
-        for (int q = 0; q < RL / 2; ++q) {
+        for (int q = 0; q < HALF; ++q) {
             const int k = k0 + q * F::L;
-            add_bins(row, k, pack[k], o.lo[q]);
-            add_bins(row, N - k, pack[N - k], o.hi[q]);
+            add_bins(acc + (size_t)(4 * q) * T, acc + (size_t)(4 * q + 1) * T, k, pack[(size_t)q * T], o.lo[q]);
+            add_bins(acc + (size_t)(4 * q + 2) * T, acc + (size_t)(4 * q + 3) * T, N - k, pack[(size_t)(HALF + q) * T], o.hi[q]);
         }
-        if (tid == 0) add_bins(row, N / 2, pack[N / 2], o.half);
+        add_bins(acc + (size_t)(4 * HALF) * T, acc + (size_t)(4 * HALF + 1) * T, N / 2, pack[(size_t)(2 * HALF) * T], o.half);
     }
     static MGX_HD void phase_loose_frames(int tid, long long begin, long long end, bool count_rms, const AnalysisArgs& a,
                                           Thread& t) {
@@ -509,6 +506,28 @@ struct AnalysisQuad {
             AB::to_ms(lr, m, s);
             if (count_rms) t.sumsq += (double)(m * m);
             t.peak = fmaxf(t.peak, fmaxf(fabsf(lr.x), fabsf(lr.y)));
+        }
+    }
+    // accumulators -> the workgroup's spectrum rows ([2][2 N' + 1]); the pair of bin 0 holds bins 0, 2N', N' (and N'
+    // once more, left out)
+    static MGX_HD void phase_write_spectrum(int tid, int wg, const AnalysisArgs& a) {
+        if (!F::has_row(tid)) return;
+        const int k0 = F::frequency_at(tid * RL);
+        for (int c = 0; c < 2; ++c) {
+            float* row = a.wg_spec + ((size_t)wg * 2 + c) * (2 * N + 1);
+            const float* acc = acc_of(a, wg, c != 0) + tid;
+            MGX_UNROLL
+            for (int q = 0; q < HALF; ++q) {
+                const int k = k0 + q * F::L;
+                row[k] = acc[(size_t)(4 * q) * T];
+                row[2 * N - k] = acc[(size_t)(4 * q + 1) * T];
+                row[N - k] = acc[(size_t)(4 * q + 2) * T];
+                if (k != 0) row[N + k] = acc[(size_t)(4 * q + 3) * T];
+            }
+            if (tid == 0) {
+                row[N / 2] = acc[(size_t)(4 * HALF) * T];
+                row[3 * N / 2] = acc[(size_t)(4 * HALF + 1) * T];
+            }
         }
     }
 };

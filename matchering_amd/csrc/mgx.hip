@@ -155,7 +155,7 @@ struct DevBuf {
 
 struct TrackWork {              // per-track analysis workspace + results (device)
     DevBuf wg_sumsq, wg_peak, wg_spec, stats, rms, loud, avg;   // avg: [2][F/2+1] double
-    DevBuf wg_pack;                                              // fft_size 65536: [nwg][F/4+1] float2 (AnalysisQuad)
+    DevBuf wg_pack;                                              // fft_size 65536: AnalysisQuad's scratch, 408 KB per workgroup
     DevBuf part;                                                 // [SPEC_SLICES][2][F/2+1] partial spectrum sums
     int divisions = 0, segs_per_piece = 0, segs_per_wg = 0, chunks = 0, nwg = 0, is_reference = 0;
     long long piece = 0;
@@ -168,8 +168,7 @@ struct PlanDev {
     // the same operator in two packed, banded factors (fft_size >= 16384; mgx_kernels.h, k_fir_apply_a / _b)
     struct Factor {
         double* packed = nullptr;       // the rows' windows, one after the other
-        int2* band = nullptr;           // [rows] window of each row
-        long long* off = nullptr;       // [rows] where a row's window starts in `packed`
+        FactorRow* rows = nullptr;      // [rows] window of each row and where it starts in `packed`
         size_t bytes = 0;
     } A, B;
     std::shared_ptr<FirPlanHost> plan;      // keeps the host tables alive as long as the device copy
@@ -425,7 +424,8 @@ static int choose_chunks(mgx_handle* h, const mgx_config* cfg, TrackWork* const*
         MGX_TRY(ensure(h, w.wg_sumsq, (size_t)w.nwg * sizeof(double)));
         MGX_TRY(ensure(h, w.wg_peak, (size_t)w.nwg * sizeof(float)));
         MGX_TRY(ensure(h, w.wg_spec, (size_t)w.nwg * 2 * (half + 1) * sizeof(float)));
-        if (cfg->fft_size == 65536) MGX_TRY(ensure(h, w.wg_pack, (size_t)w.nwg * (cfg->fft_size / 4 + 1) * sizeof(float2)));
+        if (cfg->fft_size == 65536)
+            MGX_TRY(ensure(h, w.wg_pack, (size_t)w.nwg * AnalysisQuad<14>::SCRATCH_FLOAT2 * sizeof(float2)));
         MGX_TRY(ensure(h, w.stats, sizeof(TrackStats)));
         MGX_TRY(ensure(h, w.rms, (size_t)w.divisions * sizeof(double)));
         MGX_TRY(ensure(h, w.loud, (size_t)w.divisions * sizeof(int)));
@@ -563,25 +563,27 @@ static int build_fir_operator(mgx_handle* h, const FirPlanView& pl, double** out
 
 // A dense [rows][cols] matrix -> its rows' windows (k_fir_band), packed.  The dense matrix is freed.
 static int pack_fir_factor(mgx_handle* h, double* dense, int rows, int cols, PlanDev::Factor& f) {
-    HIP_TRY(hipMalloc((void**)&f.band, (size_t)rows * sizeof(int2)));
-    hipLaunchKernelGGL(k_fir_band, dim3(rows), dim3(256), 0, h->stream, (const double*)dense, cols, f.band);
+    int2* band_dev = nullptr;
+    HIP_TRY(hipMalloc((void**)&band_dev, (size_t)rows * sizeof(int2)));
+    hipLaunchKernelGGL(k_fir_band, dim3(rows), dim3(256), 0, h->stream, (const double*)dense, cols, band_dev);
     HIP_TRY(hipGetLastError());
     std::vector<int2> band(rows);
-    HIP_TRY(hipMemcpyAsync(band.data(), f.band, (size_t)rows * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(band.data(), band_dev, (size_t)rows * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    std::vector<long long> off(rows);
+    HIP_TRY(hipFree(band_dev));
+    std::vector<FactorRow> desc(rows);
     long long total = 0;
     for (int r = 0; r < rows; ++r) {
-        off[r] = total;
+        desc[r] = FactorRow{band[r].x, band[r].y, total};
         total += (band[r].y - band[r].x + 1) & ~1;               // (rows start on 16-byte boundaries)
     }
     f.bytes = (size_t)std::max<long long>(total, 2) * sizeof(double);
-    HIP_TRY(hipMalloc((void**)&f.off, (size_t)rows * sizeof(long long)));
+    HIP_TRY(hipMalloc((void**)&f.rows, (size_t)rows * sizeof(FactorRow)));
     HIP_TRY(hipMalloc((void**)&f.packed, f.bytes));
-    HIP_TRY(hipMemcpyAsync(f.off, off.data(), (size_t)rows * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(f.rows, desc.data(), (size_t)rows * sizeof(FactorRow), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemsetAsync(f.packed, 0, f.bytes, h->stream));
-    hipLaunchKernelGGL(k_fir_pack, dim3(rows), dim3(256), 0, h->stream, (const double*)dense, cols, (const int2*)f.band,
-                       (const long long*)f.off, f.packed);
+    hipLaunchKernelGGL(k_fir_pack, dim3(rows), dim3(256), 0, h->stream, (const double*)dense, cols, (const FactorRow*)f.rows,
+                       f.packed);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     HIP_TRY(hipFree(dense));
@@ -724,9 +726,9 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
         hipLaunchKernelGGL(k_fir_b, dim3(2), dim3(1024), lds_scan, h->stream, pl, scratch);
     } else if (factored) {
         hipLaunchKernelGGL(k_fir_apply_a, dim3(pl.lw.anchors), dim3(256), 0, h->stream, pl, (const double*)pd.A.packed,
-                           (const int2*)pd.A.band, (const long long*)pd.A.off, (const double*)raw, scratch);
+                           (const FactorRow*)pd.A.rows, (const double*)raw, scratch);
         hipLaunchKernelGGL(k_fir_apply_b, dim3((pl.bins + 255) / 256), dim3(256), 0, h->stream, pl, (const double*)pd.B.packed,
-                           (const int2*)pd.B.band, (const long long*)pd.B.off, (const double*)raw, scratch);
+                           (const FactorRow*)pd.B.rows, (const double*)raw, scratch);
     } else {
         hipLaunchKernelGGL(k_fir_matvec, dim3(pl.bins), dim3(256), 0, h->stream, pl, (const double*)pd.M,
                            (const int2*)pd.band, (const double*)raw, scratch);

@@ -730,7 +730,7 @@ __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) v
 }
 
 // fft_size = 4 * Fft2<LOG2H>::N (analysis2_kernel.h, AnalysisQuad): the same grid layout and outputs, four transforms
-// per segment; the spectrum sums live in wg_spec from the start (every bin has one owning thread)
+// per segment; the spectrum sums live in the workgroup's slice of a.wg_pack until the end
 template <int LOG2H>
 __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) void k_analyze_quad(AnalysisArgs a0,
                                                                                                   AnalysisArgs a1,
@@ -797,6 +797,7 @@ __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) v
         if (d == a.divisions - 1)
             AQ::phase_loose_frames(tid, (long long)a.divisions * a.piece, a.n, false, a, th);
     }
+    AQ::phase_write_spectrum(tid, wg, a);
     const double ss = block_sum<F::T>(th.sumsq, dscratch);
     const float pk = block_max<F::T>(th.peak, fscratch);
     if (tid == 0) {
@@ -1401,6 +1402,12 @@ __global__ __launch_bounds__(256) void k_fir_matvec(FirPlanView pl, const double
 // i the handful of anchors around it) and stored PACKED, row after row, only the window k_fir_band found:
 // 3.4 MB at fft_size 16384 where M is 537 MB (of which the product read 83 MB per pair, 28 us), a few MB more at
 // 65536 where M would be 8.6 GB.  Built like M, by pushing unit vectors through the chain's own kernels.
+// One 16-byte descriptor per row: its window [first, last) and where it starts in the packed array (one load, not a
+// chain of two, in front of a row's data).
+struct FactorRow {
+    int first, last;
+    long long off;
+};
 // unit anchor `col0 + plane` as the fits, nothing on the raw side (phase_pin reads raw[1])
 __global__ __launch_bounds__(256) void k_fir_unit_fit(FirPlanView pl, double* scratch, int col0) {
     const int plane = blockIdx.x;
@@ -1417,24 +1424,24 @@ __global__ __launch_bounds__(256) void k_fir_gather_plane(FirPlanView pl, double
     dense[(size_t)i * stride + col0 + c] = from_fit ? s.fit[i] : s.smooth[i];
 }
 // packed[off[row] + j - band[row].x] = dense[row][j] over the row's window; grid = rows
-__global__ __launch_bounds__(256) void k_fir_pack(const double* dense, int stride, const int2* band, const long long* off,
-                                                  double* packed) {
+__global__ __launch_bounds__(256) void k_fir_pack(const double* dense, int stride, const FactorRow* rows, double* packed) {
     const int row = blockIdx.x;
-    const int first = band[row].x, last = band[row].y;
+    const int first = rows[row].first, last = rows[row].last;
     const double* src = dense + (size_t)row * stride;
-    double* dst = packed + off[row] - first;
+    double* dst = packed + rows[row].off - first;
     for (int j = first + threadIdx.x; j < last; j += 256) dst[j] = src[j];
 }
 // fit[plane][a] = sum_j A[a][j] raw[plane][j]: one 256-thread workgroup per anchor, both channels per pass, the whole
 // window in flight at once (the widest is 0.31 * bins + 62 columns: eleven loads per thread at fft_size 16384);
 // grid = anchors.  (One WAVE per anchor, the first version, walked the wide windows in five dependent batches:
 // 20 us for the two factors against the dense product's 28, profiles/r05_p_fir_factored_first_version.txt.)
-__global__ __launch_bounds__(256) void k_fir_apply_a(FirPlanView pl, const double* A, const int2* band, const long long* off,
-                                                     const double* raw, double* scratch) {
+__global__ __launch_bounds__(256) void k_fir_apply_a(FirPlanView pl, const double* A, const FactorRow* rows, const double* raw,
+                                                     double* scratch) {
     __shared__ double red[2][4];
     const int a = blockIdx.x, tid = threadIdx.x;
-    const int first = band[a].x, last = band[a].y;
-    const double* m = A + off[a] - first;
+    const FactorRow row = rows[a];
+    const int first = row.first, last = row.last;
+    const double* m = A + row.off - first;
     const double* r0 = raw;
     const double* r1 = raw + pl.bins;
     double a0 = 0.0, a1 = 0.0;
@@ -1465,13 +1472,14 @@ __global__ __launch_bounds__(256) void k_fir_apply_a(FirPlanView pl, const doubl
 }
 // smooth[plane][i] = sum_a B[i][a] fit[plane][a] (a handful of terms: one thread per bin), bins 0 and 1 pinned
 // (match_frequencies.py:72-73); grid = ceil(bins / 256)
-__global__ __launch_bounds__(256) void k_fir_apply_b(FirPlanView pl, const double* B, const int2* band, const long long* off,
-                                                     const double* raw, double* scratch) {
+__global__ __launch_bounds__(256) void k_fir_apply_b(FirPlanView pl, const double* B, const FactorRow* rows, const double* raw,
+                                                     double* scratch) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= pl.bins) return;
     const FirScratch s0 = fir_scratch(scratch, pl, 0), s1 = fir_scratch(scratch, pl, 1);
-    const int first = band[i].x, last = band[i].y;
-    const double* m = B + off[i] - first;
+    const FactorRow row = rows[i];
+    const int first = row.first, last = row.last;
+    const double* m = B + row.off - first;
     double a0 = 0.0, a1 = 0.0;
     for (int a = first; a < last; a += 8) {                      // (windows are 4 - 10 anchors wide: one batch, two at most)
         double v[8], f0[8], f1[8];

@@ -505,7 +505,7 @@ static int analyze_quad_impl(const float* x, long long n, const mgx_config* cfg,
     const int nwg = divisions * a.chunks_per_piece;
     std::vector<double> wg_sumsq(nwg);
     std::vector<float> wg_peak(nwg), wg_spec((size_t)nwg * 2 * (half + 1), -1.f);      // (the kernel clears its rows)
-    std::vector<float2> wg_pack((size_t)nwg * (F::N + 1));
+    std::vector<float2> wg_pack((size_t)nwg * AQ::SCRATCH_FLOAT2);
     a.wg_sumsq = wg_sumsq.data();
     a.wg_peak = wg_peak.data();
     a.wg_spec = wg_spec.data();
@@ -550,6 +550,7 @@ static int analyze_quad_impl(const float* x, long long n, const mgx_config* cfg,
                 FOR_THREADS(F::T) AQ::phase_loose_frames(tid, (long long)divisions * piece, n, false, a, th[tid]);
             }
         }
+        FOR_THREADS(F::T) AQ::phase_write_spectrum(tid, wg, a);
         double ss = 0.0;
         float pk = 0.f;
         FOR_THREADS(F::T) { ss += th[tid].sumsq; pk = std::fmax(pk, th[tid].peak); }
