@@ -345,6 +345,8 @@ def share_one_gpu_over_rccl(rank):
     talk over the loop-back socket transport -- enough to prove the exchange end to end where no second GPU
     exists; never set when every rank has its own GPU."""
     os.environ["NCCL_HOSTID"] = f"mgx-bench-rank-{rank}"
+    # ... and the limiters of two processes on one chip must not wait for each other (batch.ranks_share_a_gpu)
+    os.environ.setdefault("MGX_LIMIT_TICKETS", "1")
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
     os.environ.setdefault("NCCL_IB_DISABLE", "1")
     os.environ.setdefault("NCCL_SHM_DISABLE", "1")

@@ -120,7 +120,17 @@ def lanes_allowed(world_size=1):
     from .device import device_count
 
     sharing = max(1, -(-int(world_size) // max(1, device_count())))
+    if sharing > 1:
+        ranks_share_a_gpu()
     return max(1, MAX_LANES // sharing)
+
+
+def ranks_share_a_gpu():
+    """More rank PROCESSES than GPUs: their limiter launches can be resident on one chip together, where chunks dealt by
+    workgroup number may wait for each other for ever (mgx.hip, LimiterChain -- handles of one process are chained,
+    processes cannot see each other).  The library then deals chunks by an atomic ticket: slower by a fifth, safe with
+    any neighbour.  Read by the library at every limiter launch."""
+    os.environ.setdefault("MGX_LIMIT_TICKETS", "1")
 
 
 _measuring = threading.Lock()

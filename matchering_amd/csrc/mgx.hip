@@ -180,6 +180,24 @@ struct PlanDev {
 static std::mutex g_plan_mu;
 static std::map<std::pair<int, const FirPlanHost*>, PlanDev> g_plan_dev;
 
+// Limiter launches of one device never run side by side.  k_limit deals its chunks by workgroup number (no atomic
+// ticket): a chunk waits for words of lower-numbered chunks only, and every XCD's dispatcher hands out its share of a
+// grid in order, so within ONE launch the lowest unfinished chunk is always resident.  Two limiter launches resident
+// together break that: launch A's waiting workgroups can fill the XCD on which launch B's lowest chunk would start
+// while B's fill the one A needs (seen with two rank PROCESSES sharing a GPU: the bounded waits expired,
+// profiles/r05_u_*).  Handles of one process (the two or three lanes of a batch) therefore chain their limiter
+// launches through an event per handle -- a limiter fills the chip by itself, nothing is lost -- while every other
+// kernel of the lanes still overlaps freely.  Processes that share a GPU cannot see each other: they set
+// MGX_LIMIT_TICKETS=1 (bench.py and batch.py do when ranks outnumber GPUs), and a handle whose wait expires all the
+// same falls back to tickets by itself (check_device_error).
+constexpr int MAX_DEVICES = 64;
+struct LimiterChain {
+    std::mutex mu;
+    hipEvent_t last = nullptr;      // recorded behind the device's most recent limiter launch
+    int live = 0;                   // handles alive on the device
+};
+static LimiterChain g_limiter_chain[MAX_DEVICES];
+
 struct mgx_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -221,6 +239,7 @@ struct mgx_handle {
     // the limiter's chunks are its workgroups' numbers; after a look-back wait has expired once on this handle they are
     // drawn from an atomic ticket instead, which does not lean on the dispatch order (k_limit, mgx_kernels.h)
     bool limiter_tickets = false;
+    hipEvent_t lim_done = nullptr;                                // behind this handle's latest limiter launch (LimiterChain)
     int masters_outstanding = 0;            // mgx_master calls queued since the last check of the error words
     int downloads_outstanding = 0;          // device-to-host copies queued behind them
     ncclComm_t comm = nullptr;
@@ -1076,10 +1095,22 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
         HIP_TRY(hipMemsetAsync(h->lim_published.p, 0xff, pub_bytes, h->stream));
         HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 4, h->stream));
     }
+    // behind the device's previous limiter launch if another handle queued it (LimiterChain); a handle that is alone
+    // on its device records nothing: its launches are ordered by its one stream
+    LimiterChain& chain = g_limiter_chain[h->device % MAX_DEVICES];
+    std::unique_lock<std::mutex> lock(chain.mu);
+    const bool shared = chain.live > 1;
+    if (shared && chain.last && chain.last != h->lim_done) HIP_TRY(hipStreamWaitEvent(h->stream, chain.last, 0));
+    int rc = 0;
     switch (lp.general) {
-        case 0: return launch_limiter(h, a, threads);
-        default: return launch_limiter_general<2>(h, a, lp);
+        case 0: rc = launch_limiter(h, a, threads); break;
+        default: rc = launch_limiter_general<2>(h, a, lp); break;
     }
+    if (rc == 0 && shared) {
+        HIP_TRY(hipEventRecord(h->lim_done, h->stream));
+        chain.last = h->lim_done;
+    }
+    return rc;
 }
 
 // A bounded device-side wait expired (never seen in normal operation; the spins are bounded so that a lost word
@@ -1224,6 +1255,13 @@ int mgx_create(int device, mgx_handle** out) {
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&h->ev0));
     HIP_TRY(hipEventCreate(&h->ev1));
+    HIP_TRY(hipEventCreateWithFlags(&h->lim_done, hipEventDisableTiming));
+    {
+        // the second handle of a device: whatever limiter the first has in flight was queued without an event
+        LimiterChain& chain = g_limiter_chain[device % MAX_DEVICES];
+        std::lock_guard<std::mutex> lock(chain.mu);
+        if (++chain.live == 2) HIP_TRY(hipDeviceSynchronize());
+    }
     HIP_TRY(hipHostMalloc((void**)&h->error_host, 64, hipHostMallocMapped));
     std::memset(h->error_host, 0, 64);
     HIP_TRY(hipHostGetDevicePointer((void**)&h->error_dev, h->error_host, 0));
@@ -1250,6 +1288,13 @@ int mgx_destroy(mgx_handle* h) {
     if (!h) return 0;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    {
+        LimiterChain& chain = g_limiter_chain[h->device % MAX_DEVICES];
+        std::lock_guard<std::mutex> lock(chain.mu);
+        if (chain.last == h->lim_done) chain.last = nullptr;       // (its limiter has finished: the stream has drained)
+        --chain.live;
+    }
+    if (h->lim_done) hipEventDestroy(h->lim_done);
     if (h->comm) ncclCommDestroy(h->comm);
     DevBuf* bufs[] = {&h->y, &h->mid, &h->block_peak, &h->filt, &h->taps, &h->partial, &h->cstate,
                       &h->scalars, &h->lim_published, &h->lim_ctrl, &h->lim_weights, &h->lim_tables, &h->fir_robust, &h->peak_words, &h->fir_scratch, &h->round_ctr, &h->tail_gains, &h->band, &h->band_info,
@@ -1257,7 +1302,7 @@ int mgx_destroy(mgx_handle* h) {
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (TrackWork& w : h->track) {
-        DevBuf* tb[] = {&w.wg_sumsq, &w.wg_peak, &w.wg_spec, &w.stats, &w.rms, &w.loud, &w.avg, &w.part};
+        DevBuf* tb[] = {&w.wg_sumsq, &w.wg_peak, &w.wg_spec, &w.wg_pack, &w.stats, &w.rms, &w.loud, &w.avg, &w.part};
         for (DevBuf* b : tb)
             if (b->p) hipFree(b->p);
     }

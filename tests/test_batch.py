@@ -139,6 +139,42 @@ def test_gpu_lanes_are_bit_identical_to_single_runs():
 
 
 @pytest.mark.gpu
+def test_gpu_limiters_of_two_handles_never_wait_for_each_other():
+    """Two device handles of one process, each with a queue of two-minute pairs whose limiter grids (1477 chunks) are
+    larger than the chip holds at once (1024): left to themselves the two limiter launches would be resident together,
+    each XCD's slots full of one launch's waiting workgroups while the other launch's lowest chunk cannot start there
+    (k_limit deals chunks by workgroup number).  The library chains limiter launches of a device through an event per
+    handle (mgx.hip, LimiterChain): every call completes, no look-back wait expires, results equal a lone run's."""
+    from matchering_amd.device import Device
+
+    cfg = mg.Config()
+    native = cfg.to_native()
+    t = np.clip(1.4 * synth(120.0, 44100, 71), -1, 1).astype(np.float32)       # hot: every chunk is busy
+    r = np.clip(2.5 * synth(100.0, 44100, 72), -1, 1).astype(np.float32)
+    lone = Device(0)
+    try:
+        td, rd, out = lone.upload(t), lone.upload(r), lone.alloc(t.shape[0] * 8)
+        lone.master(td, t.shape[0], rd, r.shape[0], native, result=out, want_report=False)
+        want = np.array(lone.download(out, (t.shape[0], 2)))
+    finally:
+        lone.close()
+    a, b = Device(0), Device(0)
+    try:
+        bufs = []
+        for d in (a, b):
+            bufs.append((d.upload(t), d.upload(r), d.alloc(t.shape[0] * 8)))
+        a.synchronize(), b.synchronize()
+        for _ in range(12):                                                      # queued without waiting: the lanes of a batch
+            for d, (td, rd, out) in zip((a, b), bufs):
+                d.master(td, t.shape[0], rd, r.shape[0], native, result=out, want_report=False)
+        for d, (td, rd, out) in zip((a, b), bufs):
+            d.synchronize()                                                      # (raises if a bounded wait expired)
+            assert np.array_equal(np.array(d.download(out, (t.shape[0], 2))), want)
+    finally:
+        a.close(), b.close()
+
+
+@pytest.mark.gpu
 def test_gpu_album_mode_one_broadcast_fir_for_every_track():
     """batch.master_album on one rank: the FIR designed on track 0 goes through ncclBroadcast (RCCL, a
     one-rank communicator here) and is applied to every track; levels are matched per track.  Track 0
