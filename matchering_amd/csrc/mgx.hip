@@ -1921,9 +1921,20 @@ int mgx_last_fir(mgx_handle* h, void** taps_dev, int32_t* taps) {
 }
 
 // ---- RCCL ----------------------------------------------------------------------
+// The ranks of a job are the GPUs of ONE node (they meet over a local socket, matchering_amd/ranks.py), and the data
+// path between them is xGMI: the bootstrap needs no interface but loop-back and nothing has to look for InfiniBand.
+// So neither is left to RCCL's probing of a box without a network whose host name does not resolve: RCCL's first
+// initialisation in a process normally takes 2 - 5 s here either way (tools/rccl_init_time.py), but on one box of the
+// pool it took 457 s with RCCL's own defaults (profiles/r05_w_*; cause not established -- the box was gone with the
+// call).  Only set where the host has not chosen itself.
+static void single_node_rccl_defaults() {
+    setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+    setenv("NCCL_IB_DISABLE", "1", 0);
+}
 int mgx_comm_unique_id(void* id128) {
     if (!id128) return fail(MGX_ERR_ARGUMENT, "null argument");
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    single_node_rccl_defaults();
     ncclUniqueId id;
     NCCL_TRY(ncclGetUniqueId(&id));
     std::memcpy(id128, &id, sizeof(id));
@@ -1932,6 +1943,7 @@ int mgx_comm_unique_id(void* id128) {
 int mgx_comm_init(mgx_handle* h, const void* id128, int rank, int world) {
     if (!h || !id128) return fail(MGX_ERR_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(h->device));
+    single_node_rccl_defaults();
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     NCCL_TRY(ncclCommInitRank(&h->comm, world, id, rank));
