@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <vector>
 
 #include "../../matchering_amd/csrc/analysis2_kernel.h"
@@ -18,6 +19,7 @@
 #include "../../matchering_amd/csrc/conv_wide_kernel.h"
 #include "../../matchering_amd/csrc/fir_design.h"
 #include "../../matchering_amd/csrc/host_params.h"
+#include "../../matchering_amd/csrc/fir_plan.h"
 
 using namespace mgx;
 
@@ -833,6 +835,88 @@ extern "C" int emu_design_fir_direct(const mgx_config* cfg, const double* avg_ta
                       cfg->lowess_it, cfg->lowess_delta, cfg->min_value};
     design_fir_direct(avg_target, avg_reference, p, taps, curve_raw, curve_smooth);
     return 0;
+}
+// The raw -> smooth operator in its two factors through the LOWESS anchors (mgx.hip build_fir_factors, mgx_kernels.h
+// k_fir_apply_a / k_fir_apply_b), with the phase functions the device kernels run: unit raw curves -> the anchors' fits
+// (A), unit fits -> the smooth curve (B), rows cut to the window above 1e-18 of their largest entry (k_fir_band), then
+// smooth = B (A raw) with bins 0 and 1 pinned.  Returns the windows' total sizes (in doubles) for the two factors.
+extern "C" int emu_fir_factored(const mgx_config* cfg, const double* raw_in, double* smooth_out, long long* a_doubles,
+                                long long* b_doubles) {
+    using FD = FirDesign;
+    FirDesignParams p{cfg->fft_size, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac,
+                      0, cfg->lowess_delta, cfg->min_value};
+    std::shared_ptr<FirPlanHost> plan = FirPlanHost::get(p);
+    const FirPlanView pl = plan->view(plan->blob());
+    const int bins = pl.bins, anchors = pl.lw.anchors;
+    std::vector<double> raw(bins), m1(bins), on_log(pl.nlog), fit(anchors), log_s(pl.nlog), m2(pl.nlog), smooth(bins);
+    FirScratch s{raw.data(), m1.data(), on_log.data(), fit.data(), log_s.data(), m2.data(), smooth.data()};
+    std::vector<Affine> sc(FD::Scan::SCRATCH);
+#define ALL(stmt) for (int tid = 0; tid < FD::T; ++tid) { stmt; }
+    auto solve = [&](const SplineTables& sp, const double* y, double* m) {
+        ALL(FD::phase_fwd_local(tid, sp, y, sc.data()))
+        ALL(FD::Scan::scan_groups(sc.data(), tid))
+        ALL(FD::Scan::scan_top(sc.data(), tid))
+        ALL(FD::phase_fwd_apply(tid, sp, y, sc.data(), m))
+        ALL(FD::phase_bwd_local(tid, sp, m, sc.data()))
+        ALL(FD::Scan::scan_groups(sc.data(), tid))
+        ALL(FD::Scan::scan_top(sc.data(), tid))
+        ALL(FD::phase_bwd_apply(tid, sp, sc.data(), m))
+        ALL(FD::phase_closure(tid, sp, m))
+    };
+    std::vector<double> A((size_t)anchors * bins), B((size_t)bins * anchors);
+    for (int col = 0; col < bins; ++col) {                       // k_fir_unit_a + k_fir_lowess + k_fir_gather_plane
+        for (int k = 0; k < bins; ++k) raw[k] = k == col ? 1.0 : 0.0;
+        solve(pl.s1, s.raw, s.m1);
+        ALL(FD::phase_eval(tid, pl.s1, s.raw, s.m1, s.on_log))
+        ALL(FD::phase_lowess_fit(tid, pl.lw, s.on_log, s.fit))
+        for (int a = 0; a < anchors; ++a) A[(size_t)a * bins + col] = fit[a];
+    }
+    for (int col = 0; col < anchors; ++col) {                    // k_fir_unit_fit + k_fir_b + k_fir_gather_plane
+        for (int a = 0; a < anchors; ++a) fit[a] = a == col ? 1.0 : 0.0;
+        raw[1] = 0.0;
+        ALL(FD::phase_lowess_fill(tid, pl.lw, s.fit, s.log_s))
+        solve(pl.s2, s.log_s, s.m2);
+        ALL(FD::phase_eval(tid, pl.s2, s.log_s, s.m2, s.smooth))
+        ALL(FD::phase_pin(tid, s))
+        for (int i = 0; i < bins; ++i) B[(size_t)i * anchors + col] = smooth[i];
+    }
+#undef ALL
+    auto window = [](const double* row, int n, int& first, int& last) {          // k_fir_band
+        double mx = 0.0;
+        for (int j = 0; j < n; ++j) mx = std::fmax(mx, std::fabs(row[j]));
+        const double cut = mx * 1e-18;
+        first = n, last = 0;
+        for (int j = 0; j < n; ++j)
+            if (std::fabs(row[j]) > cut) { first = std::min(first, j); last = std::max(last, j + 1); }
+        if (first >= last) first = last = 0;
+    };
+    long long asz = 0, bsz = 0;
+    std::vector<double> f0(anchors);
+    for (int a = 0; a < anchors; ++a) {                           // k_fir_apply_a
+        int first, last;
+        window(A.data() + (size_t)a * bins, bins, first, last);
+        asz += last - first;
+        double acc = 0.0;
+        for (int j = first; j < last; ++j) acc = std::fma(A[(size_t)a * bins + j], raw_in[j], acc);
+        f0[a] = acc;
+    }
+    for (int i = 0; i < bins; ++i) {                              // k_fir_apply_b
+        int first, last;
+        window(B.data() + (size_t)i * anchors, anchors, first, last);
+        bsz += last - first;
+        double acc = 0.0;
+        for (int a = first; a < last; ++a) acc = std::fma(B[(size_t)i * anchors + a], f0[a], acc);
+        smooth_out[i] = i == 0 ? 0.0 : i == 1 ? raw_in[1] : acc;
+    }
+    if (a_doubles) *a_doubles = asz;
+    if (b_doubles) *b_doubles = bsz;
+    return 0;
+}
+
+extern "C" int emu_fir_anchors(const mgx_config* cfg) {
+    FirDesignParams p{cfg->fft_size, cfg->internal_sample_rate, cfg->lin_log_oversampling, cfg->lowess_frac,
+                      0, cfg->lowess_delta, cfg->min_value};
+    return FirPlanHost::get(p)->anchors();
 }
 extern "C" int emu_lowess_robust(const double* y, int n, double frac, double delta, int it, double* fit) {
     lowess(y, n, frac, delta, it, fit);

@@ -397,6 +397,41 @@ def test_fir_design_phases_with_lowess_iterations(emu, it):
     assert np.abs(want_smooth - mo.smooth_matching_curve(a_r / np.maximum(p.min_value, a_t), p0)).max() > 1e-3
 
 
+@pytest.mark.parametrize("fft,sr", [(256, 44100), (1024, 96000)])
+def test_fir_operator_in_two_factors_through_the_lowess_anchors(emu, fft, sr):
+    """raw -> smooth as B (A raw) (mgx.hip build_fir_factors; k_fir_apply_a / k_fir_apply_b), built and applied on the
+    host with the device's own phase functions: equal to the chain run on the curve itself (emu_design_fir) and to the
+    oracle's smoothing (match_frequencies.py:45-75) to float64 rounding, bins 0 and 1 pinned, and both factors banded
+    (their windows a small part of anchors x bins)."""
+    import matchering_amd as mg
+
+    rng = np.random.RandomState(fft)
+    bins = fft // 2 + 1
+    k = np.arange(bins)
+    a_t = (1.0 / (1.0 + k / 40.0) + 0.02 * rng.rand(bins)) * fft
+    a_r = (1.2 / (1.0 + k / 25.0) + 0.02 * rng.rand(bins)) * fft
+    a_r[bins // 3] *= 6.0
+    cfg = mg.Config(fft_size=fft, internal_sample_rate=sr, max_piece_size=fft * 4 / sr)
+    native = cfg.to_native()
+    taps, raw, chain = np.zeros(fft), np.zeros(bins), np.zeros(bins)
+    assert emu.emu_design_fir(ctypes.byref(native), _dp(a_t), _dp(a_r), _dp(taps), _dp(raw), _dp(chain)) == 0
+    factored = np.zeros(bins)
+    a_size, b_size = ctypes.c_longlong(), ctypes.c_longlong()
+    emu.emu_fir_factored.argtypes = [ctypes.c_void_p, c_double_p, c_double_p, ctypes.POINTER(ctypes.c_longlong),
+                                     ctypes.POINTER(ctypes.c_longlong)]
+    assert emu.emu_fir_factored(ctypes.byref(native), _dp(raw), _dp(factored), ctypes.byref(a_size),
+                                ctypes.byref(b_size)) == 0
+    scale = np.abs(chain).max()
+    assert np.abs(factored - chain).max() <= 1e-12 * scale
+    assert factored[0] == 0.0 and factored[1] == raw[1]
+    p = mo.params(fft_size=fft, internal_sample_rate=sr)
+    want = mo.smooth_matching_curve(a_r / np.maximum(p.min_value, a_t), p)
+    assert np.abs(factored - want).max() <= 1e-9 * np.abs(want).max()
+    anchors = emu.emu_fir_anchors(ctypes.byref(native))
+    assert 0 < anchors <= (fft // 2) * cfg.lin_log_oversampling + 1
+    assert 0 < a_size.value < 0.5 * anchors * bins and 0 < b_size.value < 0.2 * anchors * bins
+
+
 def test_butterworth_design_matches_scipy(emu):
     """butter_tf (host_params.h) against scipy.signal.butter for the orders and cut-offs the limiter uses
     (hyrax.py:55-72): 7 Hz hold, 800 / 3000 Hz release, sample rates 8 k to 192 k."""
