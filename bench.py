@@ -437,6 +437,9 @@ def run(args, ranks):
                    "pairs_per_gpu_per_step": wl.pairs, "parallelism": f"pairs x{ranks.world * wl.pairs}",
                    **({"lane_choice": wl.lane_choice} if wl.lane_choice else {})},
         "rank_gpus": rank_gpus, "physical_gpus": physical, "shared_gpu": physical < ranks.world,
+        # how k_limit hands out its chunks: by workgroup number, or by atomic ticket where rank
+        # PROCESSES share a chip (two limiter launches resident together must not wait for each other)
+        "limiter_chunks": "atomic ticket" if os.environ.get("MGX_LIMIT_TICKETS") == "1" else "workgroup number",
         "pipeline_hbm_model": {"bytes_per_frame": model, "achieved_GBs": round(pipeline_gbs, 1),
                                "peak_GBs": HBM_PEAK_GBS * physical,
                                "frac_of_8TBs": round(pipeline_gbs / (HBM_PEAK_GBS * physical), 4),
