@@ -173,9 +173,9 @@ struct PlanDev {
     } A, B;
     std::shared_ptr<FirPlanHost> plan;      // keeps the host tables alive as long as the device copy
 };
-// One copy per (device, Config's design parameters) for the whole process, not per handle: the operator
-// is bins^2 doubles (34 MB at fft_size 4096, 537 MB at 16384), and the three device handles a batch runs
-// on one GPU (batch.py) would otherwise each build and hold their own.  Entries live as long as the
+// One copy per (device, Config's design parameters) for the whole process, not per handle: the operator is bins^2
+// doubles up to fft_size 8192 (34 MB at 4096), two packed factors of a few MB beyond, and the three device handles a
+// batch runs on one GPU (batch.py) would otherwise each build and hold their own.  Entries live as long as the
 // process: a handle that is destroyed may leave kernels of its siblings reading them.
 static std::mutex g_plan_mu;
 static std::map<std::pair<int, const FirPlanHost*>, PlanDev> g_plan_dev;
