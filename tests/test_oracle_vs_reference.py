@@ -65,6 +65,23 @@ def test_smallest_fft_sizes_the_reference_runs(fft_size):
         assert np.abs(mine - np.ascontiguousarray(want)).max() <= 1e-11
 
 
+@pytest.mark.parametrize("fft_size", [32768, 65536])
+def test_largest_fft_sizes_on_the_inputs_of_the_gpu_test(fft_size):
+    """tests/test_gpu_parity.py::test_master_fft_size_32768_and_65536 compares the device with the oracle on exactly this
+    pair and configuration (192 kHz, 2 s): here the oracle is held against the unmodified reference on them -- the three
+    outputs and the FIR pair (65536 is the largest fft_size libmgx runs; the reference takes any power of two)."""
+    sr = 192000
+    target, reference = make_pair(2.0, sr, pair=14, reference_seconds=1.7)
+    cfg = dict(internal_sample_rate=sr, fft_size=fft_size, max_piece_size=0.6)
+    outs_ref, inter = rr.run_reference(target, reference, cfg)
+    trace = {}
+    outs = mo.master(target, reference, mo.params(**cfg), True, True, True, trace=trace)
+    for mine, want in zip(outs, outs_ref):
+        assert np.abs(mine - np.ascontiguousarray(want)).max() <= 1e-11
+    assert np.abs(trace["fir_mid"] - inter["fir_mid"]).max() <= 1e-12 * np.abs(inter["fir_mid"]).max()
+    assert np.abs(trace["fir_side"] - inter["fir_side"]).max() <= 1e-12 * np.abs(inter["fir_side"]).max()
+
+
 @pytest.mark.parametrize("cfg", [dict(fft_size=2), dict(fft_size=4), dict(limiter=dict(hold=0.25)),
                                  dict(limiter=dict(hold=0.05))])
 def test_what_the_reference_itself_cannot_run(cfg):
