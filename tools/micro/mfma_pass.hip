@@ -9,6 +9,7 @@
 //   2  shared: per wave half the butterflies each way    3  rescale only (the loop's fixed cost)
 //   4  waves 0-3, 8-11 VALU, the others idle             5  waves 4-7, 12-15 MFMA, the others idle
 //   6  waves 0-3, 8-11 VALU and waves 4-7, 12-15 MFMA   (every SIMD holds two waves of each kind)
+//  13  VALU butterflies, the two passes of a direction fused: the exchange between them through v_permlane*_swap
 // Prints us per iteration and block, the shader clock during the run (s_memtime against the 100 MHz counter), and the
 // deviation of the result from the input after the identity (and between modes).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I matchering_amd/csrc -o tools/micro/mfma_pass tools/micro/mfma_pass.hip
@@ -18,10 +19,12 @@
 #include <cstdlib>
 #include <vector>
 #include "fft2_mfma.h"
+#include "fft2_lanes.h"
 
 using namespace mgx;
 using F = Fft2<14>;
 using FM = Fft2Mfma<14>;
+using FL = Fft2Lanes<14>;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -61,6 +64,10 @@ __global__ __launch_bounds__(1024) void k(float2* data, const float2* tw, int it
             FM::pass_shared<2, true, 0>(t, lds, table + F::MID_TABLE1, wi);
             asm volatile("" ::: "memory");
             FM::pass_shared<1, true, 0>(t, lds, table, wi);
+        } else if (MODE == 13) {           // the two middle passes as one phase, exchange through the lanes (fft2_lanes.h)
+            FL::fwd_mid_fused(t, lds, table);
+            asm volatile("" ::: "memory");
+            FL::inv_mid_fused(t, lds, table);
         } else if (MODE == 2) {
             FM::pass_shared<1, false, 1>(t, lds, table, wf);
             asm volatile("" ::: "memory");
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(1024) void k(float2* data, const float2* tw, int it
             FM::pass_shared<1, true, 1>(t, lds, table, wi);
         }
         asm volatile("" ::: "memory");
-        if (MODE <= 3) {
+        if (MODE <= 3 || MODE == 13) {
             // the wave's own 1024 points, times 1/64
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -238,6 +245,7 @@ int main(int argc, char** argv) {
     run<4>("4 half the waves VALU, the others idle", d_data, d_tw, input, blocks, iters, d_clocks, nullptr);
     run<5>("5 half the waves MFMA, the others idle", d_data, d_tw, input, blocks, iters, d_clocks, nullptr);
     run<6>("6 half the waves VALU beside half MFMA", d_data, d_tw, input, blocks, iters, d_clocks, nullptr);
+    run<13>("13 fused middle passes (lane exchange)", d_data, d_tw, input, blocks, iters, d_clocks, &keep);
     printf("registers only (no LDS): per iteration a VALU wave issues two radix-8 butterflies + twiddles, a matrix wave 16 MFMAs\n");
     float* d_out;
     CK(hipMalloc(&d_out, 256 * 1024 * sizeof(float)));
