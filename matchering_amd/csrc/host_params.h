@@ -170,6 +170,11 @@ inline std::vector<double> lookback_weights(double alpha, int chunk, int cap) {
     return w;
 }
 
+// blocks per chunk asked for from outside the parameter rule (0: none); set by mgx.hip (MGX_LIMIT_THREADS)
+inline int& limiter_threads_wish() {
+    static int wish = 0;
+    return wish;
+}
 // utils.py:50-55, hyrax.py:43-75.  Returns an error text, empty when fine.
 inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
     const double sr = c.internal_sample_rate;
@@ -195,10 +200,19 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
     p.rel_f = butter1(c.release_filter_coefficient / c.release_ms, sr);
     // frames after which the attack smoother has forgotten its state (rho^ha <= MGX_ATTACK_FORGET)
     p.ha = (int)std::ceil(std::log(MGX_ATTACK_FORGET) / std::log(rho));
-    // 256 blocks per chunk while the halos leave at least a quarter of them to the core, else 1024
+    // 256 blocks per chunk while the halos leave at least a quarter of them to the core, else 1024;
+    // `limiter_threads_wish` (256 / 512 / 1024, 0 = this rule): what mgx.hip asks for (measurement aid, and the rule
+    // for sample rates whose halos eat more than a fifth of a 256-block chunk)
     p.threads = 256;
     p.geo = LimiterBlock<256>::geometry(p.hw, p.hb, p.ha);
-    if (p.geo.core_blocks < 64) {
+    int wish = limiter_threads_wish();
+    if (p.geo.core_blocks < 64 && wish < 1024) wish = 1024;
+    if (wish == 512 && (c.hold_filter_order > 1 || c.release_filter_order > 1)) wish = 0;     // (the general kernel is 256 only)
+    if (wish == 512) {
+        p.threads = 512;
+        const LimiterBlock<512>::Geometry g = LimiterBlock<512>::geometry(p.hw, p.hb, p.ha);
+        p.geo.gl = g.gl; p.geo.gr = g.gr; p.geo.gw = g.gw; p.geo.core_blocks = g.core_blocks; p.geo.chunk = g.chunk;
+    } else if (wish == 1024) {
         p.threads = 1024;
         const LimiterBlock<1024>::Geometry g = LimiterBlock<1024>::geometry(p.hw, p.hb, p.ha);
         p.geo.gl = g.gl; p.geo.gr = g.gr; p.geo.gw = g.gw; p.geo.core_blocks = g.core_blocks; p.geo.chunk = g.chunk;

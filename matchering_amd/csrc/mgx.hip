@@ -135,7 +135,7 @@ static void code_sizes_from_library(int (&bytes)[CODE_KERNELS][CODE_VARIANTS]) {
                 const size_t len = std::strlen(CODE_NAMES[c]);
                 if (len >= 3 && std::strcmp(CODE_NAMES[c] + len - 3, "ILi") == 0) {      // templated: ...ILi<number>E
                     const int number = std::atoi(hit + len);
-                    variant = number == 256 ? 0 : number == 1024 ? 1 : number;
+                    variant = number == 256 ? 0 : number == 1024 ? 1 : number == 512 ? 2 : number;
                 }
                 if (variant < 0 || variant >= CODE_VARIANTS) continue;
                 int& slot = bytes[c][variant];
@@ -980,9 +980,17 @@ static int run_clipped_sumsq(mgx_handle* h, const float* mid, long long piece, i
 }
 
 // look-back words and control block of a limiter launch over n frames (allocated, not initialised)
+// blocks per limiter chunk: the rule of host_params.h, unless MGX_LIMIT_THREADS = 256 / 512 / 1024 asks otherwise
+// (measurement aid; read where the parameters are derived so that an A/B inside one process sees it)
+static void limiter_threads_from_environment() {
+    const char* e = std::getenv("MGX_LIMIT_THREADS");
+    const int v = e ? std::atoi(e) : 0;
+    limiter_threads_wish() = (v == 256 || v == 512 || v == 1024) ? v : 0;
+}
 static int limiter_state(mgx_handle* h, long long n, const mgx_config* cfg, unsigned long long** published,
                          long long* words, int** ticket) {
     LimiterParams lp;
+    limiter_threads_from_environment();
     const std::string err = limiter_params(*cfg, lp);
     if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
     const long long nchunks = (n + lp.geo.chunk - 1) / lp.geo.chunk;
@@ -1036,6 +1044,15 @@ static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
         const size_t lds = LimiterBlock<1024>::LDS_BYTES;
         MGX_TRY((allow_lds(k_limit<1024, 1>, lds)));
         hipLaunchKernelGGL((k_limit<1024, 1>), grid, dim3(1024), lds, h->stream, a);
+    } else if (threads == 512) {
+        const size_t lds = LimiterBlock<512>::LDS_BYTES;
+        if (a.hw == 96 && a.hb == 95 && a.gr == 55 && a.gl == 12 && a.gw == 6) {          // 96 kHz (BASELINE config #5)
+            MGX_TRY((allow_lds(k_limit<512, 2, 96, 95, 55>, lds)));
+            hipLaunchKernelGGL((k_limit<512, 2, 96, 95, 55>), grid, dim3(512), lds, h->stream, a);
+        } else {
+            MGX_TRY((allow_lds(k_limit<512, 2>, lds)));
+            hipLaunchKernelGGL((k_limit<512, 2>), grid, dim3(512), lds, h->stream, a);
+        }
     } else {
         launch_limiter_256(a, grid, h->stream);
     }
@@ -1047,6 +1064,7 @@ static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
 static int limiter_args(mgx_handle* h, const float* y, long long n, const mgx_config* cfg, const double* gain_dev,
                         const double* post_dev, const int* active_dev, float* out, LimiterArgs& a, int* threads,
                         LimiterParams& lp) {
+    limiter_threads_from_environment();
     const std::string err = limiter_params(*cfg, lp);
     if (!err.empty()) return fail(MGX_ERR_UNSUPPORTED, err);
     if (n < 8) return fail(MGX_ERR_ARGUMENT, "limiter input too short");
@@ -1627,10 +1645,11 @@ static int master_impl(mgx_handle* h, const float* target_dev, int64_t n_target,
                        int64_t n_reference, const mgx_config* cfg, const float* fir_given, float* result_dev,
                        float* result_no_limiter_dev, float* result_no_limiter_normalized_dev, mgx_report* report);
 // every launch of one stages.main, queued on the handle's stream (no host round trip)
-static int dev_repeat(const char* name) {
+static int dev_repeat_default(const char* name, int fallback) {
     const char* e = std::getenv(name);
-    return e ? std::max(1, std::atoi(e)) : 1;
+    return e ? std::max(1, std::atoi(e)) : fallback;
 }
+static int dev_repeat(const char* name) { return dev_repeat_default(name, 1); }
 static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
     const float* target_dev = c.target;
     const float* reference_dev = c.reference;
@@ -1681,7 +1700,7 @@ static int queue_master(mgx_handle* h, const mgx_handle::MasterCall& c) {
         ra.mid = (const float*)h->mid.p;
         ra.piece = tw.piece;
         ra.divisions = tw.divisions;
-        ra.chunks = std::max(1, 1024 / tw.divisions);        // ~1000 workgroups: each pays one publish + ticket
+        ra.chunks = std::max(1, dev_repeat_default("MGX_ROUND_WGS", 1024) / tw.divisions);     // ~1000 workgroups: each pays one publish + ticket
         // (round 0's partial sums, and behind them the peak words of k_correction_tail's workgroups)
         MGX_TRY(ensure(h, h->partial, (size_t)2 * ra.divisions * ra.chunks * sizeof(double)));
         ra.partial = (double*)h->partial.p;

@@ -10,6 +10,7 @@
 #include "conv2_kernel.h"
 #include "conv_delay_kernel.h"
 #include "conv_wide_kernel.h"
+#include "fft2_lanes.h"
 #include "fir_plan.h"
 #include "limiter_general.h"
 
@@ -34,6 +35,50 @@ __device__ __forceinline__ void pass_sync() {
     if constexpr (F::WAVE_LOCAL) asm volatile("" ::: "memory");
     else lds_barrier();
 #endif
+}
+
+// The middle passes of a transform, forward and inverse, as the kernels below call them (each followed / preceded by
+// the pass_sync the separate passes had).  A four-pass plan (16384 points) runs its two radix-8 passes as ONE phase
+// with the exchange between them in the wave's lanes (fft2_lanes.h: bit-identical results, one LDS round trip and one
+// wait fewer per direction: k_conv_wide<14> 144.3 -> 139.4 us, k_conv_delay<14> 238.5 -> 232.7, profiles/r06_b_*);
+// -DMGX_SEPARATE_MID_PASSES builds the two-phase form for an A/B.  LANES = false: kernels that hold an accumulator row
+// or a second transform's registers across the middle passes (k_conv<14>, the two- and four-transform analysis) keep
+// the two-phase form -- both butterflies of a thread alive at once is 16 registers they do not have.
+template <class F, bool LANES = true>
+__device__ __forceinline__ void fwd_middle_passes(int tid, float2* lds, const float2* mid_table) {
+#ifndef MGX_SEPARATE_MID_PASSES
+    if constexpr (F::P == 4 && LANES) {
+        Fft2Lanes<ilog2(F::N)>::fwd_mid_fused(tid, lds, mid_table);
+        pass_sync<F>();
+        return;
+    }
+#endif
+    if constexpr (F::P >= 3) {
+        F::fwd_mid(tid, lds, mid_table);
+        pass_sync<F>();
+    }
+    if constexpr (F::P == 4) {
+        F::fwd_mid2(mgx_opaque(tid), lds, mid_table);
+        pass_sync<F>();
+    }
+}
+template <class F, bool LANES = true>
+__device__ __forceinline__ void inv_middle_passes(int tid, float2* lds, const float2* mid_table) {
+#ifndef MGX_SEPARATE_MID_PASSES
+    if constexpr (F::P == 4 && LANES) {
+        pass_sync<F>();
+        Fft2Lanes<ilog2(F::N)>::inv_mid_fused(tid, lds, mid_table);
+        return;
+    }
+#endif
+    if constexpr (F::P == 4) {
+        pass_sync<F>();
+        F::inv_mid2(tid, lds, mid_table);
+    }
+    if constexpr (F::P >= 3) {
+        pass_sync<F>();
+        F::inv_mid(mgx_opaque(tid), lds, mid_table);
+    }
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -200,23 +245,9 @@ __device__ __forceinline__ void conv_channel(int tid, const Conv2Args& a, float2
     __builtin_amdgcn_sched_barrier(0);
     CB::fetch_filter(tid, SIDE ? a.h_side : a.h_mid, rf);      // a phase early: the middle pass hides its latency
     __syncthreads();
-    if (F::P >= 3) {
-        CB::phase_fwd_mid(opaque(tid), lds, mid_table);
-        pass_sync<F>();
-    }
-    if (F::P == 4) {
-        CB::phase_fwd_mid2(opaque(tid), lds, mid_table);
-        pass_sync<F>();
-    }
+    fwd_middle_passes<F, false>(opaque(tid), lds, mid_table);
     CB::phase_filter(tid, rf, lds);
-    if (F::P == 4) {
-        pass_sync<F>();
-        CB::phase_inv_mid2(opaque(tid), lds, mid_table);
-    }
-    if (F::P >= 3) {
-        pass_sync<F>();
-        CB::phase_inv_mid(opaque(tid), lds, mid_table);
-    }
+    inv_middle_passes<F, false>(opaque(tid), lds, mid_table);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);      // keeps the next phase's LDS reads from being lifted into this one
 }
@@ -239,14 +270,7 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
         __builtin_amdgcn_sched_barrier(0);
         if (!LATE_FILTER) CB::fetch_filter(tid, h + (size_t)k * F::N, rf);
         __syncthreads();
-        if (F::P >= 3) {
-            CB::phase_fwd_mid(opaque(tid), lds, mid_table);
-            pass_sync<F>();
-        }
-        if (F::P == 4) {
-            CB::phase_fwd_mid2(opaque(tid), lds, mid_table);
-            pass_sync<F>();
-        }
+        fwd_middle_passes<F, false>(opaque(tid), lds, mid_table);
         __builtin_amdgcn_sched_barrier(0);
         if (LATE_FILTER) CB::fetch_filter(opaque(tid), h + (size_t)k * F::N, rf);
         CB::phase_accumulate(tid, rf, lds, acc);
@@ -255,14 +279,7 @@ __device__ __forceinline__ void conv_channel_partitioned(int tid, long long pair
     }
     CB::phase_finish_row(tid, acc, lds);
     __builtin_amdgcn_sched_barrier(0);
-    if (F::P == 4) {
-        pass_sync<F>();
-        CB::phase_inv_mid2(opaque(tid), lds, mid_table);
-    }
-    if (F::P >= 3) {
-        pass_sync<F>();
-        CB::phase_inv_mid(opaque(tid), lds, mid_table);
-    }
+    inv_middle_passes<F, false>(opaque(tid), lds, mid_table);
     __syncthreads();
 }
 
@@ -404,14 +421,7 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         CD::phase_pass0_held(opaque(tid), ps, held, newer, lds);       // (the newer half was asked for a block ago)
         lds_barrier();
         DEV_CONV_MARK(0);                   // frames, pass 0, barrier
-        if (F::P >= 3) {
-            CB::phase_fwd_mid(opaque(tid), lds, mid_table);
-            pass_sync<F>();
-        }
-        if (F::P == 4) {
-            CB::phase_fwd_mid2(opaque(tid), lds, mid_table);
-            pass_sync<F>();
-        }
+        fwd_middle_passes<F>(opaque(tid), lds, mid_table);
         __builtin_amdgcn_sched_barrier(0);
         DEV_CONV_MARK(1);                   // middle passes
         CD::phase_row(opaque(tid), lds);
@@ -426,14 +436,7 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
             continue;
         }
         CD::phase_row_back(opaque(tid), lds);
-        if (F::P == 4) {
-            pass_sync<F>();
-            CB::phase_inv_mid2(opaque(tid), lds, mid_table);
-        }
-        if (F::P >= 3) {
-            pass_sync<F>();
-            CB::phase_inv_mid(opaque(tid), lds, mid_table);
-        }
+        inv_middle_passes<F>(opaque(tid), lds, mid_table);
         // the newer half of the next block's window: asked for here, its latency under the last inverse pass and the
         // stores (asked for a phase earlier, behind the multiply, it costs 24 B more scratch and 11 us)
         CD::template fetch_half<CD::R0 / 2>(opaque(tid), b + 1, a, newer);
@@ -447,9 +450,19 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
     }
 }
 
-// F taps on N = 4F blocks (conv_wide_kernel.h): workgroup w takes blocks w, w + G, w + 2G, ... and asks for the frames of
-// its next block while the current one is in its inverse transform.  a.npairs counts BLOCKS of 3N/4 frames here and
-// pair_peak has one entry per block.
+// F taps on N = 4F blocks (conv_wide_kernel.h): every workgroup takes one block per round of the grid and asks for the
+// frames of its next block while the current one is in its inverse transform.  a.npairs counts BLOCKS of 3N/4 frames
+// here and pair_peak has one entry per block.
+// Which block: workgroup w is (observed to be) placed on XCD w % 8.  Round i covers blocks [i G, (i + 1) G) in eight runs
+// of G / 8 consecutive blocks, one run per XCD, so that a block and its neighbour -- whose windows share N / 4 frames --
+// are fetched through the same L2 (until round 6: blocks w, w + G, ... -- neighbours on different XCDs, the shared quarter
+// fetched from HBM twice: FETCH_SIZE 112 MiB x 2 for 169 MB of frames).  Placement affects speed only.
+__device__ __forceinline__ long long conv_wide_block(unsigned w, unsigned round, unsigned grid) {
+#ifndef MGX_CONV_WIDE_STRIDED
+    if ((grid & 7u) == 0) return ((long long)round * 8 + (w & 7u)) * (grid >> 3) + (w >> 3);
+#endif
+    return (long long)round * grid + w;
+}
 template <int LOG2N>
 __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) void k_conv_wide(Conv2Args a) {
     warm_code(CODE_CONV, CODE_VARIANT_CONV_WIDE);
@@ -464,9 +477,11 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
     typename CB::Persist ps;
     CB::load_persist(tid, a.tw, mid_table, ps);
     typename CW::Frames frames;
-    CW::fetch(tid, blockIdx.x, a, frames);
+    CW::fetch(tid, conv_wide_block(blockIdx.x, 0, gridDim.x), a, frames);
     __syncthreads();
-    for (long long b = blockIdx.x; b < a.npairs; b += gridDim.x) {
+    for (unsigned round = 0;; ++round) {
+        const long long b = conv_wide_block(blockIdx.x, round, gridDim.x);
+        if (b >= a.npairs) break;
         // (as in k_conv: nothing derived from the pass-0 twiddles or the thread id may be hoisted out of the loop)
 #pragma unroll
         for (int q = 0; q < F::LB0; ++q) asm volatile("" : "+v"(ps.tw0.b[q].x), "+v"(ps.tw0.b[q].y));
@@ -477,14 +492,7 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         CW::phase_pass0(opaque(tid), ps, frames, lds);
         lds_barrier();
         DEV_CONV_MARK(0);                   // pass 0, barrier
-        if (F::P >= 3) {
-            CB::phase_fwd_mid(opaque(tid), lds, mid_table);
-            pass_sync<F>();
-        }
-        if (F::P == 4) {
-            CB::phase_fwd_mid2(opaque(tid), lds, mid_table);
-            pass_sync<F>();
-        }
+        fwd_middle_passes<F>(opaque(tid), lds, mid_table);
         __builtin_amdgcn_sched_barrier(0);
         DEV_CONV_MARK(1);                   // middle passes
         typename CW::Filters filt;
@@ -497,17 +505,10 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         __builtin_amdgcn_sched_barrier(0);
         DEV_CONV_MARK(3);                   // multiply, barrier
         CW::phase_row_back(opaque(tid), lds);
-        if (F::P == 4) {
-            pass_sync<F>();
-            CB::phase_inv_mid2(opaque(tid), lds, mid_table);
-        }
-        if (F::P >= 3) {
-            pass_sync<F>();
-            CB::phase_inv_mid(opaque(tid), lds, mid_table);
-        }
+        inv_middle_passes<F>(opaque(tid), lds, mid_table);
         // the next block's window: its latency under the last inverse pass and the stores -- the barriers from here
         // to the top of the loop order LDS traffic only (a __syncthreads() would wait for these loads)
-        CW::fetch(opaque(tid), b + gridDim.x, a, frames);
+        CW::fetch(opaque(tid), conv_wide_block(blockIdx.x, round + 1, gridDim.x), a, frames);
         lds_barrier();
         DEV_CONV_MARK(4);                   // row back, inverse middle passes, barrier
         const float pk = CW::phase_store(opaque(tid), b, a, ps, lds);
@@ -533,14 +534,7 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_wide_prep(const float
     CB::load_persist(tid, tw, mid_table, ps);
     CW::phase_load_taps(tid, taps + (size_t)ch * CW::TAPS, ps, lds);
     __syncthreads();
-    if (F::P >= 3) {
-        CB::phase_fwd_mid(tid, lds, mid_table);
-        pass_sync<F>();
-    }
-    if (F::P == 4) {
-        CB::phase_fwd_mid2(tid, lds, mid_table);
-        pass_sync<F>();
-    }
+    fwd_middle_passes<F>(tid, lds, mid_table);
     CB::phase_write_filter(tid, lds, (float)(g / (double)F::N), tables + (size_t)ch * F::N);
 }
 
@@ -561,14 +555,7 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T)) void k_conv_prep(const float* tap
     CB::load_persist(tid, tw, mid_table, ps);
     CB::phase_load_taps(tid, taps + ((size_t)ch * parts + k) * CB::TAPS, ps, lds);
     __syncthreads();
-    if (F::P >= 3) {
-        CB::phase_fwd_mid(tid, lds, mid_table);
-        pass_sync<F>();
-    }
-    if (F::P == 4) {
-        CB::phase_fwd_mid2(tid, lds, mid_table);
-        pass_sync<F>();
-    }
+    fwd_middle_passes<F>(tid, lds, mid_table);
     CB::phase_write_filter(tid, lds, (float)(g / (double)F::N), tables + ((size_t)ch * parts + k) * F::N);
 }
 
@@ -630,14 +617,7 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
         AB::fetch(tid, (long long)d * a.piece + (long long)s * F::N, a, raw);
         AB::phase_load(tid, raw, ps, th, lds);
         lds_barrier();
-        if (F::P >= 3) {
-            AB::phase_fwd_mid(tid, lds, mid_table);
-            pass_sync<F>();
-        }
-        if (F::P == 4) {
-            AB::phase_fwd_mid2(tid, lds, mid_table);
-            pass_sync<F>();
-        }
+        fwd_middle_passes<F>(tid, lds, mid_table);
         typename AB::Row own;
         AB::phase_row(tid, own, lds);
         lds_barrier();
@@ -687,28 +667,14 @@ __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) v
         const long long start = (long long)d * a.piece + (long long)s * 2 * F::N;
         AD::template phase_load<false>(tid, start, a, ps, th, lds);
         lds_barrier();
-        if (F::P >= 3) {
-            AD::AB::phase_fwd_mid(tid, lds, mid_table);
-            pass_sync<F>();
-        }
-        if (F::P == 4) {
-            AD::AB::phase_fwd_mid2(tid, lds, mid_table);
-            pass_sync<F>();
-        }
+        fwd_middle_passes<F, false>(tid, lds, mid_table);
         AD::phase_row(tid, lds);
         lds_barrier();
         AD::template phase_magnitudes<false>(tid, th, lds);
         lds_barrier();
         AD::template phase_load<true>(tid, start, a, ps, th, lds);
         lds_barrier();
-        if (F::P >= 3) {
-            AD::AB::phase_fwd_mid(tid, lds, mid_table);
-            pass_sync<F>();
-        }
-        if (F::P == 4) {
-            AD::AB::phase_fwd_mid2(tid, lds, mid_table);
-            pass_sync<F>();
-        }
+        fwd_middle_passes<F, false>(tid, lds, mid_table);
         AD::phase_row(tid, lds);
         lds_barrier();
         AD::template phase_magnitudes<true>(tid, th, lds);
@@ -756,14 +722,7 @@ __global__ __launch_bounds__(Fft2<LOG2H>::T, analysis_waves_per_simd<LOG2H>()) v
     AQ::AB::chunk_segments(a, ch, s0, s1);
     auto transform = [&]() {
         lds_barrier();
-        if (F::P >= 3) {
-            AQ::AB::phase_fwd_mid(opaque(tid), lds, mid_table);
-            pass_sync<F>();
-        }
-        if (F::P == 4) {
-            AQ::AB::phase_fwd_mid2(opaque(tid), lds, mid_table);
-            pass_sync<F>();
-        }
+        fwd_middle_passes<F, false>(opaque(tid), lds, mid_table);
         AQ::phase_row(opaque(tid), lds);
         lds_barrier();
     };
@@ -2993,7 +2952,7 @@ __global__ __launch_bounds__(256, 2) void k_limit_general(LimiterArgs a, General
 // instantiation (-1) otherwise; the results are the same to the bit.
 template <int T, int WGS, int HW = -1, int HB = -1, int GR = -1>
 __global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a0) {
-    warm_code(CODE_LIMIT, T == 256 ? 0 : 1);
+    warm_code(CODE_LIMIT, T == 256 ? 0 : T == 1024 ? 1 : 2);
     using LB = LimiterBlock<T>;
     LimiterArgs a = a0;
     if (HW >= 0) {
