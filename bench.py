@@ -18,7 +18,8 @@ Workloads (BASELINE.json configs):
   8min_fir_only   configs[1]  the same pair, limiter bypassed (``result_no_limiter`` only)
   4min_x8_full    configs[3]  one GPU's share of "64 four-minute pairs over 8 GPUs": eight pairs per step,
                               submitted to three device handles (three HIP streams) -- the default for N > 1
-  96k_16k_full    configs[4]  one 4-minute 96 kHz pair with a 16384-tap FIR (partitioned overlap-save)
+  96k_16k_full    configs[4]  one 4-minute 96 kHz pair with a 16384-tap FIR (frequency-domain delay line)
+  96k_16k_x16_full configs[4] one GPU's share of "batch 128 on 8 GPUs": sixteen such pairs per step through the lanes
 With N ranks every rank masters its own pairs (pairs are independent: no data-path collective, weak
 scaling); the FIR tables are all-gathered over RCCL after the timed region, the only traffic that
 crosses xGMI.
@@ -44,7 +45,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md)
 HBM_COPY_GBS = 6290.0          # measured float4 copy ceiling, same guide
 # SURVEY.md 8(d) byte models, bytes per target frame
-PIPELINE_BYTES = {"8min_full": 72, "8min_fir_only": 64, "4min_x8_full": 72, "96k_16k_full": 72}
+PIPELINE_BYTES = {"8min_full": 72, "8min_fir_only": 64, "4min_x8_full": 72, "96k_16k_full": 72, "96k_16k_x16_full": 72}
+LANE_WORKLOADS = {"4min_x8_full": (44100, 4096, 240.0, 8), "96k_16k_x16_full": (96000, 16384, 240.0, 16)}
+REPEAT_BLOCKS = 5              # further K-step blocks behind the one `value` is taken from (ms_per_step_repeats)
 KERNEL_BYTES = {"convolve": 16,    # S3: read 8 + write 8 (the mid plane's 4 B are booked to S4)
                 "limit": 16}       # read 8 + write 8 per launch of the one-pass limiter (S5's 24 B model
                                    # counts a second read that this kernel takes from the L2 / Infinity Cache)
@@ -68,7 +71,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto", choices=["auto"] + WORKLOADS,
-                    help="auto = 8min_full on one GPU, 4min_x8_full per rank on several")
+                    help="auto = 8min_full on one GPU, 4min_x8_full per rank on several (96k_16k_x16_full: config #5's "
+                         "per-GPU share, sixteen 96 kHz pairs per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the side workloads and the PCIe figure")
     ap.add_argument("--no-traffic", action="store_true",
@@ -185,8 +189,8 @@ class Workload:
         self.lanes = [self.dev]
         self.lane_choice = None
         self.sample_rate, self.fft, self.seconds, self.pairs = 44100, 4096, 480.0, 1
-        if name == "4min_x8_full":
-            self.seconds, self.pairs = 240.0, 8
+        if name in LANE_WORKLOADS:
+            self.sample_rate, self.fft, self.seconds, self.pairs = LANE_WORKLOADS[name]
             # two or three device handles, whichever a short measured batch says is faster on THIS GPU
             # (batch.choose_lanes: a pair's latency-bound stretches -- FIR design, level decisions, the
             # limiter's look-back waits -- are filled by the other pairs' kernels; boxes of the pool disagree
@@ -207,8 +211,20 @@ class Workload:
         self.want_limiter = name != "8min_fir_only"
         self.jobs = []
         self.host_pair = None
+        # (sixteen 96 kHz pairs are a minute of host synthesis: four are synthesised, the other twelve are those with
+        # the channels swapped and / or the target a little quieter -- distinct audio, distinct level decisions and
+        # FIRs, the same kernels and bytes)
+        self.synthesised = min(self.pairs, 4) if name == "96k_16k_x16_full" else self.pairs
+        base = []
         for k in range(self.pairs):
-            target, reference = make_pair(self.seconds, self.sample_rate, pair=rank * self.pairs + k)
+            if k < self.synthesised:
+                target, reference = make_pair(self.seconds, self.sample_rate, pair=rank * self.pairs + k)
+                base.append((target, reference))
+            else:
+                bt, br = base[k % self.synthesised]
+                variant = k // self.synthesised
+                target = np.ascontiguousarray(bt[:, ::-1] if variant & 1 else bt) * np.float32(1.0 - 0.03 * variant)
+                reference = np.ascontiguousarray(br[:, ::-1]) if variant & 2 else br
             if k == 0:
                 self.host_pair = (target, reference)
             d = self.lanes[k % len(self.lanes)]
@@ -228,9 +244,13 @@ class Workload:
             d.synchronize()
 
     def describe(self):
-        if self.name == "4min_x8_full":
-            what = (f"8 x 240 s stereo 44100 Hz pairs per GPU (config #4's per-GPU share), {len(self.lanes)} device "
-                    f"handles (measured choice)")
+        if self.name in LANE_WORKLOADS:
+            which = "#4" if self.name == "4min_x8_full" else "#5"
+            what = (f"{self.pairs} x {self.seconds:.0f} s stereo {self.sample_rate} Hz pairs per GPU (config {which}'s per-GPU "
+                    f"share), {len(self.lanes)} device handles (measured choice)")
+            if self.synthesised < self.pairs:
+                what += (f"; {self.synthesised} pairs synthesised, the others derived from them (channels swapped, target "
+                         f"scaled)")
         else:
             what = f"{self.seconds:.0f} s stereo {self.sample_rate} Hz pair per GPU"
         tail = "full pipeline incl. Hyrax limiter" if self.want_limiter else "matching-EQ FIR only (limiter bypassed)"
@@ -339,6 +359,13 @@ class StandIn:
 
     name, frames, pairs, lane_choice = "stand_in", 44100, 1, None
 
+    def __init__(self, stands_for="auto"):
+        self.stands_for = stands_for
+        self.fft = 16384 if stands_for.startswith("96k_16k") else 4096
+        if stands_for in LANE_WORKLOADS:
+            rate, _, seconds, self.pairs = LANE_WORKLOADS[stands_for]
+            self.frames = int(rate * seconds) * self.pairs
+
     def step(self):
         time.sleep(0.001)
 
@@ -346,7 +373,8 @@ class StandIn:
         pass
 
     def describe(self):
-        return "stand-in: no GPU, one step = 1 ms of sleep (plumbing test of the multi-rank path)"
+        return (f"stand-in for {self.stands_for}: no GPU, one step = 1 ms of sleep (plumbing test of the multi-rank path; "
+                f"frames and pairs per step are the workload's)")
 
 
 def share_one_gpu_over_rccl(rank):
@@ -390,7 +418,7 @@ def run(args, ranks):
         "launch": "self" if os.environ.get("MGX_BENCH_SELF_LAUNCHED") else ("launcher" if ranks.world > 1 else "single"),
     }
     if args.stand_in:
-        wl, lib, name, sharing = StandIn(), None, "stand_in", False
+        wl, lib, name, sharing = StandIn(args.workload), None, "stand_in", False
     else:
         import matchering_amd as mg
         from matchering_amd._native import check, library
@@ -405,7 +433,7 @@ def run(args, ranks):
         if name == "auto":
             name = "8min_full" if ranks.world == 1 else "4min_x8_full"
         lanes = args.lanes
-        if name == "4min_x8_full" and lanes <= 0 and ranks.world > 1:
+        if name in LANE_WORKLOADS and lanes <= 0 and ranks.world > 1:
             # ONE calibration per job, not one per rank: rank 0 measures two handles against three on its GPU (the GPUs
             # of a node are one model) while the others wait at a barrier, and every rank adopts the choice
             from matchering_amd.batch import choose_lanes, lane_choice_report
@@ -417,11 +445,16 @@ def run(args, ranks):
             decided = ranks.gather(mine)[0]
             lanes = int(decided["lanes"])
         wl = Workload(name, ranks.rank, ranks.local, mg, Device, device_count, make_pair, world=ranks.world, lanes=lanes)
-        if name == "4min_x8_full" and args.lanes <= 0 and ranks.world > 1:
+        if name in LANE_WORKLOADS and args.lanes <= 0 and ranks.world > 1:
             wl.lane_choice = decided
     spun = spin_up(wl.sync, wl.step, args.spinup)
     own_seconds = []
     elapsed = timed_steps(ranks, wl.sync, wl.step, args.steps, args.warmup, own_seconds)
+    # REPEAT_BLOCKS further blocks of the same K steps, each between its own two barriers: `value` stays the FIRST block
+    # (so that `steps` says what it was measured on), the spread of all of them stands beside it
+    blocks_ms = [elapsed / args.steps * 1e3]
+    for _ in range(REPEAT_BLOCKS):
+        blocks_ms.append(timed_steps(ranks, wl.sync, wl.step, args.steps, 0) / args.steps * 1e3)
     frames_total = wl.frames * args.steps * ranks.world
     value = frames_total / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
@@ -440,6 +473,10 @@ def run(args, ranks):
 
     line.update({
         "value": round(value, 2), "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_repeats": {"min": round(min(blocks_ms), 4), "median": round(statistics.median(blocks_ms), 4),
+                                "max": round(max(blocks_ms), 4), "blocks": len(blocks_ms),
+                                "note": f"{len(blocks_ms)} blocks of {args.steps} steps each, back to back, each between two "
+                                        "barriers (maximum over ranks); the first one is `ms_per_step` / `value`"},
         "spinup": {"seconds": args.spinup, "steps": spun, "recovered_calls": getattr(spin_up, "recovered", 0),
                    "note": "untimed steps before the W warm-up steps, so that the K timed steps see a busy device rather "
                            "than the climb out of idle; no measurable effect on the boxes seen so far"},
@@ -476,7 +513,9 @@ def run(args, ranks):
             if ranks.rank == 0:
                 check(lib.mgx_comm_unique_id(id_buf))
             uid = ranks.broadcast_bytes(id_buf.raw, 128)
+            t_init = time.perf_counter()
             check(lib.mgx_comm_init(dev.handle, ctypes.c_char_p(uid), ranks.rank, ranks.world))
+            exchange["init_s"] = time.perf_counter() - t_init
             seen = ctypes.c_int32()
             check(lib.mgx_comm_count(dev.handle, ctypes.byref(seen)))
             taps_dev, taps = ctypes.c_void_p(), ctypes.c_int32()
@@ -491,6 +530,7 @@ def run(args, ranks):
             # every rank mastered its own pairs, so the gathered tables must differ from rank to rank
             distinct = len({firs[r].tobytes() for r in range(ranks.world)})
             exchange["result"] = {"bytes_per_rank": count * 4, "ok": ok, "ranks_seen": int(seen.value),
+                                  "rccl_init_s": round(exchange.get("init_s", 0.0), 3),
                                   "distinct_tables": distinct,
                                   "transport": ("loop-back sockets (ranks share a GPU: NCCL_HOSTID made distinct per rank)"
                                                 if sharing else "RCCL default (xGMI peer-to-peer between the node's GPUs)")}
@@ -511,8 +551,21 @@ def run(args, ranks):
         # (every rank gets here within its 120 s, stuck or not, so this gather cannot wait for a missing one)
         everyone = ranks.gather(mine)                          # the line carries rank 0's view and how many ranks agree
         line["rccl_fir_allgather"] = dict(everyone[0], ranks_ok=sum(1 for e in everyone if e.get("ok")))
+        # the slowest rank's ncclCommInitRank: a box on which RCCL takes minutes to come up shows HERE, not in a timeout
+        line["rccl_init_s"] = max((e.get("rccl_init_s") or 0.0) for e in everyone)
     elif ranks.world > 1:
         line["rendezvous"] = {"ranks_seen": len(ranks.gather(ranks.rank)), "transport": "matchering_amd.ranks"}
+        # the exchange's shape without RCCL: every rank's (fake) FIR pair, 2 x fft_size float32, gathered over the
+        # rendezvous socket -- what the GPU path all-gathers over xGMI
+        count = 2 * wl.fft
+        t_init = time.perf_counter()
+        tables = ranks.gather(np.full(count, float(ranks.rank + 1), np.float32).tobytes())
+        line["rccl_fir_allgather"] = {"bytes_per_rank": count * 4, "ok": len(tables) == ranks.world and
+                                      all(len(t) == count * 4 for t in tables), "ranks_seen": len(tables),
+                                      "distinct_tables": len(set(tables)), "rccl_init_s": None,
+                                      "transport": "matchering_amd.ranks (stand-in: no RCCL without a GPU)",
+                                      "ranks_ok": len(tables)}
+        line["rccl_init_s"] = None
 
     if ranks.world > 1 and not stuck:
         # the SAME workload on one rank alone (the other ranks are idle, their GPUs too): the N = 1 point of a scaling
@@ -589,6 +642,11 @@ def run(args, ranks):
                 line["file_to_file"] = file_to_file(mg, wl.host_pair)
             except Exception as exc:        # noqa: BLE001 -- an unwritable temp folder must not lose the measurement
                 line["file_to_file"] = {"error": repr(exc)}
+            try:
+                line["first_call"] = first_call(wl.host_pair)
+                line["first_call_ms"] = line["first_call"].get("first_call_ms")
+            except Exception as exc:        # noqa: BLE001
+                line["first_call"] = {"error": repr(exc)[:200]}
         if not args.no_cpu_baseline:
             # the timed workload's own output (first pair, as the last timed step left it in HBM), fetched before
             # anything else runs on the handle, against what the oracle computes from the same float32 inputs
@@ -606,6 +664,61 @@ def run(args, ranks):
         print(json.dumps(line), file=line_out, flush=True)
     if stuck:                       # (a rank still inside the collective would keep the others' teardown waiting)
         os._exit(0)
+
+
+FIRST_CALL_CHILD = r"""
+import time
+t_start = time.perf_counter()
+import json, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+target, reference = np.load({tp!r}), np.load({rp!r})
+t_loaded = time.perf_counter()
+import matchering_amd as mg
+from matchering_amd import stages
+t_imported = time.perf_counter()
+cfg = mg.Config()
+stages.main(target, reference, cfg)
+t_first = time.perf_counter()
+stages.main(target, reference, cfg)
+t_second = time.perf_counter()
+other = mg.Config(lowess_frac=0.04)          # another Config: its raw -> smooth operator is built anew, all else is warm
+stages.main(target, reference, other)
+t_third = time.perf_counter()
+print("FIRST " + json.dumps({{"import_ms": (t_imported - t_loaded) * 1e3, "first_main_ms": (t_first - t_imported) * 1e3,
+                             "second_main_ms": (t_second - t_first) * 1e3, "third_main_new_config_ms": (t_third - t_second) * 1e3}}))
+"""
+
+
+def first_call(pair):
+    """What the FIRST mastering of a fresh process costs (missing #5): the reference pays its whole cost
+    in every process() call (core.py:32-121); here the first call of a process also loads the code object, creates the
+    handle, fills the twiddle tables and the block pools and builds the Config's raw -> smooth operator -- none of which
+    is inside any other number of this line.  A child process: import -> first stages.main result on the workload's pair
+    (host arrays in, host arrays out), then the same call again (warm), then a call with another Config (only the
+    operator is new)."""
+    import shutil
+    import tempfile
+
+    folder = tempfile.mkdtemp(prefix="mgx_first_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        tp, rp = os.path.join(folder, "t.npy"), os.path.join(folder, "r.npy")
+        np.save(tp, pair[0])
+        np.save(rp, pair[1])
+        run = subprocess.run([sys.executable, "-c", FIRST_CALL_CHILD.format(root=ROOT, tp=tp, rp=rp)], capture_output=True,
+                             text=True, timeout=300)
+        if run.returncode != 0:
+            return {"error": run.stderr[-300:]}
+        got = json.loads(next(ln for ln in run.stdout.splitlines() if ln.startswith("FIRST "))[6:])
+    finally:
+        shutil.rmtree(folder, ignore_errors=True)
+    first = got["import_ms"] + got["first_main_ms"]
+    return {"first_call_ms": round(first, 1), "import_ms": round(got["import_ms"], 1),
+            "first_main_ms": round(got["first_main_ms"], 1), "second_main_ms": round(got["second_main_ms"], 1),
+            "operator_build_ms": round(max(0.0, got["third_main_new_config_ms"] - got["second_main_ms"]), 1),
+            "note": "fresh child process, from `import matchering_amd` to the first stages.main result on the 8-minute pair "
+                    "(pageable numpy in, pinned numpy out); second_main_ms = the same call again; operator_build_ms = a call "
+                    "with another Config minus that (only the Config's raw -> smooth operator is new)"}
 
 
 def file_to_file(mg, pair):
@@ -734,6 +847,7 @@ def reference_main(target, reference, sample_rate, fft, need, runs_budget_s=12.0
                                   need_no_limiter_normalized=need[2])
             runs.append(time.perf_counter() - t0)
     m = build_ref.manifest()
+    build_ref.unload()                   # (the stub modules and the staged package leave this process again)
     import platform
 
     import scipy
@@ -794,13 +908,16 @@ def cpu_baseline(wl, name, all_cores=True):
                "port": dict(port, port_over_reference_seconds=round(cpu_s / ref_s, 3),
                             max_abs_difference_from_reference=float(np.abs(gap).max())),
                "note": "kind 'reference': sergree/matchering's own stages.main, byte-compiled from /root/reference by "
-                       "oracle/build_ref.py and shipped under oracle/_ref/ (git-ignored); `port` is the oracle on the same pair"}
+                       "oracle/build_ref.py under oracle/_ref/ (git- and gpurun-ignored: only where /root/reference exists); "
+                       "`port` is the oracle on the same pair"}
     else:
         out = dict(port, kind="port", host=host,
                    sample=f"the workload's first pair ({n} frames), best of {len(runs)} runs of oracle/mastering_oracle.py "
                           f"({sum(runs):.0f} s of CPU work)",
-                   note=f"kind 'port': no staged reference on this box ({why_not}); this is the oracle, not "
-                        f"sergree/matchering itself")
+                   note="kind 'port': the oracle (oracle/mastering_oracle.py), not sergree/matchering itself -- a Python "
+                        "reference does not travel to the GPU box in any form; port_vs_reference = both timed on ONE host "
+                        "(the build container, tools/cpu_port_vs_reference.py) and the largest difference of their outputs "
+                        f"on the 8-minute pair ({why_not})")
         ratio_path = os.path.join(ROOT, "profiles", "cpu_port_vs_reference.json")
         if os.path.exists(ratio_path):
             with open(ratio_path) as fh:

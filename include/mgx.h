@@ -35,7 +35,12 @@ enum mgx_status {
     MGX_ERR_HIP = -2,          /* HIP runtime error (message has the hipError name) */
     MGX_ERR_NO_DEVICE = -3,    /* no usable GPU: there is NO CPU fallback */
     MGX_ERR_UNSUPPORTED = -4,  /* valid for the reference but not implemented here */
-    MGX_ERR_RCCL = -5
+    MGX_ERR_RCCL = -5,
+    MGX_ERR_RETRY = -6         /* a bounded device-side wait expired (the GPU is shared with somebody else's kernels); the
+                                  outputs of the calls since the last synchronisation are not valid, the handle has
+                                  switched to the mode that cannot wait for ever, and the same call succeeds when made
+                                  again.  Blocking calls retry by themselves where nothing of the failed run has
+                                  reached the host; this code is for the asynchronous ones. */
 };
 
 /* matchering/defaults.py:25-58 LimiterConfig + :61-155 Config, the fields the
@@ -118,8 +123,14 @@ int mgx_timer_stop(mgx_handle* h, float* milliseconds);
  * before the GPU has finished (mgx_synchronize to wait); with a report it waits
  * itself and fills it.
  * Limits (MGX_ERR_UNSUPPORTED, never a silent approximation): fft_size in
- * [8, 65536]; limiter filter orders 1 or 2; lowess_it in [0, 64]; tracks up to 536 million
- * frames (32-bit byte offsets; 3.3 hours at 44.1 kHz). */
+ * [8, 65536]; lowess_it in [0, 64]; tracks up to 536 million frames (32-bit byte
+ * offsets; 3.3 hours at 44.1 kHz); limiter hold / release filters (defaults.py:48-56
+ * accepts any positive order, hyrax.py:61-73 runs it) of order 1 to 3 whose
+ * transfer-function form is well conditioned: a filter of order n at fc Hz is refused
+ * when the rounding noise of the reference's own float64 recursion, about
+ * 1.1e-16 / (2 pi fc / fs)^(n - 1/2) of full scale, exceeds 1e-6 -- there is then no
+ * well-defined output to be within 1e-5 of (at the default cut-offs: hold order 3
+ * runs, release order 3 does not; tests/test_limiter_order3_conditioning.py). */
 int mgx_master(mgx_handle* h, const float* target_dev, int64_t n_target,
                const float* reference_dev, int64_t n_reference, const mgx_config* cfg,
                float* result_dev, float* result_no_limiter_dev,

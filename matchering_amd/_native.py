@@ -126,12 +126,21 @@ SYMBOLS = {
 STAGES = ("analyze", "design_fir", "filter_spectra", "convolve", "correct_levels", "scale_outputs", "limit")
 
 
+ERR_RETRY = -6          # enum mgx_status MGX_ERR_RETRY (include/mgx.h)
+
+
 class MgxError(RuntimeError):
     """A libmgx call failed; ``code`` is the negative mgx_status."""
 
     def __init__(self, code, message):
         super().__init__(f"libmgx error {code}: {message}")
         self.code = code
+
+    @property
+    def retry(self):
+        """The handle recovered from a device-side wait that expired (the GPU is shared): what was queued since the
+        last synchronisation is lost, the same calls made again succeed (``MGX_ERR_RETRY``)."""
+        return self.code == ERR_RETRY
 
 
 _lib = None

@@ -2,6 +2,8 @@
 // by the HIP library and the CPU emulation harness).
 #pragma once
 
+#include <cstdio>
+
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -55,13 +57,66 @@ inline void butter_tf(int order, double fc, double fs, double* b, double* a) {
     }
 }
 
-// an order-K section (limiter_general.h) from a filter of order <= K, and the powers of its state matrix
+// ---- the shifted basis of limiter_general.h ("state maps"), from a section's float64 coefficients ---------------
+// order k <= K; d = 2 pi fc / fs.  With m = k-1-i, t = k-1-j (binomials C):
+//     w_i = d^m sum_j C(k-1-j, m) z_j            z_j = sum_i d^-(k-1-i) C(k-1-i, t) (-1)^(k-1-i-t) w_i
+//     w' = (I + dm) w + bd x:   dm[i][i+1] = d,   dm[i][0] -= d^-i S_{i+1},   S_s = sum_m a_m C(k-m, k-s)
+//     bd_i = d^m sum_j C(k-1-j, m) B_j,   B_j = b_{j+1} - a_{j+1} b_0
+// (S_k = p(1) ~ d^k: the sums cancel, which is why they are taken in extended precision from the float64 coefficients
+// the reference really uses -- exact to 1e-19 absolute, 1e-10 of their size.)  States beyond the filter's own order
+// (a lower-order filter carried in a K-state section) are identically zero: their rows and columns are left empty.
+struct ShiftedBasis {
+    std::vector<long double> step;      // [K][K]  I + dm on the leading k x k block, zero elsewhere
+    std::vector<long double> dm, zw;    // [K][K]
+    std::vector<long double> bd;        // [K]
+};
+inline long double binomial(int n, int r) {
+    if (r < 0 || r > n) return 0.0L;
+    long double v = 1.0L;
+    for (int i = 0; i < r; ++i) v = v * (long double)(n - i) / (long double)(i + 1);
+    return v;
+}
+inline ShiftedBasis shifted_basis(int k, int K, const double* b, const double* a, double fc, double fs) {
+    using W = long double;
+    const W d = 6.283185307179586476925286766559L * (W)fc / (W)fs;
+    ShiftedBasis s;
+    s.step.assign((size_t)K * K, 0.0L);
+    s.dm.assign((size_t)K * K, 0.0L);
+    s.zw.assign((size_t)K * K, 0.0L);
+    s.bd.assign(K, 0.0L);
+    auto dpow = [&](int e) { return std::pow(d, (W)e); };
+    for (int i = 0; i < k; ++i) {
+        const int m = k - 1 - i;
+        if (i + 1 < k) s.dm[(size_t)i * K + i + 1] = d;
+        W sum = 0.0L;                                         // S_{i+1}
+        for (int q = 0; q <= k; ++q) sum += (W)a[q] * binomial(k - q, k - (i + 1));
+        s.dm[(size_t)i * K] -= dpow(-i) * sum;
+        W bsum = 0.0L;
+        for (int j = 0; j < k; ++j) bsum += binomial(k - 1 - j, m) * ((W)b[j + 1] - (W)a[j + 1] * (W)b[0]);
+        s.bd[i] = dpow(m) * bsum;
+        for (int j = 0; j < k; ++j) {                         // z_j from w_i
+            const int t = k - 1 - j;
+            if (t <= m) s.zw[(size_t)j * K + i] = dpow(-m) * binomial(m, t) * (((m - t) & 1) ? -1.0L : 1.0L);
+        }
+    }
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) s.step[(size_t)i * K + j] = (i == j ? 1.0L : 0.0L) + s.dm[(size_t)i * K + j];
+    return s;
+}
+// an order-K section (limiter_general.h) from a filter of order <= K with its shifted-basis form
 template <int K>
-inline IirK<K> section_of(int order, const double* b, const double* a) {
+inline IirK<K> section_of(int order, const double* b, const double* a, const ShiftedBasis& sb) {
     IirK<K> f;
     for (int i = 0; i <= K; ++i) {
         f.b[i] = i <= order ? b[i] : 0.0;
         f.a[i] = i <= order ? a[i] : 0.0;
+    }
+    for (int i = 0; i < K; ++i) {
+        f.bd[i] = (double)sb.bd[i];
+        for (int j = 0; j < K; ++j) {
+            f.dm[i][j] = (double)sb.dm[(size_t)i * K + j];
+            f.zw[i][j] = (double)sb.zw[(size_t)i * K + j];
+        }
     }
     return f;
 }
@@ -77,15 +132,6 @@ inline void mat_mul(int k, const std::vector<Wide>& x, const std::vector<Wide>& 
             r[(size_t)i * k + j] = s;
         }
     out = r;
-}
-// state matrix of the transposed direct form II section: z' = A z + B x, A[i][0] = -a[i+1], A[i][i+1] = 1
-inline std::vector<Wide> state_matrix(int k, const double* a) {
-    std::vector<Wide> m((size_t)k * k, 0.0L);
-    for (int i = 0; i < k; ++i) {
-        m[(size_t)i * k] = -(Wide)a[i + 1];
-        if (i + 1 < k) m[(size_t)i * k + i + 1] = 1.0L;
-    }
-    return m;
 }
 inline std::vector<Wide> mat_identity(int k) {
     std::vector<Wide> r((size_t)k * k, 0.0L);
@@ -114,7 +160,9 @@ inline std::vector<double> block_powers(int k, const std::vector<Wide>& m) {
     }
     return out;
 }
-// (A^chunk)^m until its largest entry drops below 1e-10 (at least one, at most `cap`: empty = did not decay)
+// (A^chunk)^m until its largest entry drops below 1e-13 (at least one, at most `cap`: empty = did not decay).
+// (In the shifted basis the entries are O(1) times the decay -- no n^(K-1) factors as in the section's own basis, where
+// 1e-10 used to be conservative -- and the states' own sizes differ by powers of d: three decades of margin.)
 inline std::vector<double> lookback_matrices(int k, const std::vector<Wide>& m, int chunk, int cap) {
     const std::vector<Wide> step = mat_power(k, m, chunk);
     std::vector<double> out;
@@ -122,7 +170,7 @@ inline std::vector<double> lookback_matrices(int k, const std::vector<Wide>& m, 
     for (int n = 0; n < cap; ++n) {
         Wide big = 0.0L;
         for (Wide v : cur) big = std::fmax(big, std::fabs(v));
-        if (n > 0 && big <= 1e-10L) return out;
+        if (n > 0 && big <= 1e-13L) return out;
         append_rounded(out, cur);
         mat_mul(k, step, cur, cur);
     }
@@ -142,7 +190,8 @@ struct LimiterParams {
     double hold_b[LIMITER_MAX_ORDER + 1], hold_a[LIMITER_MAX_ORDER + 1];
     double rel_b[LIMITER_MAX_ORDER + 1], rel_a[LIMITER_MAX_ORDER + 1];
     int hold_order = 1, rel_order = 1;
-    std::vector<double> pow_hold, pow_rel, wk_hold, wk_rel;    // [17][K][K], [17][K][K], [n][K][K], [n][K][K]
+    std::vector<double> pow_hold, pow_rel, wk_hold, wk_rel;    // [17][K][K], [17][K][K], [n][K][K], [n][K][K] (shifted basis)
+    ShiftedBasis hold_sb, rel_sb;
     Iir1 att, hold_f, rel_f;
     int threads;                                   // blocks per chunk the limiter kernel runs with: 256 or 1024
     LimiterBlock<256>::Geometry geo;               // (the same struct for every T)
@@ -183,8 +232,34 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
     if (p.attack < 1) return "limiter attack shorter than one sample";
     if (p.hold < 3) return "limiter hold shorter than three samples (the reference's sliding window is empty there)";
     if (c.hold_filter_order < 1 || c.release_filter_order < 1) return "hold/release filter orders must be positive";
-    if (c.hold_filter_order > LIMITER_MAX_ORDER || c.release_filter_order > LIMITER_MAX_ORDER)
-        return "hold/release filter orders above 2 are not implemented (ill-conditioned in the reference's transfer-function form: limiter_general.h)";
+    // Routed by conditioning, not by order (limiter_general.h): the rounding noise of the reference's own float64
+    // recursion, ~1.1e-16 / d^(order - 1/2) with d = 2 pi fc / fs the poles' distance from z = 1, must stay under 1e-6
+    // of full scale -- above that there is no well-defined output to be within 1e-5 of.
+    {
+        const double two_pi = 6.283185307179586;
+        const struct { const char* name; int order; double fc; } filters[2] = {
+            {"hold", c.hold_filter_order, c.hold_filter_coefficient},
+            {"release", c.release_filter_order, c.release_filter_coefficient / c.release_ms}};
+        for (const auto& f : filters) {
+            if (f.order == 1) continue;
+            const double d = two_pi * f.fc / sr;
+            const double noise = d > 0.0 ? 1.1e-16 / std::pow(d, f.order - 0.5) : 1.0;
+            if (!(noise <= 1e-6)) {
+                char text[320];
+                std::snprintf(text, sizeof text,
+                              "%s filter of order %d at %.4g Hz is ill-conditioned in the reference's transfer-function form: its own "
+                              "float64 recursion carries rounding noise of ~%.1e of full scale (limit 1e-6; limiter_general.h) -- "
+                              "refused rather than approximated", f.name, f.order, f.fc, noise);
+                return text;
+            }
+            if (f.order > LIMITER_MAX_ORDER) {
+                char text[200];
+                std::snprintf(text, sizeof text, "%s filter order %d: the chunked limiter is built for orders up to %d", f.name,
+                              f.order, LIMITER_MAX_ORDER);
+                return text;
+            }
+        }
+    }
     p.hold_order = c.hold_filter_order;
     p.rel_order = c.release_filter_order;
     p.general = (p.hold_order > 1 || p.rel_order > 1) ? (p.hold_order > p.rel_order ? p.hold_order : p.rel_order) : 0;
@@ -232,7 +307,10 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
         butter_tf(p.rel_order, c.release_filter_coefficient / c.release_ms, sr, p.rel_b, p.rel_a);
         for (int i = p.hold_order + 1; i <= LIMITER_MAX_ORDER; ++i) p.hold_b[i] = p.hold_a[i] = 0.0;
         for (int i = p.rel_order + 1; i <= LIMITER_MAX_ORDER; ++i) p.rel_b[i] = p.rel_a[i] = 0.0;
-        const std::vector<Wide> mh = state_matrix(k, p.hold_a), mr = state_matrix(k, p.rel_a);
+        // block maps and chunk words live in the shifted basis (limiter_general.h): the powers are those of I + dm
+        p.hold_sb = shifted_basis(p.hold_order, k, p.hold_b, p.hold_a, c.hold_filter_coefficient, sr);
+        p.rel_sb = shifted_basis(p.rel_order, k, p.rel_b, p.rel_a, c.release_filter_coefficient / c.release_ms, sr);
+        const std::vector<Wide>&mh = p.hold_sb.step, &mr = p.rel_sb.step;
         p.pow_hold = block_powers(k, mh);
         p.pow_rel = block_powers(k, mr);
         p.wk_hold = lookback_matrices(k, mh, p.geo.chunk, 1 << 14);
@@ -283,8 +361,8 @@ inline long long limiter_words(const LimiterParams& p, long long nchunks) { retu
 template <int K>
 inline GeneralArgs<K> general_fill(const LimiterParams& p, const double* tables, unsigned long long* published, long long nchunks) {
     GeneralArgs<K> g;
-    g.hold = section_of<K>(p.hold_order, p.hold_b, p.hold_a);
-    g.rel = section_of<K>(p.rel_order, p.rel_b, p.rel_a);
+    g.hold = section_of<K>(p.hold_order, p.hold_b, p.hold_a, p.hold_sb);
+    g.rel = section_of<K>(p.rel_order, p.rel_b, p.rel_a, p.rel_sb);
     g.pow_hold = tables;
     g.pow_rel = g.pow_hold + p.pow_hold.size();
     g.w_hold = g.pow_rel + p.pow_rel.size();

@@ -1,11 +1,24 @@
-// Hold and release low-passes of order 2 (hyrax.py:55-73 with hold_filter_order /
-// release_filter_order = 2) inside the chunked limiter of limiter_kernel.h.  (Written for order K; see
-// LIMITER_MAX_ORDER for why K stops at 2.)
+// Hold and release low-passes of order 2 and 3 (hyrax.py:55-73 with hold_filter_order /
+// release_filter_order > 1) inside the chunked limiter of limiter_kernel.h.  (Written for order K; see
+// LIMITER_MAX_ORDER for which filters are run and which are refused.)
 //
 // scipy.signal.lfilter runs an order-K filter as a transposed direct form II section with K states:
 //     y = b0 x + z[0];   z[i] = z[i+1] + b[i+1] x - a[i+1] y   (i < K-1);   z[K-1] = b[K] x - a[K] y
 // The state update is linear, z' = A z + B x, so everything limiter_kernel.h does with first-order
-// filters carries over with K x K matrices where it has scalars:
+// filters carries over with K x K matrices where it has scalars.
+// State maps are NOT formed in the section's own basis.  A is the companion matrix of p(lambda) = lambda^K + a1
+// lambda^(K-1) + ... whose roots lie at a distance d = 2 pi fc / fs from 1 and from each other: its powers have
+// entries ~n^(K-1) that cancel to O(1) results, and a composition of such maps in float64 loses a factor d^-(K-1)
+// (1e6 for a third-order 7 Hz filter: RMS error 2e-2 when round 6 first tried; the second-order filters got away with
+// 4e-8).  Read z as the coefficients of a polynomial s(lambda) = sum_i z_i lambda^(K-1-i): A is multiplication by
+// lambda modulo p.  In the basis q^(K-1-i), q = (lambda - 1) / d -- the delta-operator form -- the same
+// multiplication is I + d C with C the companion matrix of p(1 + d q) / d^K, whose entries are O(1): products of
+// such maps are as accurate as float64 is (2e-8 against scipy.signal.lfilter for that 7 Hz filter, 1e-10 at order 2,
+// on a 9 s burst signal).  The host derives dm = d C, bd and zw from the section's float64 coefficients in extended
+// precision (host_params.h shifted_basis); a thread runs its 16 frames from zero in the shifted basis for the block
+// map, takes its entering state back to the section's basis (z = zw w: O(1) entries, no cancellation) and produces
+// its outputs with scipy's own recursion, so what comes out is the reference's arithmetic on a state good to 1e-15.
+// With that:
 //   * a thread's 16 frames act on the carried state as z -> A^count z + v (v = the state its frames
 //     produce from zero): a StateMap; maps compose across the workgroup by an ordered scan;
 //   * a chunk publishes the K state words its core frames produce from a zero carry, and a chunk's
@@ -23,20 +36,28 @@
 
 namespace mgx {
 
-// Orders above 2 are refused.  The reference runs these filters in transfer-function form
-// (scipy.signal.butter -> lfilter), whose K poles lie within ~1e-5 (release, 0.27 Hz) to ~1e-3 (hold, 7 Hz)
-// of z = 1 and of each other.  From order 3 on, that form is ill-conditioned in float64: the state
-// matrix's power A^3520 computed in double has spectral radius 141 where the exact one has 0.94 (order 3,
-// release cut-off), so chunk aggregates cannot be formed, and the reference's own sample-by-sample
-// recursion carries rounding noise of ~1e-16 / (1-r)^(K-1/2) -- 6e-5 of full scale at order 3, more than
-// the signal at order 4 -- which no reordered evaluation can reproduce.  Order 2 is well behaved (noise
-// ~1e-9, matrix powers good to 1e-9 with the host's extended precision).
-constexpr int LIMITER_MAX_ORDER = 2;
+// Which orders run.  The reference runs these filters in transfer-function form (scipy.signal.butter -> lfilter),
+// whose K poles lie at a distance d = 2 pi fc / fs from z = 1 and from each other: ~4e-5 for the release filter
+// (0.27 Hz), ~1e-3 for the hold filter (7 Hz) at the default settings.  That form is ill-conditioned in float64 when
+// d^(K - 1/2) gets small: the reference's own sample-by-sample recursion then carries rounding noise of about
+// 1.1e-16 / d^(K - 1/2) of full scale -- 1.2e-5 for a third-order release filter (measured 1.9e-5 against the same
+// recursion in 80-bit arithmetic, tests/test_limiter_order3_conditioning.py), more than the signal at order 4 --
+// which no reordered evaluation can reproduce, and the state matrix's power A^3520 computed in double has spectral
+// radius 141 where the exact one has 0.94, so chunk aggregates cannot be formed either.  A third-order HOLD filter
+// is clean (3.5e-9).  So the rule is the conditioning, not the order (host_params.h limiter_params): a filter is
+// refused when that estimate exceeds 1e-6; what passes runs here with K = the larger order (<= 3: the orders this
+// file is instantiated for), a filter of lower order carried with zero trailing coefficients.
+constexpr int LIMITER_MAX_ORDER = 3;
 
 template <int K>
 struct IirK {
     double b[K + 1];               // b[0..K]
     double a[K + 1];               // a[0] = 1
+    // the same filter's state update in the SHIFTED basis the block maps and chunk words live in (see "state maps" below):
+    // w' = w + dm w + bd x, and the section's own states are z = zw w
+    double dm[K][K];
+    double bd[K];
+    double zw[K][K];
 };
 template <int K>
 struct StateMap {
@@ -108,17 +129,35 @@ struct LimiterGeneral {
         z[K - 1] = f.b[K] * x - f.a[K] * y;
         return y;
     }
-    // the map of a thread's first `count` frames
+    // one frame of the same filter's state in the shifted basis: w' = w + dm w + bd x
+    static MGX_HD void step_shifted(const IirK<K>& f, double (&w)[K], double x) {
+        double n[K];
+        for (int i = 0; i < K; ++i) {
+            double s = f.bd[i] * x;
+            for (int k = 0; k < K; ++k) s = fma(f.dm[i][k], w[k], s);
+            n[i] = w[i] + s;
+        }
+        for (int i = 0; i < K; ++i) w[i] = n[i];
+    }
+    // shifted state -> the section's own states
+    static MGX_HD void to_section(const IirK<K>& f, const double (&w)[K], double (&z)[K]) {
+        for (int i = 0; i < K; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < K; ++k) s = fma(f.zw[i][k], w[k], s);
+            z[i] = s;
+        }
+    }
+    // the map of a thread's first `count` frames (shifted basis; pow = powers of I + dm)
     static MGX_HD StateMap<K> block_map(const IirK<K>& f, const float (&x)[E], int count, const double* pow) {
         StateMap<K> r;
-        double z[K];
-        for (int i = 0; i < K; ++i) z[i] = 0.0;
+        double w[K];
+        for (int i = 0; i < K; ++i) w[i] = 0.0;
         for (int j = 0; j < E; ++j)
-            if (j < count) step(f, z, (double)x[j]);
+            if (j < count) step_shifted(f, w, (double)x[j]);
         const double* p = pow + (size_t)count * K * K;
         for (int i = 0; i < K; ++i) {
             for (int j = 0; j < K; ++j) r.m[i][j] = p[i * K + j];
-            r.v[i] = z[i];
+            r.v[i] = w[i];
         }
         return r;
     }
@@ -174,7 +213,8 @@ struct LimiterGeneral {
                 unsigned long long* q = word(g, a.nchunks, filter, k, c);
                 unsigned long long v = poll_word(q);
                 int spins = 0;
-                while (v == LIMITER_UNPUBLISHED && spins < LB::MAX_SPINS) {
+                long long t0 = 0;
+                while (v == LIMITER_UNPUBLISHED && wait_on(spins, t0, a.gave_up, LB::MAX_SPINS)) {
                     backoff(spins);
                     v = poll_word(q);
                     ++spins;
@@ -198,8 +238,9 @@ struct LimiterGeneral {
         for (int j = 0; j < E; ++j) { th.x2[j] = 0.f; th.mx[j] = 0.f; }
         if (!th.core) return identity();
         float pw = (float)(att_deferred * LB::attack_kappa(a.att) * th.att_decay);
-        double z[K];
-        apply(pre, hold_carry, z);
+        double w[K], z[K];
+        apply(pre, hold_carry, w);
+        to_section(g.hold, w, z);
         for (int j = 0; j < E; ++j) {
             const bool in = j < th.valid;
             const float ho = in ? (float)step(g.hold, z, (double)th.sh[j]) : 0.f;
@@ -214,8 +255,9 @@ struct LimiterGeneral {
     static MGX_HD void phase_gain(int tid, const GeneralArgs<K>& g, Thread& th, const StateMap<K>& pre,
                                   const double (&rel_carry)[K], float* lds) {
         if (!th.core) return;
-        double z[K];
-        apply(pre, rel_carry, z);
+        double w[K], z[K];
+        apply(pre, rel_carry, w);
+        to_section(g.rel, w, z);
         float* gn = LB::plane(lds) + tid * LB::STRIDE;
         for (int j = 0; j < E; ++j) {
             const float ro = j < th.valid ? (float)step(g.rel, z, (double)th.x2[j]) : 0.f;

@@ -41,8 +41,12 @@
 //    the attack pole, a handful for the 7 Hz hold filter, ~170 for the 0.27 Hz release filter).
 //    No chunk ever waits for another chunk's look-back of the same filter, so the dependency
 //    depth is two (release aggregates need the exact hold output) however long the track is.
-//    Chunk numbers are drawn from an atomic ticket, so every chunk a workgroup waits for has
-//    already started.
+//    A chunk is its workgroup's number (k_limit in mgx_kernels.h: the dispatcher hands workgroups out in
+//    the order of their numbers, so every chunk a workgroup waits for has already started -- an
+//    assumption about ONE launch that is alone on the chip, observed on this firmware and partition
+//    mode, documented nowhere) or, on a handle that has ever seen a wait expire and under
+//    MGX_LIMIT_TICKETS=1, a number drawn from an atomic ticket (true whatever the dispatcher does).
+//    Every wait is bounded in time (wait_on below); an expired one raises the handle's error word.
 //  * Order of work inside a chunk: the hold path first (its aggregate is what successors wait for
 //    longest), then the attack path to completion -- so that few 16-frame arrays are live at a time --
 //    and the look-back words are asked for as soon as the chunk's own aggregates are published and
@@ -93,7 +97,9 @@ struct LimiterArgs {
     const double* w_att;
     int n_hold, n_rel, n_att;
     int* ticket;                   // chunk dispenser (zeroed before the launch)
-    int* error;                    // set to 1 if a bounded wait expired
+    int* error;                    // set to 1 if a bounded wait expired (page-locked HOST memory: written, never polled)
+    int* gave_up;                  // the same fact in device memory: a waiter that runs out of time sets it, the others look
+                                   // at it (zeroed with the ticket before the launch)
     // quiet chunks (limit_chunk_quiet): release state a core of zero input leaves per unit of hold carry,
     // log2 of the three poles, 0 when the closed forms do not apply (equal hold and release poles)
     double quiet_rel_gain;
@@ -121,6 +127,30 @@ inline void publish_word(unsigned long long* p, unsigned long long v) { *p = v; 
 inline unsigned long long poll_word(unsigned long long* p) { return *p; }
 inline void backoff(int) {}
 #endif
+// How long a wait for another workgroup's word may last.  Nothing a chunk waits for takes longer than the kernel
+// itself (hundreds of microseconds); the bound exists so that a word that never comes -- the failure the handle
+// recovers from, mgx.hip check_device_error -- costs a bounded time and never hangs the GPU.  It is a TIME (the
+// constant 100 MHz counter), not a poll count: 50 ms, looked at every 256 polls (~0.2 ms: a wait that ends as waits
+// do never gets there), and a waiter also gives up as soon as any other has (`gave_up`, a word in DEVICE memory:
+// the launch is lost whatever this chunk does), so a lost launch ends about 50 ms after its first waiter started --
+// the figure INTEGRATION.md quotes.  Nothing on this path reads host memory (a first version polled the handle's
+// page-locked error word: every waiter's read crossed PCIe and the limiter took 0.96 ms instead of 0.13).
+// `t0` = 0 on entry; `gave_up` may be null (then only the time counts).
+#if defined(__HIPCC__) && !defined(MGX_HOST_EMU)
+constexpr long long WAIT_BUDGET_TICKS = 5000000;                 // 50 ms of the 100 MHz counter
+__device__ __forceinline__ bool wait_on(int spins, long long& t0, int* gave_up, int max_spins) {
+    if (max_spins > 0) return spins < max_spins;                 // test builds: a poll count
+    if ((spins & 255) != 255) return true;
+    if (gave_up && __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    const long long now = wall_clock64();
+    if (t0 == 0) t0 = now;
+    if (now - t0 < WAIT_BUDGET_TICKS) return true;
+    if (gave_up) __hip_atomic_store(gave_up, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return false;
+}
+#else
+inline bool wait_on(int spins, long long&, int*, int max_spins) { return spins < (max_spins > 0 ? max_spins : 1); }
+#endif
 MGX_HD unsigned long long double_bits(double v) {
     union { double d; unsigned long long u; } c;
     c.d = v;
@@ -143,7 +173,7 @@ struct LimiterBlock {
 #ifdef MGX_TEST_LIMITER_MAX_SPINS                         // tests/test_device_errors.py: a look-back that gives up quickly
     static constexpr int MAX_SPINS = MGX_TEST_LIMITER_MAX_SPINS;
 #else
-    static constexpr int MAX_SPINS = 1 << 20;
+    static constexpr int MAX_SPINS = 0;                // product: bounded by time (wait_on), not by a poll count
 #endif
     static constexpr int POLL_SLOTS = 4;               // look-back words a lane keeps in flight (x64 lanes)
 
@@ -550,7 +580,8 @@ struct LimiterBlock {
                 unsigned long long* q = a.published + (size_t)slot * a.nchunks + c;
                 unsigned long long v = p.v[k];
                 int spins = 0;
-                while (v == LIMITER_UNPUBLISHED && spins < MAX_SPINS) {
+                long long t0 = 0;
+                while (v == LIMITER_UNPUBLISHED && wait_on(spins, t0, a.gave_up, MAX_SPINS)) {
                     backoff(spins);
                     v = poll_word(q);
                     ++spins;
@@ -569,7 +600,8 @@ struct LimiterBlock {
             unsigned long long* q = a.published + (size_t)slot * a.nchunks + c;
             unsigned long long v = poll_word(q);
             int spins = 0;
-            while (v == LIMITER_UNPUBLISHED && spins < MAX_SPINS) {
+            long long t0 = 0;
+            while (v == LIMITER_UNPUBLISHED && wait_on(spins, t0, a.gave_up, MAX_SPINS)) {
                 backoff(spins);
                 v = poll_word(q);
                 ++spins;

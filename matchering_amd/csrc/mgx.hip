@@ -220,6 +220,7 @@ struct mgx_handle {
     // set by a kernel whose bounded wait expired (limiter look-back, level-correction round): one word of
     // page-locked host memory the kernels write through its device address, so that every blocking call
     // can look at it for free once the stream has drained
+    bool limiter_ran_by_number = false;      // a limiter launch since the last error check dealt chunks by workgroup number
     int* error_host = nullptr;
     int* error_dev = nullptr;
     int last_taps = 0;
@@ -1002,7 +1003,7 @@ static int limiter_state(mgx_handle* h, long long n, const mgx_config* cfg, unsi
     return 0;
 }
 
-// hold / release filters of order 2: k_limit_general<K>, its tables uploaded when the parameters change
+// hold / release filters of order 2 or 3: k_limit_general<K>, its tables uploaded when the parameters change
 template <int K>
 static int launch_limiter_general(mgx_handle* h, const LimiterArgs& a, const LimiterParams& lp) {
     const std::vector<double> t = general_tables(lp);
@@ -1108,10 +1109,12 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     a.published = (unsigned long long*)h->lim_published.p;
     const char* force_tickets = std::getenv("MGX_LIMIT_TICKETS");             // measurement aid / tests: "1" = always tickets
     a.ticket = (h->limiter_tickets || (force_tickets && force_tickets[0] == '1')) ? (int*)h->lim_ctrl.p : nullptr;
+    h->limiter_ran_by_number = h->limiter_ran_by_number || a.ticket == nullptr;     // (since the last error check)
     a.error = h->error_dev;
+    a.gave_up = (int*)h->lim_ctrl.p + 2;                      // ([0] the ticket, [2] "a waiter has given up")
     if (!preset_done) {
         HIP_TRY(hipMemsetAsync(h->lim_published.p, 0xff, pub_bytes, h->stream));
-        HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 4, h->stream));
+        HIP_TRY(hipMemsetAsync(h->lim_ctrl.p, 0, 16, h->stream));
     }
     // behind the device's previous limiter launch if another handle queued it (LimiterChain); a handle that is alone
     // on its device records nothing: its launches are ordered by its one stream
@@ -1122,7 +1125,8 @@ static int run_limiter(mgx_handle* h, const float* y, long long n, const mgx_con
     int rc = 0;
     switch (lp.general) {
         case 0: rc = launch_limiter(h, a, threads); break;
-        default: rc = launch_limiter_general<2>(h, a, lp); break;
+        case 2: rc = launch_limiter_general<2>(h, a, lp); break;
+        default: rc = launch_limiter_general<3>(h, a, lp); break;
     }
     if (rc == 0 && shared) {
         HIP_TRY(hipEventRecord(h->lim_done, h->stream));
@@ -1152,8 +1156,10 @@ static int check_device_error(mgx_handle* h, bool may_requeue = false) {
     h->requeued = false;
     const int outstanding = h->masters_outstanding;
     const int copies = h->downloads_outstanding;
+    const bool by_number = h->limiter_ran_by_number;
     h->masters_outstanding = 0;
     h->downloads_outstanding = 0;
+    h->limiter_ran_by_number = false;
     if (!h->error_host) return 0;
     volatile int* e = (volatile int*)h->error_host;
     const int what = (e[DEVICE_ERROR_SLOT_LOOKBACK] ? DEVICE_ERROR_LOOKBACK : 0) | (e[DEVICE_ERROR_SLOT_TAIL] ? DEVICE_ERROR_TAIL : 0) |
@@ -1171,7 +1177,9 @@ static int check_device_error(mgx_handle* h, bool may_requeue = false) {
     // per round from now on) and an expired limiter look-back while chunks were dealt by workgroup number (-> tickets from
     // now on).  Anything else, or the same again in the safer mode, is a lost word.
     const bool tail_new = (what & DEVICE_ERROR_TAIL) && !h->avoid_tail;
-    const bool lookback_new = (what & DEVICE_ERROR_LOOKBACK) && !h->limiter_tickets;
+    // (by the mode the failed launches REALLY ran in: under MGX_LIMIT_TICKETS=1 the handle's own switch may still be
+    // off while every launch drew tickets -- an expired wait is then a lost word, not something to run again)
+    const bool lookback_new = (what & DEVICE_ERROR_LOOKBACK) && !h->limiter_tickets && by_number;
     const bool recoverable = (!(what & DEVICE_ERROR_TAIL) || tail_new) && (!(what & DEVICE_ERROR_LOOKBACK) || lookback_new);
     if (recoverable) {
         if (tail_new) h->avoid_tail = true;                      // whatever happens next, this handle stops using the tail
@@ -1193,7 +1201,7 @@ static int check_device_error(mgx_handle* h, bool may_requeue = false) {
             }
             for (int i = 0; i < DEVICE_ERROR_SLOTS; ++i) e[i] = 0;
         } else {
-            return fail(MGX_ERR_HIP, tail_new
+            return fail(MGX_ERR_RETRY, tail_new
                 ? "the level-correction tail kernel's workgroups were not resident together (the GPU is shared) and "
                   "the results of the mgx_master calls since the last synchronisation are not valid; this handle now "
                   "runs one launch per correction round: call again"
@@ -1527,6 +1535,12 @@ int mgx_limit(mgx_handle* h, const float* x_dev, int64_t n, const mgx_config* cf
     *post = post_gain;
     HIP_TRY(hipMemcpyAsync(h->scalars.p, post, sizeof(double), hipMemcpyHostToDevice, h->stream));
     CorrectionState host_cs;
+    // Error words that earlier asynchronous mgx_master calls may have left are THEIRS: looked at (and reported) before
+    // this call queues anything, so that the retry below can only ever answer for this call's own limiter.
+    if (h->masters_outstanding > 0) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        MGX_TRY(check_device_error(h));
+    }
     for (int attempt = 0;; ++attempt) {
         const bool tickets_before = h->limiter_tickets;
         MGX_TRY(run_limiter(h, x_dev, n, cfg, &cs->gain, (const double*)h->scalars.p, &cs->limiter_active, out_dev));

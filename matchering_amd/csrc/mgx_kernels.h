@@ -1910,7 +1910,7 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
     if (a.lim_published) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.lim_words; i += (long long)gridDim.x * 256)
             a.lim_published[i] = ~0ull;
-        if (blockIdx.x == 0 && threadIdx.x == 0) *a.lim_ticket = 0;      // ticket only: a raised error sticks
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.lim_ticket[0] = a.lim_ticket[2] = 0;      // ticket and "gave up" (mgx.hip run_limiter); a raised error sticks
     }
     // this workgroup's slice of the band buffer, one compacted list per wave
     float* wave_band = bc.lists + wave * bc.wave_cap;
@@ -2081,13 +2081,14 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
 #ifdef MGX_TEST_TAIL_MAX_SPINS                             // tests/test_device_errors.py: a tail that gives up quickly
 constexpr int TAIL_MAX_SPINS = MGX_TEST_TAIL_MAX_SPINS;
 #else
-constexpr int TAIL_MAX_SPINS = 1 << 20;
+constexpr int TAIL_MAX_SPINS = 0;                          // product: bounded by time (wait_on, limiter_kernel.h)
 #endif
 // one lane's bounded wait for an 8-byte flag word to leave the all-ones pattern (`on_expiry` and the error word on expiry)
 __device__ __forceinline__ unsigned long long poll_word(const unsigned long long* w, int* error, unsigned long long on_expiry) {
     unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int spins = 0;
-    while (v == ~0ull && spins < TAIL_MAX_SPINS) {
+    long long t0 = 0;
+    while (v == ~0ull && wait_on(spins, t0, nullptr, TAIL_MAX_SPINS)) {
         if (spins < 64) __builtin_amdgcn_s_sleep(1);
         else __builtin_amdgcn_s_sleep(16);
         v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2214,7 +2215,7 @@ __global__ __launch_bounds__(256) void k_correction_tail(RoundArgs a, int groups
     if (a.lim_published) {
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.lim_words; i += (long long)gridDim.x * 256)
             a.lim_published[i] = ~0ull;
-        if (blockIdx.x == 0 && threadIdx.x == 0) *a.lim_ticket = 0;      // ticket only: a raised error sticks
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.lim_ticket[0] = a.lim_ticket[2] = 0;      // ticket and "gave up" (mgx.hip run_limiter); a raised error sticks
     }
     TAIL_STAMP(1);
     if ((int)blockIdx.x == total) {                                      // uniform: the extra workgroup decides

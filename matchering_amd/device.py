@@ -386,6 +386,9 @@ class Device:
     def comm_init(self, rank, world, exchange=None):
         """Join a communicator of ``world`` ranks.  ``exchange(payload, size) -> bytes`` must hand rank 0's
         128-byte id to every rank (bench.Ranks.broadcast_bytes does); not needed for world == 1."""
+        from .ranks import single_node_rccl_defaults
+
+        single_node_rccl_defaults()          # (only what the host has not set; nothing when the ranks span machines)
         lib = library()
         uid = ctypes.create_string_buffer(128)
         if rank == 0:

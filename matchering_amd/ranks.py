@@ -40,6 +40,37 @@ def rank_environment():
     return rank, world, local
 
 
+def ranks_are_on_this_node():
+    """True unless ``MGX_RENDEZVOUS=tcp://host:port`` names another machine."""
+    explicit = os.environ.get("MGX_RENDEZVOUS", "")
+    if not explicit.startswith("tcp://"):
+        return True
+    host = explicit[6:].rpartition(":")[0]
+    return host in ("", "127.0.0.1", "localhost", "::1")
+
+
+def single_node_rccl_defaults():
+    """Tell RCCL, before its first initialisation, that the job's ranks are the GPUs of ONE node.
+
+    The data path between them is xGMI and the bootstrap needs no interface but loop-back, so neither is left to RCCL's
+    probing of a box whose host name may not resolve: ``NCCL_SOCKET_IFNAME=lo`` and ``NCCL_IB_DISABLE=1``, each only
+    where the host has not chosen itself, and not at all when the rendezvous names another machine (a loop-back
+    bootstrap cannot reach it).  RCCL's first initialisation normally takes 2 - 5 s here either way
+    (tools/rccl_init_time.py); on one box of the pool it took 457 s with RCCL's own defaults
+    (profiles/r05_w_*).  This lives in the Python front end, not in libmgx: changing the environment of a host
+    process is the host's decision -- a C/C++ host that binds ``mgx_comm_*`` sets the two
+    variables itself -- and it runs where a job sets itself up (``Ranks()``, ``Device.comm_init``),
+    which is before the batch lanes' threads exist.  Returns what it set."""
+    if not ranks_are_on_this_node():
+        return {}
+    done = {}
+    for key, value in (("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1")):
+        if key not in os.environ:
+            os.environ[key] = value
+            done[key] = value
+    return done
+
+
 def _address():
     explicit = os.environ.get("MGX_RENDEZVOUS", "")
     if explicit.startswith("tcp://"):
@@ -114,6 +145,7 @@ class Ranks:
         self.root = None                     # other ranks: the socket to rank 0
         self.listener = None
         if self.world > 1:
+            single_node_rccl_defaults()
             self._meet()
 
     # ---- rendezvous ------------------------------------------------------------------------------------

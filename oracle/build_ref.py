@@ -87,6 +87,21 @@ def manifest():
         return json.load(fh)
 
 
+_installed = []
+
+
+def unload():
+    """Take the stubs ``load`` installed, the staged package and its path out of this process again."""
+    for name in list(_installed):
+        sys.modules.pop(name, None)
+    del _installed[:]
+    for name in [n for n in sys.modules if n == "matchering" or n.startswith("matchering.")]:
+        if STAGED in (getattr(sys.modules[name], "__file__", "") or ""):
+            sys.modules.pop(name, None)
+    while STAGED in sys.path:
+        sys.path.remove(STAGED)
+
+
 def load():
     """Import the staged reference (sourceless).  Raises ImportError when it is not staged."""
     if not staged():
@@ -102,12 +117,19 @@ def load():
             raise NotImplementedError("the LOWESS stand-in of the CPU baseline covers lowess_it = 0 (the default)")
         return np.stack((exog, lowess_it0(endog, frac, delta)), axis=1)
 
+    def _not_here(*_a, **_k):
+        raise RuntimeError("soundfile / resampy are stubs of oracle/build_ref.py: stages.main never reaches them")
+
+    # (the reference imports both at module level -- checker.py:22 `from resampy import resample` -- so the stubs must
+    # carry the names; whoever loads this into a process that also runs the product calls unload() when done: the
+    # product's checker would otherwise find this `resample` instead of taking its ImportError fallback)
     for name in ("soundfile", "resampy"):
         if name not in sys.modules:
             mod = types.ModuleType(name)
-            mod.resample = None
+            mod.resample = _not_here
             mod.check_format = lambda *a, **k: True
             sys.modules[name] = mod
+            _installed.append(name)
     if "statsmodels.api" not in sys.modules:
         pkg = types.ModuleType("statsmodels")
         api = types.ModuleType("statsmodels.api")
@@ -115,6 +137,7 @@ def load():
         pkg.api = api
         sys.modules["statsmodels"] = pkg
         sys.modules["statsmodels.api"] = api
+        _installed.extend(["statsmodels", "statsmodels.api"])
     if "matchering" in sys.modules and not getattr(sys.modules["matchering"], "__file__", "").startswith(STAGED):
         raise ImportError("another `matchering` is already imported in this process")
     if STAGED not in sys.path:

@@ -817,6 +817,7 @@ extern "C" int emu_limit(const float* x, long long n, const mgx_config* cfg, dou
     LimiterParams lp;
     if (!limiter_params(*cfg, lp).empty()) return -1;
     if (lp.general == 2) return limit_general_impl<2>(lp, x, n, cfg, gain, post_gain, out);
+    if (lp.general == 3) return limit_general_impl<3>(lp, x, n, cfg, gain, post_gain, out);
     if (lp.threads == 1024) return limit_impl<1024>(lp, x, n, cfg, gain, post_gain, out, dbg_sl, dbg_sh);
     return limit_impl<256>(lp, x, n, cfg, gain, post_gain, out, dbg_sl, dbg_sh);
 }

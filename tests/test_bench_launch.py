@@ -46,6 +46,22 @@ def test_self_launched_ranks_print_one_line(world):
     assert 0.5 < line["value"] / (world * n1["value"]) < 1.5              # a curve of one workload: efficiency near 1
 
 
+def test_config_5_per_gpu_share_on_eight_ranks():
+    """VERDICT round 5, next #7: the line a driver's 8-GPU run of config #5's per-GPU share would print, without a GPU."""
+    line = _bench("--gpus", "8", "--workload", "96k_16k_x16_full")
+    assert line["n_gpus"] == 8 and len(line["rank_gpus"]) == 8 and line["physical_gpus"] == 8
+    cfg = line["config"]
+    assert cfg["pairs_per_gpu_per_step"] == 16 and cfg["frames_per_gpu_per_step"] == 16 * 240 * 96000
+    assert "96k_16k_x16_full" in cfg["workload"] and cfg["parallelism"] == "pairs x128"       # batch 128 on 8 GPUs
+    gathered = line["rccl_fir_allgather"]
+    assert gathered["bytes_per_rank"] == 2 * 16384 * 4 == 131072 and gathered["ok"] and gathered["ranks_seen"] == 8
+    assert gathered["distinct_tables"] == 8 and "rccl_init_s" in line
+    n1 = line["n1_same_workload"]
+    assert n1["unit"] == "Msamples/s" and 0.5 < line["value"] / (8 * n1["value"]) < 1.5
+    rep = line["ms_per_step_repeats"]
+    assert rep["blocks"] == 6 and rep["min"] <= rep["median"] <= rep["max"] and rep["min"] <= line["ms_per_step"] <= rep["max"]
+
+
 def test_single_rank_needs_no_rendezvous():
     line = _bench("--gpus", "1")
     assert line["n_gpus"] == 1 and line["launch"] == "single" and "rendezvous" not in line

@@ -186,7 +186,7 @@ def test_an_expired_tail_never_hands_out_the_failed_run(mode):
     if mode == "download":
         assert "download rms_ok True note True" in done.stdout, done.stdout + done.stderr[-2000:]
     else:
-        assert f"{mode} raised -2 True" in done.stdout, done.stdout + done.stderr[-2000:]
+        assert f"{mode} raised -6 True" in done.stdout, done.stdout + done.stderr[-2000:]
         assert f"{mode} retry rms_ok True" in done.stdout, done.stdout
 
 
@@ -243,3 +243,41 @@ print("C", " ".join(repr(c) for c in rep.correction_coefficients[:6]), float(np.
     a, b = outs
     assert len(a) == 7 and all(abs(x / y - 1.0) <= 1e-12 for x, y in zip(a[:6], b[:6]))
     assert abs(a[6] / b[6] - 1.0) <= 1e-6
+
+
+# ---- how long a lost launch costs ----------------------------------------------------------
+# The product bounds every wait by TIME (limiter_kernel.h wait_on: 50 ms, and every waiter gives up once one has).  A third
+# test build loses the word but keeps the product's bound: the first synchronize pays one budget for the launch dealt by
+# workgroup number, the call is queued again by the library with tickets and pays it once more (the word is still lost),
+# then fails for good -- two budgets and two short kernels, where 2^20 back-offs per waiter cost seconds until round 6.
+TIMED_VARIANT = os.path.join(BUILD_DIR, "libmgx_losewordtimed.so")
+TIMED_FLAGS = ("-DMGX_TEST_LOSE_WORD",)
+TIMED_CHILD = CHILD.replace("dev.master(t, target.shape[0], r, reference.shape[0], native, result=out, want_report=False)\n    try:",
+                            "dev.master(t, target.shape[0], r, reference.shape[0], native, result=out, want_report=False)\n"
+                            "    import time\n    t0 = time.perf_counter()\n    try:") \
+                   .replace('        print("raised", attempt)', '        print("raised", attempt, "after_ms", round((time.perf_counter() - t0) * 1e3, 1))')
+
+
+def build_timed_variant():
+    sys.path.insert(0, ROOT)
+    from matchering_amd import build as native_build
+
+    os.makedirs(BUILD_DIR, exist_ok=True)
+    return native_build.build(out=TIMED_VARIANT, extra_flags=TIMED_FLAGS)
+
+
+@pytest.mark.gpu
+def test_a_lost_launch_costs_its_time_budget_not_seconds():
+    lib = build_timed_variant()
+    done = subprocess.run([sys.executable, "-c", TIMED_CHILD.format(root=ROOT)], env=dict(os.environ, MGX_LIB=lib),
+                          capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stderr[-2000:]
+    times = [float(ln.split("after_ms")[1]) for ln in done.stdout.splitlines() if "after_ms" in ln]
+    assert len(times) == 2, done.stdout + done.stderr[-2000:]
+    # attempt 0: two budgets of 50 ms (by number, then again with tickets); attempt 1: one (tickets)
+    assert 40.0 <= times[0] <= 250.0 and 40.0 <= times[1] <= 150.0, times
+    folder = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(folder):
+        with open(os.path.join(folder, "limiter_lost_launch_ms.txt"), "w") as fh:
+            fh.write(f"lost look-back word, product wait budget (50 ms): first synchronize failed after {times[0]} ms "
+                     f"(two launches: by workgroup number, then queued again with tickets), the next after {times[1]} ms\n")

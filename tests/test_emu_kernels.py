@@ -448,7 +448,7 @@ def test_butterworth_design_matches_scipy(emu):
 
 
 # (hold order, release order): the general kernel's K is the larger of the two
-FILTER_ORDERS = [(2, 2), (1, 2), (2, 1)]
+FILTER_ORDERS = [(2, 2), (1, 2), (2, 1), (3, 1), (3, 2)]
 
 
 @pytest.mark.parametrize("orders", FILTER_ORDERS)
@@ -475,6 +475,50 @@ def test_limiter_hold_and_release_filters_of_higher_order(emu, orders):
     want = mo.limit(y.astype(np.float64), mo.params(internal_sample_rate=sr, **kw))
     assert rms_error(out, want) <= 1e-6, rms_error(out, want)
     assert np.abs(out - want).max() <= 1e-5
+
+
+def test_third_order_release_filter_where_it_is_well_conditioned(emu):
+    """At 8 kHz the default release filter sits at d = 2 pi 0.267 / 8000 = 2.1e-4 from z = 1: order 3 is estimated at 1.7e-7 of
+    full scale, under the 1e-6 limit, so it runs -- and must then agree with the reference's recursion."""
+    import matchering_amd as mg
+    from matchering_amd.synth import synth
+
+    sr = 8000
+    kw = dict(release_filter_order=3)
+    rng = np.random.RandomState(5)
+    x = synth(30.0, sr, 3).astype(np.float64)
+    x *= 1.7 / np.abs(x).max()
+    x += 1e-3 * rng.randn(*x.shape)
+    y = np.ascontiguousarray(x, dtype=np.float32)
+    native = mg.Config(internal_sample_rate=sr, limiter=mg.LimiterConfig(**kw)).to_native()
+    out = np.zeros_like(y)
+    rc = emu.emu_limit(_fp(y), ctypes.c_longlong(y.shape[0]), ctypes.byref(native), ctypes.c_double(1.0),
+                       ctypes.c_double(1.0), _fp(out), None, None)
+    assert rc == 0
+    want = mo.limit(y.astype(np.float64), mo.params(internal_sample_rate=sr, **kw))
+    assert rms_error(out, want) <= 2e-6, rms_error(out, want)
+
+
+def test_limiter_filters_are_refused_by_conditioning_not_by_order(emu):
+    """host_params.h limiter_params: a filter is refused when the rounding noise of the reference's own float64 recursion,
+    ~1.1e-16 / (2 pi fc / fs)^(order - 1/2), exceeds 1e-6 (tests/test_limiter_order3_conditioning.py measures it)."""
+    import matchering_amd as mg
+
+    y = np.zeros((4096, 2), np.float32)
+    out = np.zeros_like(y)
+
+    def rc(**kw):
+        native = mg.Config(limiter=mg.LimiterConfig(**kw)).to_native()
+        return emu.emu_limit(_fp(y), ctypes.c_longlong(y.shape[0]), ctypes.byref(native), ctypes.c_double(1.0),
+                             ctypes.c_double(1.0), _fp(out), None, None)
+
+    assert rc(hold_filter_order=3) == 0                                   # 7 Hz at order 3: ~4e-9
+    assert rc(hold_filter_order=3, release_filter_order=2) == 0
+    assert rc(release_filter_order=3) == -1                               # 0.27 Hz at order 3: ~1e-5
+    assert rc(hold_filter_order=3, release_filter_order=3) == -1
+    assert rc(hold_filter_order=4) == -1                                  # ~3e-6 at 7 Hz
+    assert rc(hold_filter_order=4, hold_filter_coefficient=400.0) == -1   # clean, but no instantiation above 3
+    assert rc(release_filter_order=3, release_filter_coefficient=20000.0) == 0     # a 6.7 Hz release filter is clean at 3
 
 
 def test_limiter_lookback_across_many_chunks(emu):

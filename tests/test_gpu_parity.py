@@ -425,6 +425,44 @@ def test_limiter_hold_and_release_filters_of_order_two(orders):
     assert np.abs(out - want).max() <= 1e-5
 
 
+@pytest.mark.parametrize("orders", [(3, 1), (3, 2)])
+def test_limiter_hold_filter_of_order_three(orders):
+    """hold_filter_order = 3 (defaults.py:48-56 accepts any positive order, hyrax.py:61-66 runs
+    it).  The 7 Hz hold filter is well conditioned at order 3 (its float64 recursion is good to 4e-9,
+    tests/test_limiter_order3_conditioning.py); the release filter stays at an order whose conditioning passes.
+    k_limit_general<3>: three-state sections, 3 x 3 block maps and look-back matrices."""
+    import matchering_amd as mg
+    from matchering_amd import kernels
+    from matchering_amd.synth import synth
+
+    sr = 44100
+    kw = dict(hold_filter_order=orders[0], release_filter_order=orders[1])
+    rng = np.random.RandomState(17)
+    x = synth(20.0, sr, 9).astype(np.float64)
+    x *= 1.7 / np.abs(x).max()
+    x[:sr] *= 0.3
+    x += 1e-3 * rng.randn(*x.shape)
+    y = x.astype(np.float32)
+    out, active = kernels.limit(y, mg.Config(internal_sample_rate=sr, limiter=mg.LimiterConfig(**kw)))
+    want = mo.limit(y.astype(np.float64), mo.params(internal_sample_rate=sr, **kw))
+    assert active
+    assert rms_error(out, want) <= 1e-6
+    assert np.abs(out - want).max() <= 1e-5
+
+
+def test_master_with_third_order_hold_filter():
+    """The whole path with LimiterConfig(hold_filter_order=3), against the oracle (1e-5 RMS, the project's bar)."""
+    import matchering_amd as mg
+    from matchering_amd import stages
+    from matchering_amd.synth import make_pair
+
+    kw = dict(hold_filter_order=3)
+    target, reference = make_pair(12.0, 44100, pair=4, reference_seconds=9.0)
+    got = stages.main(target, reference, mg.Config(max_piece_size=3.0, limiter=mg.LimiterConfig(**kw)))
+    want = mo.master(target, reference, mo.params(max_piece_size=3.0, **kw), True, False, False)
+    assert rms_error(got[0], want[0]) <= RMS_TOL
+
+
 def test_master_with_second_order_limiter_filters():
     """The whole path with the limiter's filters at order 2, against the oracle."""
     import matchering_amd as mg
@@ -462,10 +500,15 @@ def test_fails_loudly_on_unsupported():
     # fft_size 2 and 4 pass defaults.py:110-112 and then fail inside the reference (tests/test_host_vs_reference.py)
     with pytest.raises(MgxError, match="fft_size below 8"):
         stages.main(t, r, mg.Config(internal_sample_rate=8000, fft_size=4, max_piece_size=1.0))
-    # limiter filters of order 3 and up: ill-conditioned in the reference's own form (limiter_general.h)
-    with pytest.raises(MgxError, match="orders above 2"):
-        stages.main(t, r, mg.Config(internal_sample_rate=8000, max_piece_size=5.0,
+    # a third-order RELEASE filter: ill-conditioned in the reference's own form (limiter_general.h) -- refused by its
+    # conditioning, not by its order (a third-order hold filter runs: test_limiter_hold_filter_of_order_three)
+    # (at 44.1 kHz: 1.2e-5 of full scale; at 8 kHz the same filter sits five times further from z = 1 and passes)
+    with pytest.raises(MgxError, match="ill-conditioned"):
+        stages.main(t, r, mg.Config(internal_sample_rate=44100, max_piece_size=5.0,
                                     limiter=mg.LimiterConfig(release_filter_order=3)))
+    with pytest.raises(MgxError, match="orders up to 3"):          # clean at this cut-off, but nothing is built for order 4
+        stages.main(t, r, mg.Config(internal_sample_rate=8000, max_piece_size=5.0,
+                                    limiter=mg.LimiterConfig(hold_filter_order=4, hold_filter_coefficient=400.0)))
 
 
 def test_process_files_end_to_end(tmp_path):

@@ -1,9 +1,12 @@
-"""oracle/build_ref.py: the reference byte-compiled where it lies, for bench.py's ``cpu_baseline`` (kind "reference").
+"""oracle/build_ref.py: the reference byte-compiled where it lies -- a CONTAINER-ONLY staging since round 6.
 
-The reference tree exists in the build container only; what travels to the GPU box is ``oracle/_ref/`` -- sourceless
-byte code, git-ignored.  These tests (CPU) hold the recipe: nothing but ``.pyc`` files and a manifest is staged, the
-staged package IS the reference (SHA-256 of every source in the manifest, its ``stages.main`` equals the oracle to
-rounding), and the directory stays out of the history.
+The reference tree exists in the build container only, and a Python reference may not travel to the GPU box in any form
+(source or byte code): ``oracle/_ref/`` is git-ignored AND gpurun-ignored.  It serves what runs here: timing the
+reference's own ``stages.main`` against the oracle on one host (tools/cpu_port_vs_reference.py ->
+profiles/cpu_port_vs_reference.json, which bench.py's ``cpu_baseline`` -- kind "port" on the GPU box -- carries along).
+These tests (CPU) hold the recipe: nothing but ``.pyc`` files and a manifest is staged, the staged package IS the
+reference (SHA-256 of every source in the manifest, its ``stages.main`` equals the oracle to rounding), and the
+directory stays out of the history and out of the snapshot.
 """
 import os
 import subprocess
@@ -23,10 +26,8 @@ def test_the_staging_directory_stays_out_of_the_history():
         assert "oracle/_ref/" in fh.read().split()
     tracked = subprocess.run(["git", "ls-files", "oracle/_ref"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
     assert tracked == ""
-    ignore = os.path.join(ROOT, ".gpurunignore")            # ... but it must travel to the GPU box
-    if os.path.exists(ignore):
-        with open(ignore) as fh:
-            assert "oracle/_ref" not in fh.read()
+    with open(os.path.join(ROOT, ".gpurunignore")) as fh:  # ... and out of the snapshot that goes to the GPU box
+        assert "oracle/_ref/" in fh.read().split()
 
 
 @pytest.mark.skipif(not (build_ref.reference_present() or build_ref.staged()), reason="no reference tree and nothing staged")

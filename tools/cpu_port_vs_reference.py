@@ -55,8 +55,16 @@ def main():
         for _ in range(2):
             t_port = min(t_port, best_of(lambda: mo.master(target, reference, ocfg, *need), args.runs))
             t_ref = min(t_ref, best_of(lambda: rr.run_reference(target, reference, {}, need=need, capture=False), args.runs))
+        # ... and what the two compute: the largest difference between their outputs on this pair (the oracle's pin at
+        # this size; the frozen fixtures of tests/golden are <= 307 k frames)
+        import numpy as np
+
+        got = [o for o in mo.master(target, reference, ocfg, *need) if o is not None][0]
+        ref_outs, _ = rr.run_reference(target, reference, {}, need=need, capture=False)
+        want = [o for o in ref_outs if o is not None][0]
         result[name] = {"oracle_s": round(t_port, 3), "reference_s": round(t_ref, 3),
-                        "oracle_over_reference": round(t_port / t_ref, 3)}
+                        "oracle_over_reference": round(t_port / t_ref, 3),
+                        "max_abs_difference_of_outputs": float(np.abs(np.asarray(got) - np.asarray(want)).max())}
         print(name, result[name], flush=True)
     with open(os.path.join(ROOT, "profiles", "cpu_port_vs_reference.json"), "w") as fh:
         json.dump(result, fh, indent=1)
