@@ -828,6 +828,10 @@ def reference_main(target, reference, sample_rate, fft, need, runs_budget_s=12.0
     try:
         import build_ref
 
+        if not build_ref.reference_present():
+            # a Python reference does not travel to the GPU box in any form: whatever byte code a snapshot may have
+            # carried along is not used there -- the reference is timed where its tree is (the build container)
+            return None, "no /root/reference on this box"
         mg_ref = build_ref.load()
     except Exception as exc:                                 # noqa: BLE001 -- not staged / wrong interpreter: the port stands in
         return None, repr(exc)[:200]

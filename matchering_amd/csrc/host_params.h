@@ -276,18 +276,12 @@ inline std::string limiter_params(const mgx_config& c, LimiterParams& p) {
     // frames after which the attack smoother has forgotten its state (rho^ha <= MGX_ATTACK_FORGET)
     p.ha = (int)std::ceil(std::log(MGX_ATTACK_FORGET) / std::log(rho));
     // 256 blocks per chunk while the halos leave at least a quarter of them to the core, else 1024;
-    // `limiter_threads_wish` (256 / 512 / 1024, 0 = this rule): what mgx.hip asks for (measurement aid, and the rule
-    // for sample rates whose halos eat more than a fifth of a 256-block chunk)
+    // `limiter_threads_wish` (256 / 1024, 0 = this rule): what mgx.hip asks for (measurement aid)
     p.threads = 256;
     p.geo = LimiterBlock<256>::geometry(p.hw, p.hb, p.ha);
     int wish = limiter_threads_wish();
     if (p.geo.core_blocks < 64 && wish < 1024) wish = 1024;
-    if (wish == 512 && (c.hold_filter_order > 1 || c.release_filter_order > 1)) wish = 0;     // (the general kernel is 256 only)
-    if (wish == 512) {
-        p.threads = 512;
-        const LimiterBlock<512>::Geometry g = LimiterBlock<512>::geometry(p.hw, p.hb, p.ha);
-        p.geo.gl = g.gl; p.geo.gr = g.gr; p.geo.gw = g.gw; p.geo.core_blocks = g.core_blocks; p.geo.chunk = g.chunk;
-    } else if (wish == 1024) {
+    if (wish == 1024) {
         p.threads = 1024;
         const LimiterBlock<1024>::Geometry g = LimiterBlock<1024>::geometry(p.hw, p.hb, p.ha);
         p.geo.gl = g.gl; p.geo.gr = g.gr; p.geo.gw = g.gw; p.geo.core_blocks = g.core_blocks; p.geo.chunk = g.chunk;

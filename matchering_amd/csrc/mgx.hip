@@ -135,7 +135,7 @@ static void code_sizes_from_library(int (&bytes)[CODE_KERNELS][CODE_VARIANTS]) {
                 const size_t len = std::strlen(CODE_NAMES[c]);
                 if (len >= 3 && std::strcmp(CODE_NAMES[c] + len - 3, "ILi") == 0) {      // templated: ...ILi<number>E
                     const int number = std::atoi(hit + len);
-                    variant = number == 256 ? 0 : number == 1024 ? 1 : number == 512 ? 2 : number;
+                    variant = number == 256 ? 0 : number == 1024 ? 1 : number;
                 }
                 if (variant < 0 || variant >= CODE_VARIANTS) continue;
                 int& slot = bytes[c][variant];
@@ -581,16 +581,26 @@ static int build_fir_operator(mgx_handle* h, const FirPlanView& pl, double** out
     return 0;
 }
 
-// A dense [rows][cols] matrix -> its rows' windows (k_fir_band), packed.  The dense matrix is freed.
+// device temporaries of the operator builds: freed on every way out, the failing ones included
+struct DevTemp {
+    void* p = nullptr;
+    ~DevTemp() { if (p) hipFree(p); }
+    DevTemp() = default;
+    DevTemp(const DevTemp&) = delete;
+    DevTemp& operator=(const DevTemp&) = delete;
+};
+constexpr size_t FIR_FACTOR_DENSE_BUDGET = (size_t)1 << 30;      // 1 GiB for a factor's dense intermediate
+
+// A dense [rows][cols] matrix -> its rows' windows (k_fir_band), packed.  The dense matrix stays the caller's.
 static int pack_fir_factor(mgx_handle* h, double* dense, int rows, int cols, PlanDev::Factor& f) {
-    int2* band_dev = nullptr;
-    HIP_TRY(hipMalloc((void**)&band_dev, (size_t)rows * sizeof(int2)));
+    DevTemp band_tmp;
+    HIP_TRY(hipMalloc(&band_tmp.p, (size_t)rows * sizeof(int2)));
+    int2* band_dev = (int2*)band_tmp.p;
     hipLaunchKernelGGL(k_fir_band, dim3(rows), dim3(256), 0, h->stream, (const double*)dense, cols, band_dev);
     HIP_TRY(hipGetLastError());
     std::vector<int2> band(rows);
     HIP_TRY(hipMemcpyAsync(band.data(), band_dev, (size_t)rows * sizeof(int2), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipFree(band_dev));
     std::vector<FactorRow> desc(rows);
     long long total = 0;
     for (int r = 0; r < rows; ++r) {
@@ -606,7 +616,6 @@ static int pack_fir_factor(mgx_handle* h, double* dense, int rows, int cols, Pla
                        f.packed);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
-    HIP_TRY(hipFree(dense));
     return 0;
 }
 
@@ -615,12 +624,13 @@ static int pack_fir_factor(mgx_handle* h, double* dense, int rows, int cols, Pla
 static int build_fir_factors(mgx_handle* h, const FirPlanView& pl, PlanDev& pd) {
     const size_t per = (size_t)3 * pl.bins + (size_t)3 * pl.nlog + pl.lw.anchors;
     const int anchors = pl.lw.anchors, batch = 256;
-    double* scratch = nullptr;
-    double* dense = nullptr;
-    HIP_TRY(hipMalloc((void**)&scratch, (size_t)batch * per * sizeof(double)));
+    DevTemp scratch_tmp, dense_tmp;
+    HIP_TRY(hipMalloc(&scratch_tmp.p, (size_t)batch * per * sizeof(double)));
+    double* scratch = (double*)scratch_tmp.p;
     const size_t lds_scan = (size_t)FirDesign::Scan::SCRATCH * sizeof(Affine);
     // A: unit raw curves -> the anchors' fits
-    HIP_TRY(hipMalloc((void**)&dense, (size_t)anchors * pl.bins * sizeof(double)));
+    HIP_TRY(hipMalloc(&dense_tmp.p, (size_t)anchors * pl.bins * sizeof(double)));
+    double* dense = (double*)dense_tmp.p;
     for (int col0 = 0; col0 < pl.bins; col0 += batch) {
         const int nb = std::min(batch, pl.bins - col0);
         hipLaunchKernelGGL(k_fir_unit_a, dim3(nb), dim3(1024), lds_scan, h->stream, pl, scratch, col0);
@@ -630,8 +640,7 @@ static int build_fir_factors(mgx_handle* h, const FirPlanView& pl, PlanDev& pd) 
     }
     HIP_TRY(hipGetLastError());
     MGX_TRY(pack_fir_factor(h, dense, anchors, pl.bins, pd.A));
-    // B: unit fits -> the smooth curve on the linear grid
-    HIP_TRY(hipMalloc((void**)&dense, (size_t)pl.bins * anchors * sizeof(double)));
+    // B: unit fits -> the smooth curve on the linear grid (the same bytes: bins x anchors)
     for (int col0 = 0; col0 < anchors; col0 += batch) {
         const int nb = std::min(batch, anchors - col0);
         hipLaunchKernelGGL(k_fir_unit_fit, dim3(nb), dim3(256), 0, h->stream, pl, scratch, col0);
@@ -641,7 +650,6 @@ static int build_fir_factors(mgx_handle* h, const FirPlanView& pl, PlanDev& pd) 
     }
     HIP_TRY(hipGetLastError());
     MGX_TRY(pack_fir_factor(h, dense, pl.bins, anchors, pd.B));
-    HIP_TRY(hipFree(scratch));
     return 0;
 }
 
@@ -657,7 +665,11 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
     const bool robust = cfg->lowess_it > 0;
     const char* env_old = std::getenv("MGX_FIR_ROUND4");
     const bool round4 = env_old && env_old[0] == '1';            // dense at 16384, the chain itself beyond
-    const bool factored = !robust && plan->bins() > 4097 && !round4;
+    // (the factors are found by pushing unit vectors through the chain into two DENSE anchors x bins matrices before they
+    // are packed: with lowess_delta = 0 every point of the log grid is an anchor -- 8.6 GB at fft_size 32768 -- so the
+    // factored form needs that intermediate to fit a budget; beyond it the chain runs on the curve itself, as in round 4)
+    const size_t dense_bytes = (size_t)plan->anchors() * (size_t)plan->bins() * sizeof(double);
+    const bool factored = !robust && plan->bins() > 4097 && !round4 && dense_bytes <= FIR_FACTOR_DENSE_BUDGET;
     const bool direct = robust || (!factored && plan->bins() > 8193);
     PlanDev pd;
     {
@@ -671,7 +683,15 @@ static int run_fir_design(mgx_handle* h, const mgx_config* cfg, const TrackWork&
             shared.plan = plan;
         }
         if (factored) {
-            if (!shared.B.packed) MGX_TRY(build_fir_factors(h, plan->view(shared.blob), shared));
+            if (!shared.A.packed || !shared.B.packed) {
+                // (a build that failed half-way leaves nothing behind: both factors or neither)
+                for (PlanDev::Factor* f : {&shared.A, &shared.B}) {
+                    if (f->rows) hipFree(f->rows);
+                    if (f->packed) hipFree(f->packed);
+                    *f = PlanDev::Factor();
+                }
+                MGX_TRY(build_fir_factors(h, plan->view(shared.blob), shared));
+            }
         } else if (!direct && !shared.M) {
             MGX_TRY(build_fir_operator(h, plan->view(shared.blob), &shared.M, &shared.band));
         }
@@ -981,12 +1001,14 @@ static int run_clipped_sumsq(mgx_handle* h, const float* mid, long long piece, i
 }
 
 // look-back words and control block of a limiter launch over n frames (allocated, not initialised)
-// blocks per limiter chunk: the rule of host_params.h, unless MGX_LIMIT_THREADS = 256 / 512 / 1024 asks otherwise
-// (measurement aid; read where the parameters are derived so that an A/B inside one process sees it)
+// blocks per limiter chunk: the rule of host_params.h, unless MGX_LIMIT_THREADS = 256 / 1024 asks otherwise (measurement
+// aid; read where the parameters are derived so that an A/B inside one process sees it).  Chunks of 512 blocks were
+// built and measured in round 6 for 96 kHz, where the halos eat a quarter of a 256-block chunk: 221 us against 204 (and
+// 306 for 1024 blocks), 84 B of scratch at the 128 registers two workgroups per CU leave -- profiles/r06_b_*; removed.
 static void limiter_threads_from_environment() {
     const char* e = std::getenv("MGX_LIMIT_THREADS");
     const int v = e ? std::atoi(e) : 0;
-    limiter_threads_wish() = (v == 256 || v == 512 || v == 1024) ? v : 0;
+    limiter_threads_wish() = (v == 256 || v == 1024) ? v : 0;
 }
 static int limiter_state(mgx_handle* h, long long n, const mgx_config* cfg, unsigned long long** published,
                          long long* words, int** ticket) {
@@ -1045,15 +1067,6 @@ static int launch_limiter(mgx_handle* h, const LimiterArgs& a, int threads) {
         const size_t lds = LimiterBlock<1024>::LDS_BYTES;
         MGX_TRY((allow_lds(k_limit<1024, 1>, lds)));
         hipLaunchKernelGGL((k_limit<1024, 1>), grid, dim3(1024), lds, h->stream, a);
-    } else if (threads == 512) {
-        const size_t lds = LimiterBlock<512>::LDS_BYTES;
-        if (a.hw == 96 && a.hb == 95 && a.gr == 55 && a.gl == 12 && a.gw == 6) {          // 96 kHz (BASELINE config #5)
-            MGX_TRY((allow_lds(k_limit<512, 2, 96, 95, 55>, lds)));
-            hipLaunchKernelGGL((k_limit<512, 2, 96, 95, 55>), grid, dim3(512), lds, h->stream, a);
-        } else {
-            MGX_TRY((allow_lds(k_limit<512, 2>, lds)));
-            hipLaunchKernelGGL((k_limit<512, 2>), grid, dim3(512), lds, h->stream, a);
-        }
     } else {
         launch_limiter_256(a, grid, h->stream);
     }
@@ -1954,20 +1967,14 @@ int mgx_last_fir(mgx_handle* h, void** taps_dev, int32_t* taps) {
 }
 
 // ---- RCCL ----------------------------------------------------------------------
-// The ranks of a job are the GPUs of ONE node (they meet over a local socket, matchering_amd/ranks.py), and the data
-// path between them is xGMI: the bootstrap needs no interface but loop-back and nothing has to look for InfiniBand.
-// So neither is left to RCCL's probing of a box without a network whose host name does not resolve: RCCL's first
-// initialisation in a process normally takes 2 - 5 s here either way (tools/rccl_init_time.py), but on one box of the
-// pool it took 457 s with RCCL's own defaults (profiles/r05_w_*; cause not established -- the box was gone with the
-// call).  Only set where the host has not chosen itself.
-static void single_node_rccl_defaults() {
-    setenv("NCCL_SOCKET_IFNAME", "lo", 0);
-    setenv("NCCL_IB_DISABLE", "1", 0);
-}
+// The ranks of a job are the GPUs of ONE node, the data path between them is xGMI and the bootstrap needs nothing but
+// loop-back -- but telling RCCL so (NCCL_SOCKET_IFNAME=lo, NCCL_IB_DISABLE=1) changes the environment of the HOST
+// process, which is the host's decision and not thread-safe against the getenv calls of a running library: the Python
+// front end does it where a job sets itself up (matchering_amd/ranks.py single_node_rccl_defaults), a C / C++ host sets
+// the two variables itself before its first mgx_comm_* call.  Nothing here calls setenv.
 int mgx_comm_unique_id(void* id128) {
     if (!id128) return fail(MGX_ERR_ARGUMENT, "null argument");
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
-    single_node_rccl_defaults();
     ncclUniqueId id;
     NCCL_TRY(ncclGetUniqueId(&id));
     std::memcpy(id128, &id, sizeof(id));
@@ -1976,7 +1983,6 @@ int mgx_comm_unique_id(void* id128) {
 int mgx_comm_init(mgx_handle* h, const void* id128, int rank, int world) {
     if (!h || !id128) return fail(MGX_ERR_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(h->device));
-    single_node_rccl_defaults();
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof(id));
     NCCL_TRY(ncclCommInitRank(&h->comm, world, id, rank));

@@ -2953,7 +2953,7 @@ __global__ __launch_bounds__(256, 2) void k_limit_general(LimiterArgs a, General
 // instantiation (-1) otherwise; the results are the same to the bit.
 template <int T, int WGS, int HW = -1, int HB = -1, int GR = -1>
 __global__ __launch_bounds__(T, WGS * T / 256) void k_limit(LimiterArgs a0) {
-    warm_code(CODE_LIMIT, T == 256 ? 0 : T == 1024 ? 1 : 2);
+    warm_code(CODE_LIMIT, T == 256 ? 0 : 1);
     using LB = LimiterBlock<T>;
     LimiterArgs a = a0;
     if (HW >= 0) {

@@ -155,3 +155,17 @@ def test_the_hot_kernels_do_not_spill():
     assert scratch("k_limitILi256ELi4ELi48ELi47E") == 0         # 48 kHz
     assert scratch("k_limitILi256ELi4ELi96ELi95E") <= 16        # 96 kHz (config #5)
     assert scratch("k_correction_tail") == 0
+    # The kernels OFF the BASELINE workloads that do spill, each with the ceiling it has today (VERDICT round 5, next #8:
+    # they must not grow silently).  k_conv<14,*>: 8192 taps on 16384-point blocks / the partitioned 32 k and 64 k tap
+    # paths (an accumulator row beside the transform); k_analyze_double / _quad: fft_size 32768 / 65536 (two and four
+    # transforms' accumulators per thread); k_analyze<10>: the 1024-point radix-32 x 32 plan on 64 threads (a row of 32
+    # points, its mirror and 34 accumulators per thread exceed 256 registers); k_limit<1024,1>: attack / hold times whose
+    # halos need 1024-block chunks (sixteen waves' scan totals).  Everything else holds its working set in registers.
+    ceilings = {"6k_convILi14ELb0E": 72, "6k_convILi14ELb1E": 240, "16k_analyze_doubleILi14E": 340, "14k_analyze_quadILi14E": 128,
+                "9k_analyzeILi10E": 64, "7k_limitILi1024ELi1E": 468, "12k_conv_delayILi14E": 64}
+    for name, entry in table.items():
+        if entry["scratch"] == 0:
+            continue
+        hit = [limit for fragment, limit in ceilings.items() if fragment in name]
+        assert hit, f"{name} spills {entry['scratch']} B per lane and has no ceiling in this test"
+        assert entry["scratch"] <= hit[0], (name, entry["scratch"], hit[0])

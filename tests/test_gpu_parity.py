@@ -310,6 +310,24 @@ def test_factored_fir_operator_equals_the_round_4_paths(fft, monkeypatch):
         assert np.abs(a - b).max() <= 2e-6
 
 
+def test_lowess_delta_zero_does_not_build_a_dense_factor():
+    """with lowess_delta = 0 every point of the log grid is a LOWESS anchor, and the factored operator's dense
+    intermediate (anchors x bins doubles) would be 2.1 GB at fft_size 16384 and 8.6 GB at 32768.  Above a 1 GiB budget the
+    plan takes round 4's paths (the dense operator at 16384), and the FIR still equals the oracle's."""
+    import matchering_amd as mg
+    from matchering_amd.synth import make_pair
+
+    sr = 96000
+    t, r = make_pair(3.0, sr, pair=4, reference_seconds=2.6)
+    kw = dict(internal_sample_rate=sr, fft_size=16384, max_piece_size=1.1, lowess_delta=0.0)
+    res, fir = _master_with_taps(t, r, mg.Config(**kw))
+    tr = {}
+    want = mo.master(t, r, mo.params(**kw), True, True, True, trace=tr)
+    ref = np.stack([tr["fir_mid"], tr["fir_side"]])
+    assert np.abs(fir - ref).max() <= 2e-6 * np.abs(ref).max()
+    assert rms_error(res[0], want[0]) <= RMS_TOL
+
+
 def test_convolution_identity_and_linearity():
     from matchering_amd import kernels
 

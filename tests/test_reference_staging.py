@@ -24,6 +24,8 @@ import build_ref  # noqa: E402
 def test_the_staging_directory_stays_out_of_the_history():
     with open(os.path.join(ROOT, ".gitignore")) as fh:
         assert "oracle/_ref/" in fh.read().split()
+    with open(os.path.join(ROOT, "bench.py")) as fh:        # ... and bench.py times it only where the reference tree is
+        assert "if not build_ref.reference_present():" in fh.read()
     tracked = subprocess.run(["git", "ls-files", "oracle/_ref"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
     assert tracked == ""
     with open(os.path.join(ROOT, ".gpurunignore")) as fh:  # ... and out of the snapshot that goes to the GPU box
