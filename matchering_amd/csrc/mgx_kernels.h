@@ -604,6 +604,15 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
     __syncthreads();
     int s0, s1;
     AB::chunk_segments(a, ch, s0, s1);
+#ifdef MGX_ANALYZE_NOT_AHEAD                 // A/B build: every segment's frames asked for at its top, as until round 6
+    constexpr bool AHEAD = false;
+#elif defined(MGX_ANALYZE_AHEAD_ALL)        // experiment: the smaller transforms too
+    constexpr bool AHEAD = LOG2N >= 11;
+#else
+    constexpr bool AHEAD = LOG2N == 14;
+#endif
+    typename AB::Raw raw;
+    if (AHEAD) AB::fetch(tid, (long long)d * a.piece + (long long)s0 * F::N, a, raw);
     for (int s = s0; s < s1; ++s) {
         // (A software prefetch of the next segment, round 4: asked for after pass 0, after the middle pass or after
         // the row pass, with the thread id opaque per iteration so that nothing is hoisted -- at 128 VGPRs every
@@ -613,13 +622,22 @@ __global__ __launch_bounds__(Fft2<LOG2N>::T, analysis_waves_per_simd<LOG2N>()) v
         // workgroup it costs.  profiles/r04_b_ab_variants.txt.  Round 5: one word of each 128-byte line of the next
         // segment asked for behind this segment's loads (one register, no scratch at 16384 points) so that the L2
         // holds it -- 149 -> 173 us at 16384 points, 88 -> 126 us at 4096: profiles/r05_p_analysis_touch_next_segment.txt)
-        typename AB::Raw raw;
-        AB::fetch(tid, (long long)d * a.piece + (long long)s * F::N, a, raw);
+        // (Round 6, 16384 points only -- one workgroup per CU, nobody else to cover a segment's load latency: the next
+        // segment's frames are asked for behind the row pass, so that they travel under the magnitudes phase; the registers
+        // they wait in are live across that phase only: k_analyze<14> 149.6 -> 130.2 us, profiles/r06_f_*.  One `raw`, no branches around it -- the form k_conv_wide
+        // prefetches in: behind the last segment of the chunk the loads run into the next chunk's frames, or past the
+        // track where the buffer's range check answers zeros, and are dropped.)
+        if (!AHEAD) AB::fetch(tid, (long long)d * a.piece + (long long)s * F::N, a, raw);
         AB::phase_load(tid, raw, ps, th, lds);
         lds_barrier();
         fwd_middle_passes<F>(tid, lds, mid_table);
         typename AB::Row own;
         AB::phase_row(tid, own, lds);
+        if (AHEAD) {
+            __builtin_amdgcn_sched_barrier(0);          // (not above the row pass: its butterflies need the registers)
+            AB::fetch(mgx_opaque(tid), (long long)d * a.piece + (long long)(s + 1) * F::N, a, raw);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         lds_barrier();
         AB::phase_magnitudes(tid, own, th, lds);
         lds_barrier();
