@@ -1984,42 +1984,57 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
             // the float64 sums -- and the band samples are compacted per THREAD: each thread counts its
             // own, one prefix sum over the wave places them, no ballot and no scalar chain per sample.
             // (A frame past the end loads as 0: clips to 0, counts as never clipped, adds nothing.)
-            for (long long s0 = head; s0 < body_end; s0 += 4 * 1024) {
-                float x[16];
+            // MGX_ROUND0_GROUPS x four 16-byte loads per thread in flight, each group of sixteen samples then summed and
+            // compacted in order (bit-identical whatever the number).  One group is the product: two and three were
+            // measured in round 6 -- the whole stage 52.1 -> 54.2 / 54.3 us -- as were more, shorter workgroups (51.5 ->
+            // 56.1 at twice as many): this kernel is not short of loads in flight (profiles/r06_b_*, r06_g_*).
+#ifndef MGX_ROUND0_GROUPS
+#define MGX_ROUND0_GROUPS 1
+#endif
+            constexpr int GROUPS = MGX_ROUND0_GROUPS;
+            for (long long s0 = head; s0 < body_end; s0 += GROUPS * 4 * 1024) {
+                float xs[GROUPS][16];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const long long i = s0 + u * 1024 + 4ll * threadIdx.x;
-                    const float4 q = i < body_end ? *reinterpret_cast<const float4*>(a.mid + i) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    x[4 * u] = q.x; x[4 * u + 1] = q.y; x[4 * u + 2] = q.z; x[4 * u + 3] = q.w;
-                }
-                float sq = 0.f, lo = 0.f;
-                int mine = 0;
-                unsigned bits = 0;
+                for (int gq = 0; gq < GROUPS; ++gq) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float c = __builtin_amdgcn_fmed3f(x[i], -1.0f, 1.0f);
-                    sq = fmaf(c, c, sq);
-                    const float m = fabsf(x[i]);
-                    const bool never = m <= t_never, always = m >= t_always;
-                    lo = fmaf(never ? x[i] : 0.f, x[i], lo);
-                    clipped_mine += always ? 1 : 0;
-                    const bool in_band = !never && !always;
-                    mine += in_band ? 1 : 0;
-                    bits |= (in_band ? 1u : 0u) << i;
+                    for (int u = 0; u < 4; ++u) {
+                        const long long i = s0 + (gq * 4 + u) * 1024 + 4ll * threadIdx.x;
+                        const float4 q = i < body_end ? *reinterpret_cast<const float4*>(a.mid + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        xs[gq][4 * u] = q.x; xs[gq][4 * u + 1] = q.y; xs[gq][4 * u + 2] = q.z; xs[gq][4 * u + 3] = q.w;
+                    }
                 }
-                acc += (double)sq;
-                low += (double)lo;
-                const int through = wave_inclusive_sum(mine);
-                int slot = filled + through - mine;
-                if (bits) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (bits & (1u << i)) {
-                            if (slot < bc.wave_cap) wave_band[slot] = x[i];
-                            ++slot;
-                        }
+                for (int gq = 0; gq < GROUPS; ++gq) {
+                    const float (&x)[16] = xs[gq];
+                    float sq = 0.f, lo = 0.f;
+                    int mine = 0;
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float c = __builtin_amdgcn_fmed3f(x[i], -1.0f, 1.0f);
+                        sq = fmaf(c, c, sq);
+                        const float m = fabsf(x[i]);
+                        const bool never = m <= t_never, always = m >= t_always;
+                        lo = fmaf(never ? x[i] : 0.f, x[i], lo);
+                        clipped_mine += always ? 1 : 0;
+                        const bool in_band = !never && !always;
+                        mine += in_band ? 1 : 0;
+                        bits |= (in_band ? 1u : 0u) << i;
+                    }
+                    acc += (double)sq;
+                    low += (double)lo;
+                    const int through = wave_inclusive_sum(mine);
+                    int slot = filled + through - mine;
+                    if (bits) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i)
+                            if (bits & (1u << i)) {
+                                if (slot < bc.wave_cap) wave_band[slot] = x[i];
+                                ++slot;
+                            }
+                    }
+                    filled += __builtin_amdgcn_readlane(through, 63);
                 }
-                filled += __builtin_amdgcn_readlane(through, 63);
             }
         } else
         for (long long s0 = head; s0 < body_end; s0 += 4 * 1024) {
