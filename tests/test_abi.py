@@ -149,7 +149,8 @@ def test_the_hot_kernels_do_not_spill():
     assert scratch("k_conv_delayILi14E") <= 64                  # config #5: 16384 taps (a dozen dwords around the store phase)
     assert scratch("11k_conv_wideILi14E") == 0                  # the headline workload: 4096 taps on 16384-point blocks
     assert scratch("6k_convILi13ELb0E") == 0                    # ... and on 8192-point blocks (MGX_NO_CONV_WIDE=1)
-    assert scratch("k_analyzeILi12E") == 0 and scratch("k_analyzeILi14E") == 0
+    assert scratch("k_analyzeILi12E") == 0
+    assert scratch("k_analyzeILi14E") <= 16                     # config #5: four dwords around the frames asked for a segment ahead
     assert scratch("k_limitILi256ELi4ELin1E") <= 16             # the general instantiation (two spilled scalars of the look-back)
     assert scratch("k_limitILi256ELi4ELi44ELi43E") == 0         # the headline workload's: 44.1 kHz, 1 ms attack and hold
     assert scratch("k_limitILi256ELi4ELi48ELi47E") == 0         # 48 kHz
@@ -162,7 +163,7 @@ def test_the_hot_kernels_do_not_spill():
     # points, its mirror and 34 accumulators per thread exceed 256 registers); k_limit<1024,1>: attack / hold times whose
     # halos need 1024-block chunks (sixteen waves' scan totals).  Everything else holds its working set in registers.
     ceilings = {"6k_convILi14ELb0E": 72, "6k_convILi14ELb1E": 240, "16k_analyze_doubleILi14E": 340, "14k_analyze_quadILi14E": 128,
-                "9k_analyzeILi10E": 64, "7k_limitILi1024ELi1E": 468, "12k_conv_delayILi14E": 64}
+                "9k_analyzeILi10E": 64, "7k_limitILi1024ELi1E": 468, "12k_conv_delayILi14E": 64, "9k_analyzeILi14E": 16}
     for name, entry in table.items():
         if entry["scratch"] == 0:
             continue
