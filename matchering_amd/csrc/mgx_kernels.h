@@ -497,6 +497,7 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         DEV_CONV_MARK(1);                   // middle passes
         typename CW::Filters filt;
         CW::fetch_filters(opaque(tid), a, filt);          // needed behind the next barrier
+#ifdef MGX_CONV_WIDE_ROW_IN_LDS                           // A/B build: the whole row through the LDS, as until round 6
         CW::phase_row(opaque(tid), lds);
         lds_barrier();
         DEV_CONV_MARK(2);                   // row forward, barrier
@@ -505,6 +506,17 @@ __global__ __launch_bounds__((Fft2<LOG2N>::T), (conv_waves_per_simd<LOG2N>())) v
         __builtin_amdgcn_sched_barrier(0);
         DEV_CONV_MARK(3);                   // multiply, barrier
         CW::phase_row_back(opaque(tid), lds);
+#else
+        typename CW::Kept kept;                           // the own half of the row stays in registers (conv_wide_kernel.h)
+        CW::phase_row_keep(opaque(tid), kept, lds);
+        lds_barrier();
+        DEV_CONV_MARK(2);                   // row forward, barrier
+        CW::phase_multiply_keep(opaque(tid), filt, kept, lds);
+        lds_barrier();                    // the partner has written this row's upper half
+        __builtin_amdgcn_sched_barrier(0);
+        DEV_CONV_MARK(3);                   // multiply, barrier
+        CW::phase_row_back_keep(opaque(tid), kept, lds);
+#endif
         inv_middle_passes<F>(opaque(tid), lds, mid_table);
         // the next block's window: its latency under the last inverse pass and the stores -- the barriers from here
         // to the top of the loop order LDS traffic only (a __syncthreads() would wait for these loads)
