@@ -2035,9 +2035,15 @@ __global__ __launch_bounds__(256) void k_correction_round(RoundArgs a) {
                     }
                     acc += (double)sq;
                     low += (double)lo;
+#ifdef MGX_DEV_ROUND0_SUMS_ONLY         // development builds only: what round 0 costs without its band lists (results are wrong)
+                    const int through = mine;
+                    int slot = filled;
+                    if (false) {
+#else
                     const int through = wave_inclusive_sum(mine);
                     int slot = filled + through - mine;
                     if (bits) {
+#endif
 #pragma unroll
                         for (int i = 0; i < 16; ++i)
                             if (bits & (1u << i)) {

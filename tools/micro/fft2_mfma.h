@@ -1,11 +1,14 @@
-// Radix-8 butterflies of Fft2's middle passes on the matrix pipe (gfx950, v_mfma_f32_16x16x4_f32).
+// Radix-8 butterflies of Fft2's middle passes on the matrix pipe (gfx950, v_mfma_f32_16x16x4_f32) -- an EXPERIMENT of
+// round 6, kept beside its micro-benchmark as the record; the product does not use it.
 //
-// Why: the 16384-point kernels are bound by VALU issue while the matrix pipe of every SIMD idles.
-// gfx950 has an exact float32 MFMA (f32 in, f32 accumulate, bitwise an fmaf chain) that runs at twice the rate of scalar
-// f32 VALU instructions, on a pipe of its own.  A radix-8 butterfly as a dense 16 x 16 real matrix costs 4.6 times the
-// flops of the butterfly network -- 512 matrix-pipe cycles per 64 butterflies where the network costs ~110 VALU
-// instructions = 440 issue cycles -- so it does not pay INSTEAD of the VALU butterflies, only BESIDE them: a wave hands
-// a share of a pass's butterflies to the matrix pipe and keeps the rest, and the two streams run concurrently.
+// The question: gfx950 has an exact float32 MFMA (f32 in, f32 accumulate, bitwise an fmaf chain) at twice the rate of
+// scalar f32 VALU instructions.  A radix-8 butterfly as a dense 16 x 16 real matrix costs 4.6 times the flops of the
+// butterfly network -- 512 matrix-pipe cycles per 64 butterflies where the network costs ~85 VALU instructions -- so it
+// could only pay BESIDE the VALU butterflies: a wave hands a share of a pass's butterflies to the matrix pipe and keeps
+// the rest, if the two streams ran concurrently.
+// The answer (tools/micro/mfma_pass.hip, profiles/r06_a_*): they do not.  A SIMD that executes a
+// v_mfma_f32_16x16x4_f32 issues no VALU instruction meanwhile; eight VALU waves beside eight matrix waves take the sum
+// of their times.  The code below is correct (1.6e-7 against the VALU passes) and slower in every mix.
 //
 // One tile = 16 butterflies (the 16 columns of the MFMA).  Lane l = 16 g + n (g = 0..3) of the wave:
 //   * loads points g and g + 4 of butterfly n (two ds_read_b64): x.re / x.im of point g + 4h are the B operands of
@@ -21,7 +24,7 @@
 // fft2.h's; a pass may be split between fwd_mid_pass-style VALU butterflies and these tiles in any proportion.
 #pragma once
 
-#include "fft2.h"
+#include "fft2.h"          // (matchering_amd/csrc, on the include path of the micro-benchmark)
 
 #if defined(__HIPCC__) && !defined(MGX_HOST_EMU)
 

@@ -12,7 +12,7 @@
 //  13  VALU butterflies, the two passes of a direction fused: the exchange between them through v_permlane*_swap
 // Prints us per iteration and block, the shader clock during the run (s_memtime against the 100 MHz counter), and the
 // deviation of the result from the input after the identity (and between modes).
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I matchering_amd/csrc -o tools/micro/mfma_pass tools/micro/mfma_pass.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -I matchering_amd/csrc -I tools/micro -o tools/micro/mfma_pass tools/micro/mfma_pass.hip
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
