@@ -26,6 +26,7 @@ SHAPES = [(7.3, 44100, 4096), (31.0, 44100, 4096), (3.1, 96000, 16384), (12.0, 4
 # (k_limit_general), long attack / hold times (1024-block chunks)
 VARIANTS = [dict(), dict(), dict(lowess_it=2),
             dict(limiter=dict(hold_filter_order=2, release_filter_order=2)),
+            dict(limiter=dict(hold_filter_order=3)),
             dict(limiter=dict(attack=8.0, hold=2.0))]
 
 
